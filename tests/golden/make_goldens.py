@@ -1,0 +1,424 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures in this directory by RUNNING THE REFERENCE.
+
+Run in the build container only (needs /root/reference):
+
+    cd /root/repo && python tests/golden/make_goldens.py
+
+The reference's Python is imported from /root/reference (never copied); two
+import-time shims stand in for packages the image lacks:
+  * `pytorch_lightning` -> LightningModule = nn.Module + save_hyperparameters /
+    log_dict / hparams (the training loop itself carries no arithmetic);
+  * `librosa`           -> empty module (only `src.utils` imports it at module
+    level; no librosa arithmetic is exercised, log-mel stays "parity unpinned").
+Inputs and weights come from `oracle.fill` (integer-exact closed forms), so the
+fixtures hold only small outputs.  Dropout masks are made explicit by swapping
+the reference *instance's* `nn.Dropout` for a fixed-mask module (the reference's
+own mask comes from torch's CPU generator, which no GPU can reproduce).
+"""
+import importlib
+import importlib.util
+import inspect
+import os
+import random
+import sys
+import types
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(os.path.dirname(HERE))
+REF = "/root/reference"
+sys.path.insert(0, REPO)
+
+from oracle import fill  # noqa: E402
+
+
+# ----------------------------------------------------------------------- shims
+def _install_shims():
+    pl = types.ModuleType("pytorch_lightning")
+
+    class _HP(dict):
+        __getattr__ = dict.__getitem__
+
+    class LightningModule(nn.Module):
+        def save_hyperparameters(self):
+            frame = inspect.currentframe().f_back
+            sig = inspect.signature(type(self).__init__)
+            loc = frame.f_locals
+            self.hparams = _HP({k: loc[k] for k in sig.parameters
+                                if k in loc and k not in ("self", "args", "kwargs")})
+
+        def log_dict(self, *a, **k):
+            pass
+
+    class LightningDataModule:
+        def __init__(self, *a, **k):
+            pass
+
+    pl.LightningModule = LightningModule
+    pl.LightningDataModule = LightningDataModule
+    pl.Trainer = object
+    cb = types.ModuleType("pytorch_lightning.callbacks")
+    cb.ModelCheckpoint = object
+    pl.callbacks = cb
+    sys.modules["pytorch_lightning"] = pl
+    sys.modules["pytorch_lightning.callbacks"] = cb
+    sys.modules["librosa"] = types.ModuleType("librosa")
+
+
+def _load_by_path(name, path):
+    spec = importlib.util.spec_from_file_location(name, path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+class FixedMaskDropout(nn.Module):
+    """Pops one explicit keep-mask per call: y = x * mask / (1 - p)."""
+
+    def __init__(self, p=0.3):
+        super().__init__()
+        self.p = p
+        self.masks = []
+
+    def forward(self, x):
+        if not self.masks:
+            return x
+        m = self.masks.pop(0)
+        return x * m.to(x.dtype) / (1.0 - self.p)
+
+
+def drop_mask(shape, salt, p=0.3):
+    return torch.from_numpy((fill.uniform01(shape, salt) >= p).astype(np.float32))
+
+
+def views(B, T, salt):
+    return torch.from_numpy(fill.normalish((B, 1, 64, T), salt))
+
+
+CFG_S = {"pretrain": {"base_encoder": {"type": "AudioNTT2020Task6", "output_dim": 2048, "return_all_layers": False},
+                      "projection_dim": 2048, "normalization": "mean_var", "lambda_barlow": 5e-5,
+                      "input": {"type": "raw_wav", "sampling_rate": 16000, "length_wave": 1.0, "n_mels": 64},
+                      "augmentations": {"MixupBYOLA": {"ratio": 0.4, "log_mixup_exp": True},
+                                        "RandomResizeCrop": {"virtual_crop_scale": [1.0, 1.5],
+                                                             "freq_crop_scale": [0.6, 1.5],
+                                                             "time_crop_scale": [0.6, 1.5]}}}}
+CFG_M = {"pretrain": dict(CFG_S["pretrain"], contrastive_dim=128, lambda_barlow=[5e-5, 5e-5, 5e-5], loss_scale="1/32",
+                          base_encoder={"type": "AudioNTT2020Task6", "output_dim": 2048, "return_all_layers": True})}
+
+
+def save(name, **arrays):
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **{k: np.asarray(v) for k, v in arrays.items()})
+    print(f"{name}.npz  {os.path.getsize(path) / 1024:.1f} KiB")
+
+
+def t2n(t):
+    return t.detach().cpu().numpy()
+
+
+def grad_digest(module):
+    """name -> (l2 norm, first 8 flat values) for every parameter gradient."""
+    names, norms, heads = [], [], []
+    for n, p in module.named_parameters():
+        if p.grad is None:
+            continue
+        names.append(n)
+        norms.append(float(p.grad.norm()))
+        h = p.grad.flatten()[:8]
+        heads.append(np.pad(t2n(h), (0, 8 - h.numel())))
+    return dict(names=np.array(names), norms=np.array(norms, np.float64), heads=np.stack(heads))
+
+
+# ------------------------------------------------------------------ generators
+def g1_window(U):
+    rows = []
+    for seed in (0, 1, 2):
+        for n in (100, 16000, 20000, 48000):
+            random.seed(seed)
+            wav = torch.arange(n, dtype=torch.float32)
+            out = U.extract_window(wav, data_size=1.0)
+            nz = torch.nonzero(out)
+            first = float(out[0])
+            # start index recoverable from the ramp; left pad from first non-zero
+            rows.append((seed, n, first, int(nz[0]) if len(nz) else -1, float(out[-1]), random.random()))
+    save("window", rows=np.array(rows, np.float64))
+
+
+def g2_runnorm(A):
+    rn = A.RunningNorm(epoch_samples=2 * 3)      # freezes after 60 updates
+    mus, sds, outs = [], [], []
+    for c in range(64):
+        x = torch.from_numpy(fill.normalish((1, 64, 101), 500 + c) * (2.0 + 0.1 * c) - 8.0 + 0.05 * c)
+        y = rn(x)
+        mus.append(float(rn.mean))
+        sds.append(float(rn.std))
+        if c in (0, 1, 2, 7, 59, 60, 63):
+            outs.append(t2n(y)[0, ::8, ::10])
+    save("runnorm", mu=np.array(mus, np.float64), sd=np.array(sds, np.float64), outs=np.stack(outs))
+
+
+def g3_aug(A_pkg):
+    for T in (101, 96):
+        np.random.seed(31)
+        random.seed(31)
+        tf = A_pkg.AugmentationModule(CFG_S, 100)
+        mix, rrc = tf.train_transform[0], tf.train_transform[1]
+        # instrument draws without touching the source: wrap get_params
+        trace = []
+        orig = type(rrc).get_params
+
+        def spy(*a, **k):
+            r = orig(*a, **k)
+            trace.append(tuple(int(v) for v in r))
+            return r
+        rrc.get_params = spy
+        v1s, v2s = [], []
+        n_clips = 20
+        for c in range(n_clips):
+            x = torch.from_numpy(fill.normalish((1, 64, T), 1000 + c) * 3.0 - 8.0)
+            v1, v2 = tf(x)
+            v1s.append(t2n(v1)[0])
+            v2s.append(t2n(v2)[0])
+        keep = [0, 1, 2, 7, 13, 19]
+        digest = np.array([[v.sum(dtype=np.float64), np.abs(v).sum(dtype=np.float64)] for v in v1s + v2s])
+        save(f"aug_T{T}", ijhw=np.array(trace, np.int32), keep=np.array(keep),
+             v1=np.stack([v1s[c] for c in keep]), v2=np.stack([v2s[c] for c in keep]), digest=digest,
+             np_state_after=np.random.random(), py_state_after=random.random())
+
+
+def g3b_bank_wrap(A):
+    """FIFO wrap-around: 2048-deep bank receives each clip twice."""
+    np.random.seed(5)
+    mix = A.MixupBYOLA(ratio=0.4, n_memory=8, log_mixup_exp=True)   # tiny bank, same code path
+    outs = []
+    for c in range(12):
+        x = torch.from_numpy(fill.normalish((1, 8, 6), 2000 + c))
+        outs.append(t2n(mix(x)))
+        outs.append(t2n(mix(x)))
+    save("mixup_wrap", outs=np.stack(outs))
+
+
+def g4_specaug(S):
+    recs, outs = [], []
+    for seed in range(8):
+        random.seed(1234 + seed)
+        x = torch.from_numpy(fill.normalish((101, 64), 3000 + seed))
+        y = S.freq_mask(x, F=30, num_masks=2)
+        y = S.time_mask(y, T=40, num_masks=2)
+        outs.append(t2n(y))
+        recs.append(random.random())
+        random.seed(1234 + seed)
+        z = S.time_mask(S.freq_mask(x, F=30, num_masks=2, replace_with_zero=True), T=40, num_masks=2,
+                        replace_with_zero=True)
+        outs.append(t2n(z))
+    save("specaug", outs=np.stack(outs), py_state_after=np.array(recs))
+
+
+def g5_encoder(ENC):
+    for T in (101, 96):
+        enc = ENC.AudioNTT2020Task6(64, 2048, True)
+        fill.fill_state_dict_(enc, seed=1)
+        fmd = FixedMaskDropout(0.3)
+        enc.fc[2] = fmd
+        x = views(2, T, 4000 + T)
+        Tp = T // 8
+        out = {}
+        # eval mode (running stats, no dropout)
+        enc.eval()
+        with torch.no_grad():
+            e1, e2, e3, e = enc(x)
+        out.update(eval_x1=t2n(e1), eval_x2=t2n(e2), eval_x3=t2n(e3), eval_x=t2n(e))
+        # train mode with explicit dropout mask
+        enc.train()
+        fmd.masks = [drop_mask((2, Tp, 2048), 4100 + T)]
+        a1, a2, a3, a = enc(x)
+        out.update(x1=t2n(a1), x2=t2n(a2), x3=t2n(a3), x=t2n(a))
+        r = [torch.from_numpy(fill.uniform(tuple(v.shape), 4200 + i)) for i, v in enumerate((a1, a2, a3, a))]
+        loss = sum((v * w).sum() for v, w in zip((a1, a2, a3, a), r))
+        loss.backward()
+        out.update(loss=float(loss))
+        gd = grad_digest(enc)
+        out.update(g_names=gd["names"], g_norms=gd["norms"], g_heads=gd["heads"])
+        out.update(bn1_rm=t2n(enc.features_1[1].running_mean), bn1_rv=t2n(enc.features_1[1].running_var),
+                   bn3_rm=t2n(enc.features_3[1].running_mean), bn3_rv=t2n(enc.features_3[1].running_var))
+        save(f"encoder_T{T}", **out)
+
+
+def g6_barlow(XS):
+    out = {}
+    for in_dim in (2048, 1024, 512):
+        p = XS.Projection(in_dim, 5e-5)
+        fill.fill_state_dict_(p, seed=in_dim)
+        p.train()
+        B = 8
+        y1 = torch.from_numpy(fill.uniform((B, in_dim), 5000 + in_dim, 0.0, 2.0)).requires_grad_()
+        y2 = torch.from_numpy(fill.uniform((B, in_dim), 5001 + in_dim, 0.0, 2.0)).requires_grad_()
+        loss = p(y1, y2)
+        loss.backward()
+        gd = grad_digest(p)
+        out[f"loss_{in_dim}"] = float(loss)
+        out[f"dy1_{in_dim}"] = t2n(y1.grad)
+        out[f"dy2_{in_dim}"] = t2n(y2.grad)
+        out[f"gn_{in_dim}"] = gd["norms"]
+        out[f"gh_{in_dim}"] = gd["heads"]
+        out[f"names_{in_dim}"] = gd["names"]
+        out[f"bn_rm_{in_dim}"] = t2n(p.bn.running_mean)[:64]
+        out[f"bn_rv_{in_dim}"] = t2n(p.bn.running_var)[:64]
+    save("barlow", **out)
+
+
+class _Trainer:
+    use_ddp = False
+    use_ddp2 = False
+
+    class datamodule:
+        name = "none"
+
+
+def _closed_queue(emb_dim, K):
+    q = torch.from_numpy(fill.normalish((emb_dim, K), 777))
+    return nn.functional.normalize(q, dim=0)
+
+
+def g7_g9_steps(XS, XM, ENC):
+    # ---- delores_s: 3 SGD steps, B=8
+    B, T, Tp = 8, 101, 12
+    torch.manual_seed(0)
+    ex = XS.Upstream_Expert(CFG_S, base_encoder=ENC.AudioNTT2020Task6)
+    fill.fill_state_dict_(ex, seed=2)
+    ex.trainer = _Trainer()
+    fmd = FixedMaskDropout(0.3)
+    ex.encoder.encoder.fc[2] = fmd
+    ex.train()
+    opt = ex.configure_optimizers()
+    losses = []
+    for s in range(3):
+        fmd.masks = [drop_mask((B, Tp, 2048), 6100 + 2 * s), drop_mask((B, Tp, 2048), 6101 + 2 * s)]
+        opt.zero_grad()
+        loss = ex.training_step((views(B, T, 6000 + 2 * s), views(B, T, 6001 + 2 * s)), s)
+        loss.backward()
+        if s == 0:
+            gd0 = grad_digest(ex)
+        opt.step()
+        losses.append(float(loss))
+    sd = ex.state_dict()
+    save("step_delores_s", losses=np.array(losses, np.float64), g_names=gd0["names"], g_norms=gd0["norms"],
+         g_heads=gd0["heads"],
+         w_conv1=t2n(sd["encoder.encoder.features_1.0.weight"]).ravel(),
+         w_fc2_head=t2n(sd["encoder.encoder.fc.3.weight"]).ravel()[:256],
+         w_p0_head=t2n(sd["p.projector.0.weight"]).ravel()[:256],
+         bn_rm=t2n(sd["p.bn.running_mean"])[:64])
+
+    # ---- delores_m: 3 SGD steps, B=8, queue 1024
+    torch.manual_seed(0)
+    K = 1024
+    em = XM.Upstream_Expert(CFG_M, base_encoder=ENC.AudioNTT2020Task6, num_negatives=K)
+    fill.fill_state_dict_(em, seed=3)
+    for pq, pk in zip(em.encoder_q.parameters(), em.encoder_k.parameters()):
+        pk.data.copy_(pq.data)
+    em.queue.copy_(_closed_queue(128, K))
+    em.trainer = _Trainer()
+    fq, fk = FixedMaskDropout(0.3), FixedMaskDropout(0.3)
+    em.encoder_q.encoder.fc[2] = fq
+    em.encoder_k.encoder.fc[2] = fk
+    em.train()
+    opt = em.configure_optimizers()
+    losses, ptrs = [], []
+    logits0 = None
+    for s in range(3):
+        fq.masks = [drop_mask((B, Tp, 2048), 7100 + 2 * s)]
+        fk.masks = [drop_mask((B, Tp, 2048), 7101 + 2 * s)]
+        a, b = views(B, T, 7000 + 2 * s), views(B, T, 7001 + 2 * s)
+        opt.zero_grad()
+        if s == 0:
+            # same call the training_step makes, captured for the MoCo-head fixture
+            hook = {}
+            orig_ce = torch.nn.functional.cross_entropy
+
+            def spy_ce(inp, tgt, *aa, **kk):
+                hook["logits"] = inp.detach().clone()
+                return orig_ce(inp, tgt, *aa, **kk)
+            XM.F.cross_entropy = spy_ce
+            loss = em.training_step((a, b), s)
+            XM.F.cross_entropy = orig_ce
+            logits0 = hook["logits"]
+        else:
+            loss = em.training_step((a, b), s)
+        loss.backward()
+        if s == 0:
+            gd0 = grad_digest(em)
+        opt.step()
+        losses.append(float(loss))
+        ptrs.append(int(em.queue_ptr))
+    sd = em.state_dict()
+    save("step_delores_m", losses=np.array(losses, np.float64), ptrs=np.array(ptrs), g_names=gd0["names"],
+         g_norms=gd0["norms"], g_heads=gd0["heads"], logits_row0=t2n(logits0[0]),
+         ce0=float(torch.nn.functional.cross_entropy(logits0, torch.zeros(B, dtype=torch.long))),
+         queue_cols=t2n(sd["queue"][:, :24]),
+         wq_conv1=t2n(sd["encoder_q.encoder.features_1.0.weight"]).ravel(),
+         wk_conv1=t2n(sd["encoder_k.encoder.features_1.0.weight"]).ravel(),
+         wk_fc=t2n(sd["encoder_k.fc.weight"]).ravel()[:256])
+
+
+def g8_contrastive(CL):
+    out = {}
+    for B, tau in ((8, 0.5), (16, 0.07)):
+        zi = nn.functional.normalize(torch.from_numpy(fill.normalish((B, 128), 8000 + B)), dim=1).requires_grad_()
+        zj = nn.functional.normalize(torch.from_numpy(fill.normalish((B, 128), 8001 + B)), dim=1).requires_grad_()
+        loss = CL.InstanceLoss(B, tau, "cpu")(zi, zj)
+        loss.backward()
+        out[f"nt_{B}"] = float(loss)
+        out[f"nt_dzi_{B}"] = t2n(zi.grad)
+        out[f"nt_dzj_{B}"] = t2n(zj.grad)
+    K, B = 16, 24
+    ci = torch.softmax(torch.from_numpy(fill.normalish((B, K), 8100)), dim=1).requires_grad_()
+    cj = torch.softmax(torch.from_numpy(fill.normalish((B, K), 8101)), dim=1).requires_grad_()
+    loss = CL.ClusterLoss(K, 1.0, "cpu")(ci, cj)
+    loss.backward()
+    out["cl"] = float(loss)
+    out["cl_dci"] = t2n(ci.grad)
+    save("contrastive", **out)
+
+
+def g10_lars(MP):
+    ps = [nn.Parameter(torch.from_numpy(fill.uniform(s, 9000 + i))) for i, s in enumerate([(16, 8), (16,), (4, 4, 3, 3)])]
+    opt = MP.LARS(ps, lr=0.2, weight_decay=1.5e-6, momentum=0.9, eta=0.001,
+                  weight_decay_filter=True, lars_adaptation_filter=True)
+    for s in range(3):
+        for i, p in enumerate(ps):
+            p.grad = torch.from_numpy(fill.uniform(tuple(p.shape), 9100 + 10 * s + i))
+        opt.step()
+    save("lars", p0=t2n(ps[0]), p1=t2n(ps[1]), p2=t2n(ps[2]))
+
+
+def main():
+    _install_shims()
+    sys.path.insert(0, REF)
+    A_pkg = importlib.import_module("src.augmentations")
+    A = importlib.import_module("src.augmentations.augmentations")
+    U = importlib.import_module("src.utils.utils")
+    ENC = _load_by_path("ref_audiontt", os.path.join(REF, "src/encoder/audiontt.py"))
+    XS = importlib.import_module("src.upstream.delores_s.upstream_expert")
+    XM = importlib.import_module("src.upstream.delores_m.upstream_expert")
+    S = _load_by_path("ref_specaug", os.path.join(REF, "extras/delores-s/specaugment.py"))
+    CL = _load_by_path("ref_closs", os.path.join(REF, "extras/slicer/contrastive_loss.py"))
+    MP = _load_by_path("ref_multiproc", os.path.join(REF, "extras/delores-s/multi_proc.py"))
+    torch.set_num_threads(8)
+    g1_window(U)
+    g2_runnorm(A)
+    g3_aug(A_pkg)
+    g3b_bank_wrap(A)
+    g4_specaug(S)
+    g5_encoder(ENC)
+    g6_barlow(XS)
+    g8_contrastive(CL)
+    g10_lars(MP)
+    g7_g9_steps(XS, XM, ENC)
+
+
+if __name__ == "__main__":
+    main()

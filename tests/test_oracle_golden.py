@@ -1,0 +1,252 @@
+"""CPU: pin the oracle (our restatement) against fixtures produced by the reference itself."""
+import random
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import augment as OA
+from oracle import fill
+from oracle import frontend as FE
+from oracle import model as OM
+from helpers import closed_queue, drop_mask, grad_digest, views
+
+
+# ---------------------------------------------------------------- G1 window
+def test_extract_window_matches_reference(golden):
+    rows = golden("window")["rows"]
+    for seed, n, first, nz0, last, after in rows:
+        random.seed(int(seed))
+        wav = torch.arange(int(n), dtype=torch.float32)
+        out = FE.extract_window(wav, data_size=1.0)
+        assert len(out) == 16000
+        assert float(out[0]) == first and float(out[-1]) == last
+        assert random.random() == after          # same number of draws consumed
+        random.seed(int(seed))
+        start, left = FE.window_start(int(n), 16000)
+        if n > 16000:
+            assert start == int(first)
+        else:
+            assert start == 0 and left == (16000 - int(n)) // 2
+
+
+# -------------------------------------------------------------- G2 RunningNorm
+def test_running_norm_recurrence(golden):
+    g = golden("runnorm")
+    rn = OA.RunningNorm(epoch_samples=2 * 3)
+    k = 0
+    for c in range(64):
+        x = torch.from_numpy(fill.normalish((1, 64, 101), 500 + c) * (2.0 + 0.1 * c) - 8.0 + 0.05 * c)
+        y = rn(x)
+        assert abs(float(rn.mean) - g["mu"][c]) <= 2e-6 * abs(g["mu"][c])
+        assert abs(float(rn.std) - g["sd"][c]) <= 2e-6 * abs(g["sd"][c])
+        if c in (0, 1, 2, 7, 59, 60, 63):
+            np.testing.assert_allclose(y.numpy()[0, ::8, ::10], g["outs"][k], rtol=0, atol=2e-5)
+            k += 1
+    # frozen after 60 updates
+    assert g["mu"][60] == g["mu"][63] and rn.n == 60
+
+
+# ------------------------------------------------------- G3 augmentation chain
+@pytest.mark.parametrize("T", [101, 96])
+def test_aug_chain_indices_and_views(golden, cfg_s, T):
+    g = golden(f"aug_T{T}")
+    np.random.seed(31)
+    random.seed(31)
+    tf = OA.AugmentationModule(cfg_s, 100)
+    v1s, v2s = [], []
+    for c in range(20):
+        x = torch.from_numpy(fill.normalish((1, 64, T), 1000 + c) * 3.0 - 8.0)
+        a, b = tf(x)
+        v1s.append(a.numpy()[0])
+        v2s.append(b.numpy()[0])
+    # bit-exact crop indices, and both RNG streams left in the same state
+    assert np.array_equal(np.array(tf.rrc.trace, np.int32), g["ijhw"])
+    assert np.random.random() == float(g["np_state_after"])
+    assert random.random() == float(g["py_state_after"])
+    for k, c in enumerate(g["keep"]):
+        np.testing.assert_allclose(v1s[c], g["v1"][k], rtol=0, atol=1e-5)
+        np.testing.assert_allclose(v2s[c], g["v2"][k], rtol=0, atol=1e-5)
+    dig = np.array([[v.sum(dtype=np.float64), np.abs(v).sum(dtype=np.float64)] for v in v1s + v2s])
+    np.testing.assert_allclose(dig, g["digest"], rtol=1e-5, atol=1e-2)
+
+
+def test_mixup_fifo_wraparound(golden):
+    g = golden("mixup_wrap")["outs"]
+    np.random.seed(5)
+    mix = OA.MixupBYOLA(ratio=0.4, n_memory=8, log_mixup_exp=True)
+    k = 0
+    for c in range(12):
+        x = torch.from_numpy(fill.normalish((1, 8, 6), 2000 + c))
+        for _ in range(2):
+            np.testing.assert_allclose(mix(x).numpy(), g[k], rtol=0, atol=2e-6)
+            k += 1
+
+
+# ---------------------------------------------------------------- G4 SpecAugment
+def test_specaugment_masks(golden):
+    g = golden("specaug")
+    k = 0
+    for seed in range(8):
+        x = torch.from_numpy(fill.normalish((101, 64), 3000 + seed))
+        random.seed(1234 + seed)
+        y = OA.time_mask(OA.freq_mask(x, F=30, num_masks=2), T=40, num_masks=2)
+        assert random.random() == g["py_state_after"][seed]
+        np.testing.assert_allclose(y.numpy(), g["outs"][k], rtol=0, atol=1e-6)
+        random.seed(1234 + seed)
+        z = OA.time_mask(OA.freq_mask(x, F=30, num_masks=2, replace_with_zero=True), T=40, num_masks=2,
+                         replace_with_zero=True)
+        assert np.array_equal(z.numpy(), g["outs"][k + 1])         # zero fill: bit-exact
+        k += 2
+
+
+def test_specaugment_survey_example():
+    """seed 1234, F=30 -> f=24, f0=28, end=31; 2nd mask f=0 -> early return."""
+    random.seed(1234)
+    tr = []
+    OA.freq_mask(torch.zeros(101, 64), F=30, num_masks=2, trace=tr)
+    assert tr == [(24, 28, 31), (0, tr[1][1], -1)]
+
+
+# ------------------------------------------------------------------ G5 encoder
+@pytest.mark.parametrize("T", [101, 96])
+def test_encoder_forward_backward(golden, T):
+    g = golden(f"encoder_T{T}")
+    enc = OM.AudioNTT2020Task6(64, 2048, True)
+    fill.fill_state_dict_(enc, seed=1)
+    x = views(2, T, 4000 + T)
+    enc.eval()
+    with torch.no_grad():
+        e = enc(x)
+    for got, key in zip(e, ("eval_x1", "eval_x2", "eval_x3", "eval_x")):
+        np.testing.assert_allclose(got.numpy(), g[key], rtol=1e-4, atol=1e-5)
+    enc.train()
+    a = enc(x, drop_mask((2, T // 8, 2048), 4100 + T))
+    for got, key in zip(a, ("x1", "x2", "x3", "x")):
+        np.testing.assert_allclose(got.detach().numpy(), g[key], rtol=1e-4, atol=1e-5)
+    r = [torch.from_numpy(fill.uniform(tuple(v.shape), 4200 + i)) for i, v in enumerate(a)]
+    loss = sum((v * w).sum() for v, w in zip(a, r))
+    loss.backward()
+    assert abs(float(loss) - float(g["loss"])) <= 1e-4 * abs(float(g["loss"])) + 1e-3
+    names, norms, heads = grad_digest(enc)
+    assert names == [str(s) for s in g["g_names"]]
+    np.testing.assert_allclose(norms, g["g_norms"], rtol=2e-4)
+    np.testing.assert_allclose(heads, g["g_heads"], rtol=2e-3, atol=1e-4)
+    np.testing.assert_allclose(enc.features_1[1].running_mean.numpy(), g["bn1_rm"], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(enc.features_3[1].running_var.numpy(), g["bn3_rv"], rtol=1e-5, atol=1e-6)
+
+
+# ------------------------------------------------------------------- G6 Barlow
+@pytest.mark.parametrize("in_dim", [2048, 1024, 512])
+def test_barlow_head(golden, in_dim):
+    g = golden("barlow")
+    p = OM.Projection(in_dim, 5e-5)
+    fill.fill_state_dict_(p, seed=in_dim)
+    p.train()
+    y1 = torch.from_numpy(fill.uniform((8, in_dim), 5000 + in_dim, 0.0, 2.0)).requires_grad_()
+    y2 = torch.from_numpy(fill.uniform((8, in_dim), 5001 + in_dim, 0.0, 2.0)).requires_grad_()
+    loss = p(y1, y2)
+    loss.backward()
+    assert abs(float(loss) - float(g[f"loss_{in_dim}"])) <= 1e-5 * abs(float(g[f"loss_{in_dim}"]))
+    np.testing.assert_allclose(y1.grad.numpy(), g[f"dy1_{in_dim}"], rtol=1e-3, atol=1e-9)
+    np.testing.assert_allclose(y2.grad.numpy(), g[f"dy2_{in_dim}"], rtol=1e-3, atol=1e-9)
+    _, norms, _ = grad_digest(p)
+    np.testing.assert_allclose(norms, g[f"gn_{in_dim}"], rtol=1e-4)
+    np.testing.assert_allclose(p.bn.running_var.numpy()[:64], g[f"bn_rv_{in_dim}"], rtol=1e-5)
+
+
+# ---------------------------------------------------------------- G8 contrastive
+def test_ntxent_and_cluster_loss(golden):
+    g = golden("contrastive")
+    for B, tau in ((8, 0.5), (16, 0.07)):
+        zi = torch.nn.functional.normalize(torch.from_numpy(fill.normalish((B, 128), 8000 + B)), dim=1).requires_grad_()
+        zj = torch.nn.functional.normalize(torch.from_numpy(fill.normalish((B, 128), 8001 + B)), dim=1).requires_grad_()
+        loss = OM.nt_xent(zi, zj, tau)
+        loss.backward()
+        assert abs(float(loss) - float(g[f"nt_{B}"])) < 1e-5
+        np.testing.assert_allclose(zi.grad.numpy(), g[f"nt_dzi_{B}"], rtol=1e-4, atol=1e-7)
+        np.testing.assert_allclose(zj.grad.numpy(), g[f"nt_dzj_{B}"], rtol=1e-4, atol=1e-7)
+    ci = torch.softmax(torch.from_numpy(fill.normalish((24, 16), 8100)), dim=1).requires_grad_()
+    cj = torch.softmax(torch.from_numpy(fill.normalish((24, 16), 8101)), dim=1).requires_grad_()
+    loss = OM.cluster_loss(ci, cj, 1.0)
+    loss.backward()
+    assert abs(float(loss) - float(g["cl"])) < 1e-5
+    np.testing.assert_allclose(ci.grad.numpy(), g["cl_dci"], rtol=1e-4, atol=1e-7)
+
+
+# ----------------------------------------------------------------------- LARS
+def test_lars(golden):
+    g = golden("lars")
+    ps = [torch.nn.Parameter(torch.from_numpy(fill.uniform(s, 9000 + i)))
+          for i, s in enumerate([(16, 8), (16,), (4, 4, 3, 3)])]
+    bufs = {}
+    for s in range(3):
+        for i, p in enumerate(ps):
+            p.grad = torch.from_numpy(fill.uniform(tuple(p.shape), 9100 + 10 * s + i))
+        OM.lars_step(ps, bufs, lr=0.2, weight_decay=1.5e-6, momentum=0.9, eta=0.001,
+                     weight_decay_filter=True, lars_adaptation_filter=True)
+    for i, p in enumerate(ps):
+        np.testing.assert_allclose(p.detach().numpy(), g[f"p{i}"], rtol=1e-6, atol=1e-7)
+
+
+# ------------------------------------------------------------- G9 training steps
+def test_delores_s_three_steps(golden, cfg_s):
+    g = golden("step_delores_s")
+    ex = OM.DeloresSExpert(cfg_s)
+    fill.fill_state_dict_(ex, seed=2)
+    ex.train()
+    B, T, Tp = 8, 101, 12
+    bufs, losses = {}, []
+    params = [p for p in ex.parameters() if p.requires_grad]
+    for s in range(3):
+        for p in params:
+            p.grad = None
+        loss = ex.training_loss(views(B, T, 6000 + 2 * s), views(B, T, 6001 + 2 * s),
+                                drop_mask((B, Tp, 2048), 6100 + 2 * s), drop_mask((B, Tp, 2048), 6101 + 2 * s))
+        loss.backward()
+        if s == 0:
+            names, norms, heads = grad_digest(ex)
+            assert names == [str(n) for n in g["g_names"]]
+            np.testing.assert_allclose(norms, g["g_norms"], rtol=5e-4)
+        OM.sgd_momentum_step(params, bufs, **{"lr": 0.03, "momentum": 0.9, "weight_decay": 1e-4})
+        losses.append(float(loss))
+    np.testing.assert_allclose(losses, g["losses"], rtol=2e-5)
+    sd = ex.state_dict()
+    np.testing.assert_allclose(sd["encoder.encoder.features_1.0.weight"].numpy().ravel(), g["w_conv1"], rtol=1e-4, atol=1e-6)
+    np.testing.assert_allclose(sd["p.projector.0.weight"].numpy().ravel()[:256], g["w_p0_head"], rtol=1e-4, atol=1e-7)
+
+
+def test_delores_m_three_steps(golden, cfg_m):
+    g = golden("step_delores_m")
+    K = 1024
+    em = OM.DeloresMExpert(cfg_m, num_negatives=K)
+    fill.fill_state_dict_(em, seed=3)
+    for pq, pk in zip(em.encoder_q.parameters(), em.encoder_k.parameters()):
+        pk.data.copy_(pq.data)
+    em.queue.copy_(closed_queue(128, K))
+    em.train()
+    B, T, Tp = 8, 101, 12
+    bufs, losses, ptrs = {}, [], []
+    params = [p for p in em.parameters() if p.requires_grad]
+    for s in range(3):
+        for p in params:
+            p.grad = None
+        parts = {}
+        loss = em.training_loss(views(B, T, 7000 + 2 * s), views(B, T, 7001 + 2 * s),
+                                drop_mask((B, Tp, 2048), 7100 + 2 * s), drop_mask((B, Tp, 2048), 7101 + 2 * s), parts)
+        loss.backward()
+        if s == 0:
+            np.testing.assert_allclose(parts["logits0"].numpy(), g["logits_row0"], rtol=1e-4, atol=1e-4)
+            assert abs(float(parts["ce"]) - float(g["ce0"])) < 1e-4
+            names, norms, _ = grad_digest(em)
+            assert names == [str(n) for n in g["g_names"]]
+            np.testing.assert_allclose(norms, g["g_norms"], rtol=5e-4)
+        OM.sgd_momentum_step(params, bufs, lr=0.03, momentum=0.9, weight_decay=1e-4)
+        losses.append(float(loss))
+        ptrs.append(int(em.queue_ptr))
+    np.testing.assert_allclose(losses, g["losses"], rtol=2e-5)
+    assert ptrs == list(g["ptrs"])
+    sd = em.state_dict()
+    np.testing.assert_allclose(sd["queue"][:, :24].numpy(), g["queue_cols"], rtol=1e-4, atol=1e-6)
+    np.testing.assert_allclose(sd["encoder_k.encoder.features_1.0.weight"].numpy().ravel(), g["wk_conv1"], rtol=1e-5, atol=1e-7)
+    np.testing.assert_allclose(sd["encoder_q.encoder.features_1.0.weight"].numpy().ravel(), g["wq_conv1"], rtol=1e-4, atol=1e-6)
