@@ -1,0 +1,372 @@
+// BatchNorm(train) statistics / finalize, fused BN+ReLU+MaxPool2 forward and backward on the channels-last
+// activations of conv blocks 2 and 3 (`src/encoder/audiontt.py:52-60, 81-93`), the per-layer temporal means
+// x_1..x_3 (`audiontt.py:76-79`), im2col and the conv weight (un)packers.
+// Activation layout everywhere: [N][T][F][C=64] (time, mel, channel) = the reference's
+// x.permute(0,3,2,1), so feature index d*64+c of the reference is contiguous memory here.
+#include "common.h"
+
+namespace {
+
+// ---------------------------------------------------------------------------------- column statistics
+// x [M][C] row-major.  sum/sumsq [C] in fp64 (atomics, caller zeroes).  C % 8 == 0; C/8 <= 256 and 256 % (C/8) == 0.
+template <typename T_, bool SQ>
+__global__ __launch_bounds__(256) void colstats_kernel(const T_* __restrict__ x, long M, int C, long ld, int rows_per_block,
+                                                       double* __restrict__ sum, double* __restrict__ sumsq) {
+    __shared__ float red[256][17];
+    const int G = C / 8, RPI = 256 / G;
+    const int cg = threadIdx.x % G, r0 = threadIdx.x / G;
+    const long row_begin = (long)blockIdx.x * rows_per_block;
+    const long row_end = min(M, row_begin + rows_per_block);
+    float s[8], q[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { s[i] = 0.f; q[i] = 0.f; }
+    for (long r = row_begin + r0; r < row_end; r += RPI) {
+        const Vec8<T_> v = Vec8<T_>::load(x + r * ld + cg * 8);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { const float f = v.get(i); s[i] += f; if (SQ) q[i] += f * f; }
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { red[threadIdx.x][i] = s[i]; red[threadIdx.x][8 + i] = q[i]; }
+    __syncthreads();
+    for (int o = threadIdx.x; o < G * 16; o += 256) {
+        const int g = o / 16, k = o % 16;
+        if (!SQ && k >= 8) continue;
+        double t = 0.0;
+        for (int r = 0; r < RPI; ++r) t += (double)red[r * G + g][k];
+        if (k < 8) atomicAdd(&sum[g * 8 + k], t);
+        else       atomicAdd(&sumsq[g * 8 + (k - 8)], t);
+    }
+}
+
+// gamma/beta may be null (affine=False).  running_* may be null.
+__global__ void bn_finalize_kernel(const double* __restrict__ sum, const double* __restrict__ sumsq, double count, int C,
+                                   const float* __restrict__ gamma, const float* __restrict__ beta, float* running_mean,
+                                   float* running_var, float momentum, float eps, float* scale, float* shift,
+                                   float* save_mean, float* save_rstd) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const double mean = sum[c] / count;
+    double var = sumsq[c] / count - mean * mean;
+    var = var < 0.0 ? 0.0 : var;
+    const double rstd = 1.0 / sqrt(var + (double)eps);
+    const double g = gamma ? (double)gamma[c] : 1.0, b = beta ? (double)beta[c] : 0.0;
+    scale[c] = (float)(g * rstd);
+    shift[c] = (float)(b - mean * g * rstd);
+    save_mean[c] = (float)mean;
+    save_rstd[c] = (float)rstd;
+    if (running_mean) {
+        running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mean;
+        const double unb = count > 1.0 ? var * count / (count - 1.0) : var;
+        running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unb;
+    }
+}
+
+// ------------------------------------------------------------------------------- BN + ReLU + MaxPool2
+// Y [N][Ti][Fi][64] -> P [N][To][Fo][64]; one thread per (n,to,fo,8-channel group)
+template <typename T_>
+__global__ __launch_bounds__(256) void bn_relu_pool_fwd_kernel(const T_* __restrict__ Y, const float* __restrict__ scale,
+                                                               const float* __restrict__ shift, T_* __restrict__ P,
+                                                               int N, int Ti, int Fi) {
+    const int To = Ti / 2, Fo = Fi / 2;
+    const long total = (long)N * To * Fo * 8;
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= total) return;
+    const int c8 = (int)(idx & 7);
+    long r = idx >> 3;
+    const int fo = (int)(r % Fo); r /= Fo;
+    const int to = (int)(r % To);
+    const int n = (int)(r / To);
+    float sc[8], sh[8], m[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { sc[i] = scale[c8 * 8 + i]; sh[i] = shift[c8 * 8 + i]; m[i] = 0.f; }
+#pragma unroll
+    for (int df = 0; df < 2; ++df)
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) {
+            const Vec8<T_> v = Vec8<T_>::load(Y + ((((long)n * Ti + 2 * to + dt) * Fi + 2 * fo + df) * 64 + c8 * 8));
+#pragma unroll
+            for (int i = 0; i < 8; ++i) m[i] = fmaxf(m[i], sc[i] * v.get(i) + sh[i]);      // m starts at 0 = ReLU
+        }
+    Vec8<T_> o;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) o.set(i, m[i]);
+    o.store(P + idx * 8);
+}
+
+// xl[n][f*64+c] = mean_t P[n][t][f][c]
+template <typename T_>
+__global__ __launch_bounds__(256) void tmean_fwd_kernel(const T_* __restrict__ P, T_* __restrict__ xl, int N, int To, int Fo) {
+    const long total = (long)N * Fo * 8;
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= total) return;
+    const int fc8 = (int)(idx % (Fo * 8));
+    const int n = (int)(idx / (Fo * 8));
+    float s[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) s[i] = 0.f;
+    for (int t = 0; t < To; ++t) {
+        const Vec8<T_> v = Vec8<T_>::load(P + (((long)n * To + t) * Fo * 64 + fc8 * 8));
+#pragma unroll
+        for (int i = 0; i < 8; ++i) s[i] += v.get(i);
+    }
+    Vec8<T_> o;
+    const float inv = 1.f / (float)To;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) o.set(i, s[i] * inv);
+    o.store(xl + idx * 8);
+}
+
+// Backward, pass 1: dbeta_c = sum routed grad, dgamma_c = sum routed grad * xhat   (fp32 atomics into stat[2][64])
+// Backward, pass 2: dY = gamma*rstd * (dyhat_routed - dbeta/n - xhat*dgamma/n) at EVERY position (incl. the
+// unpooled last time row when Ti is odd).
+template <typename T_, bool APPLY>
+__global__ __launch_bounds__(256) void bn_relu_pool_bwd_kernel(const T_* __restrict__ Y, const T_* __restrict__ dP,
+                                                               const T_* __restrict__ dxl, float inv_To,
+                                                               const float* __restrict__ scale, const float* __restrict__ shift,
+                                                               const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                               float* __restrict__ stat, float inv_count,
+                                                               T_* __restrict__ dY, int N, int Ti, int Fi) {
+    __shared__ float red[256][16];
+    const int To = Ti / 2, Fo = Fi / 2;
+    const int Tq = (Ti + 1) / 2;                 // quads along time, the last one may be half outside the pooled area
+    const long total = (long)N * Tq * Fo * 8;
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    const bool live = idx < total;
+    float db[8], dg[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { db[i] = 0.f; dg[i] = 0.f; }
+    if (live) {
+        const int c8 = (int)(idx & 7);
+        long r = idx >> 3;
+        const int fo = (int)(r % Fo); r /= Fo;
+        const int tq = (int)(r % Tq);
+        const int n = (int)(r / Tq);
+        const bool pooled = tq < To;
+        float sc[8], sh[8], mu[8], rs[8], g[8], cb[8], cg[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int c = c8 * 8 + i;
+            sc[i] = scale[c]; sh[i] = shift[c]; mu[i] = mean[c]; rs[i] = rstd[c]; g[i] = 0.f;
+            if (APPLY) { cb[i] = stat[c] * inv_count; cg[i] = stat[64 + c] * inv_count; }
+        }
+        if (pooled) {
+            const Vec8<T_> gp = Vec8<T_>::load(dP + ((((long)n * To + tq) * Fo + fo) * 64 + c8 * 8));
+#pragma unroll
+            for (int i = 0; i < 8; ++i) g[i] = gp.get(i);
+            if (dxl) {
+                const Vec8<T_> gx = Vec8<T_>::load(dxl + ((long)n * Fo * 64 + fo * 64 + c8 * 8));
+#pragma unroll
+                for (int i = 0; i < 8; ++i) g[i] += gx.get(i) * inv_To;
+            }
+        }
+        Vec8<T_> y[4];
+        int best[8];
+        float bm[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { best[i] = 0; bm[i] = 0.f; }
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            const int df = p >> 1, dt = p & 1;
+            const int t = 2 * tq + dt;
+            if (t < Ti) y[p] = Vec8<T_>::load(Y + ((((long)n * Ti + t) * Fi + 2 * fo + df) * 64 + c8 * 8));
+            else y[p] = Vec8<T_>::zero();
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const float a = sc[i] * y[p].get(i) + sh[i];
+                if (p == 0 || a > bm[i]) { bm[i] = a; best[i] = p; }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const float da = (pooled && bm[i] > 0.f) ? g[i] : 0.f;
+            g[i] = da;
+            if (!APPLY) {
+                float yb = y[0].get(i);
+#pragma unroll
+                for (int p = 1; p < 4; ++p) yb = best[i] == p ? y[p].get(i) : yb;
+                db[i] = da;
+                dg[i] = da * (yb - mu[i]) * rs[i];
+            }
+        }
+        if (APPLY) {
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                const int df = p >> 1, dt = p & 1;
+                const int t = 2 * tq + dt;
+                if (t >= Ti) continue;
+                Vec8<T_> o;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const float xhat = (y[p].get(i) - mu[i]) * rs[i];
+                    const float da = best[i] == p ? g[i] : 0.f;
+                    o.set(i, sc[i] * (da - cb[i] - xhat * cg[i]));
+                }
+                o.store(dY + ((((long)n * Ti + t) * Fi + 2 * fo + df) * 64 + c8 * 8));
+            }
+        }
+    }
+    if (!APPLY) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { red[threadIdx.x][i] = db[i]; red[threadIdx.x][8 + i] = dg[i]; }
+        __syncthreads();
+        if (threadIdx.x < 128) {
+            // thread -> (kind, channel): 64 channels x {dbeta, dgamma}; channel c lives in threads with (tid & 7) == c/8
+            const int kind = threadIdx.x >> 6, c = threadIdx.x & 63;
+            float t = 0.f;
+            for (int r = (c >> 3); r < 256; r += 8) t += red[r][kind * 8 + (c & 7)];
+            atomicAdd(&stat[kind * 64 + c], t);
+        }
+    }
+}
+
+// -------------------------------------------------------------------------------------------- im2col 3x3
+// X [N][Ti][Fi][64] -> col [N*Ti*Fi][9*64], col[pix][tap*64+c] = X[n][t+kw-1][f+kh-1][c], tap = kh*3+kw
+// (kh walks mel = torch H, kw walks time = torch W)
+template <typename T_>
+__global__ __launch_bounds__(256) void im2col_kernel(const T_* __restrict__ X, T_* __restrict__ col, int N, int Ti, int Fi) {
+    const long total = (long)N * Ti * Fi * 72;
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= total) return;
+    const int k8 = (int)(idx % 72);
+    long pix = idx / 72;
+    const int tap = k8 >> 3, c8 = k8 & 7;
+    const int f = (int)(pix % Fi);
+    const long r = pix / Fi;
+    const int t = (int)(r % Ti);
+    const long n = r / Ti;
+    const int ff = f + tap / 3 - 1, tt = t + tap % 3 - 1;
+    Vec8<T_> v = Vec8<T_>::zero();
+    if (ff >= 0 && ff < Fi && tt >= 0 && tt < Ti) v = Vec8<T_>::load(X + (((n * Ti + tt) * Fi + ff) * 64 + c8 * 8));
+    v.store(col + idx * 8);
+}
+
+// W fp32 [co][ci][3][3] (torch) -> Wf [co][tap*64+ci] (forward) and Wd [ci][tap*64+co] with the taps flipped (dgrad)
+template <typename T_>
+__global__ void pack_conv_w_kernel(const float* __restrict__ W, T_* __restrict__ Wf, T_* __restrict__ Wd) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= 64 * 576) return;
+    const int row = idx / 576, k = idx % 576, tap = k / 64, c = k % 64;
+    Wf[idx] = from_f32<T_>(W[(row * 64 + c) * 9 + tap]);                 // row = co, c = ci
+    Wd[idx] = from_f32<T_>(W[(c * 64 + row) * 9 + (8 - tap)]);           // row = ci, c = co
+}
+
+// dWp fp32 [co][tap*64+ci] -> dW [co][ci][3][3] +=
+__global__ void unpack_conv_dw_kernel(const float* __restrict__ dWp, float* __restrict__ dW) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= 64 * 576) return;
+    const int co = idx / 576, k = idx % 576, tap = k / 64, ci = k % 64;
+    dW[(co * 64 + ci) * 9 + tap] += dWp[idx];
+}
+
+}  // namespace
+
+#define DISPATCH_T(dtype, CALL_F32, CALL_BF16) do { if ((dtype) == 0) { CALL_F32; } else { CALL_BF16; } } while (0)
+
+extern "C" int audiossl_colstats(int dtype, const void* x, long M, int C, long ld, int want_sq, double* sum, double* sumsq,
+                                 void* stream) {
+    ASSL_REQUIRE(x && sum && M > 0 && C > 0 && (C % 8) == 0 && C / 8 <= 256 && 256 % (C / 8) == 0 && (ld % 8) == 0);
+    ASSL_REQUIRE((dtype == 0 || dtype == 1) && (!want_sq || sumsq));
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (hipMemsetAsync(sum, 0, sizeof(double) * C, s) != hipSuccess) return ASSL_ELAUNCH;
+    if (want_sq && hipMemsetAsync(sumsq, 0, sizeof(double) * C, s) != hipSuccess) return ASSL_ELAUNCH;
+    const int RPI = 256 / (C / 8);
+    long it = (M + (long)RPI * 1024 - 1) / ((long)RPI * 1024);      // aim for ~1024 blocks, 1..128 row-iterations each
+    it = it < 1 ? 1 : (it > 128 ? 128 : it);
+    const int rpb = RPI * (int)it;
+    const int grid = ceil_div(M, rpb);
+#define CS(TT, SQ) hipLaunchKernelGGL((colstats_kernel<TT, SQ>), dim3(grid), dim3(256), 0, s, static_cast<const TT*>(x), M, C, ld, rpb, sum, sumsq)
+    if (dtype == 0) { if (want_sq) CS(float, true); else CS(float, false); }
+    else            { if (want_sq) CS(bf16, true);  else CS(bf16, false); }
+#undef CS
+    ASSL_LAUNCH_CHECK();
+}
+
+extern "C" int audiossl_bn_finalize(const double* sum, const double* sumsq, double count, int C, const float* gamma,
+                                    const float* beta, float* running_mean, float* running_var, float momentum, float eps,
+                                    float* scale, float* shift, float* save_mean, float* save_rstd, void* stream) {
+    ASSL_REQUIRE(sum && sumsq && scale && shift && save_mean && save_rstd && C > 0 && count > 0);
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(ceil_div(C, 256)), dim3(256), 0, static_cast<hipStream_t>(stream), sum, sumsq,
+                       count, C, gamma, beta, running_mean, running_var, momentum, eps, scale, shift, save_mean, save_rstd);
+    ASSL_LAUNCH_CHECK();
+}
+
+extern "C" int audiossl_bn_relu_pool_fwd(int dtype, const void* Y, const float* scale, const float* shift, void* P, int N,
+                                         int Ti, int Fi, void* stream) {
+    ASSL_REQUIRE(Y && scale && shift && P && N > 0 && Ti >= 2 && Fi >= 2 && (Fi % 2) == 0 && (dtype == 0 || dtype == 1));
+    const long total = (long)N * (Ti / 2) * (Fi / 2) * 8;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    DISPATCH_T(dtype,
+        hipLaunchKernelGGL(bn_relu_pool_fwd_kernel<float>, dim3(ceil_div(total, 256)), dim3(256), 0, s,
+                           static_cast<const float*>(Y), scale, shift, static_cast<float*>(P), N, Ti, Fi),
+        hipLaunchKernelGGL(bn_relu_pool_fwd_kernel<bf16>, dim3(ceil_div(total, 256)), dim3(256), 0, s,
+                           static_cast<const bf16*>(Y), scale, shift, static_cast<bf16*>(P), N, Ti, Fi));
+    ASSL_LAUNCH_CHECK();
+}
+
+extern "C" int audiossl_tmean_fwd(int dtype, const void* P, void* xl, int N, int To, int Fo, void* stream) {
+    ASSL_REQUIRE(P && xl && N > 0 && To > 0 && Fo > 0 && (dtype == 0 || dtype == 1));
+    const long total = (long)N * Fo * 8;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    DISPATCH_T(dtype,
+        hipLaunchKernelGGL(tmean_fwd_kernel<float>, dim3(ceil_div(total, 256)), dim3(256), 0, s,
+                           static_cast<const float*>(P), static_cast<float*>(xl), N, To, Fo),
+        hipLaunchKernelGGL(tmean_fwd_kernel<bf16>, dim3(ceil_div(total, 256)), dim3(256), 0, s,
+                           static_cast<const bf16*>(P), static_cast<bf16*>(xl), N, To, Fo));
+    ASSL_LAUNCH_CHECK();
+}
+
+// stat: 128 floats scratch (zeroed here).  dgamma/dbeta accumulated (+=) by a tiny tail launch.
+namespace {
+__global__ void add_stat_kernel(const float* __restrict__ stat, float* dgamma, float* dbeta) {
+    const int c = threadIdx.x;
+    if (c < 64) { dbeta[c] += stat[c]; dgamma[c] += stat[64 + c]; }
+}
+}  // namespace
+
+extern "C" int audiossl_bn_relu_pool_bwd(int dtype, const void* Y, const void* dP, const void* dxl, const float* scale,
+                                         const float* shift, const float* mean, const float* rstd, float* stat, void* dY,
+                                         float* dgamma, float* dbeta, int N, int Ti, int Fi, void* stream) {
+    ASSL_REQUIRE(Y && dP && scale && shift && mean && rstd && stat && dY && dgamma && dbeta);
+    ASSL_REQUIRE(N > 0 && Ti >= 2 && Fi >= 2 && (Fi % 2) == 0 && (dtype == 0 || dtype == 1));
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (hipMemsetAsync(stat, 0, sizeof(float) * 128, s) != hipSuccess) return ASSL_ELAUNCH;
+    const long total = (long)N * ((Ti + 1) / 2) * (Fi / 2) * 8;
+    const int grid = ceil_div(total, 256);
+    const float inv_To = 1.f / (float)(Ti / 2);
+    const float inv_count = (float)(1.0 / ((double)N * Ti * Fi));
+#define BW(TT, AP) hipLaunchKernelGGL((bn_relu_pool_bwd_kernel<TT, AP>), dim3(grid), dim3(256), 0, s, static_cast<const TT*>(Y), \
+        static_cast<const TT*>(dP), static_cast<const TT*>(dxl), inv_To, scale, shift, mean, rstd, stat, inv_count,             \
+        static_cast<TT*>(dY), N, Ti, Fi)
+    if (dtype == 0) { BW(float, false); BW(float, true); } else { BW(bf16, false); BW(bf16, true); }
+#undef BW
+    hipLaunchKernelGGL(add_stat_kernel, dim3(1), dim3(64), 0, s, stat, dgamma, dbeta);
+    ASSL_LAUNCH_CHECK();
+}
+
+extern "C" int audiossl_im2col3x3(int dtype, const void* X, void* col, int N, int Ti, int Fi, void* stream) {
+    ASSL_REQUIRE(X && col && N > 0 && Ti > 0 && Fi > 0 && (dtype == 0 || dtype == 1));
+    const long total = (long)N * Ti * Fi * 72;
+    ASSL_REQUIRE((total + 255) / 256 < 2147483647L);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    DISPATCH_T(dtype,
+        hipLaunchKernelGGL(im2col_kernel<float>, dim3(ceil_div(total, 256)), dim3(256), 0, s, static_cast<const float*>(X),
+                           static_cast<float*>(col), N, Ti, Fi),
+        hipLaunchKernelGGL(im2col_kernel<bf16>, dim3(ceil_div(total, 256)), dim3(256), 0, s, static_cast<const bf16*>(X),
+                           static_cast<bf16*>(col), N, Ti, Fi));
+    ASSL_LAUNCH_CHECK();
+}
+
+extern "C" int audiossl_pack_conv_w(int dtype, const float* W, void* Wf, void* Wd, void* stream) {
+    ASSL_REQUIRE(W && Wf && Wd && (dtype == 0 || dtype == 1));
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    DISPATCH_T(dtype,
+        hipLaunchKernelGGL(pack_conv_w_kernel<float>, dim3(144), dim3(256), 0, s, W, static_cast<float*>(Wf), static_cast<float*>(Wd)),
+        hipLaunchKernelGGL(pack_conv_w_kernel<bf16>, dim3(144), dim3(256), 0, s, W, static_cast<bf16*>(Wf), static_cast<bf16*>(Wd)));
+    ASSL_LAUNCH_CHECK();
+}
+
+extern "C" int audiossl_unpack_conv_dw(const float* dWp, float* dW, void* stream) {
+    ASSL_REQUIRE(dWp && dW);
+    hipLaunchKernelGGL(unpack_conv_dw_kernel, dim3(144), dim3(256), 0, static_cast<hipStream_t>(stream), dWp, dW);
+    ASSL_LAUNCH_CHECK();
+}

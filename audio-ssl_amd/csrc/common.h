@@ -1,0 +1,84 @@
+// Shared device/host helpers for the audiossl gfx950 kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+// ---- C-ABI error codes (include/audiossl_hip.h) ---------------------------------
+#define ASSL_OK 0
+#define ASSL_EINVAL (-1)      // bad shape / null pointer / unsupported configuration
+#define ASSL_ELAUNCH (-2)     // hipGetLastError() after a launch was not hipSuccess
+#define ASSL_EALIGN (-3)      // pointer or leading dimension not 16-byte aligned
+
+#define ASSL_REQUIRE(cond) do { if (!(cond)) return ASSL_EINVAL; } while (0)
+#define ASSL_ALIGNED16(p) ((((uintptr_t)(p)) & 15) == 0)
+#define ASSL_LAUNCH_CHECK() do { if (hipGetLastError() != hipSuccess) return ASSL_ELAUNCH; return ASSL_OK; } while (0)
+
+typedef __bf16 bf16;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+static inline int ceil_div(long a, long b) { return (int)((a + b - 1) / b); }
+
+// ---- scalar conversions -----------------------------------------------------------
+__device__ __forceinline__ float to_f32(float v) { return v; }
+__device__ __forceinline__ float to_f32(bf16 v) { return (float)v; }
+template <typename T> __device__ __forceinline__ T from_f32(float v);
+template <> __device__ __forceinline__ float from_f32<float>(float v) { return v; }
+template <> __device__ __forceinline__ bf16 from_f32<bf16>(float v) { return (bf16)v; }   // RNE, NaN-preserving
+
+// 8-element vector of T (16 B for bf16, 32 B for float)
+template <typename T> struct Vec8;
+template <> struct Vec8<bf16> {
+    bf16x8 v;
+    __device__ __forceinline__ static Vec8 load(const bf16* p) { Vec8 r; r.v = *reinterpret_cast<const bf16x8*>(p); return r; }
+    __device__ __forceinline__ void store(bf16* p) const { *reinterpret_cast<bf16x8*>(p) = v; }
+    __device__ __forceinline__ static Vec8 zero() { Vec8 r; for (int i = 0; i < 8; ++i) r.v[i] = (bf16)0.f; return r; }
+    __device__ __forceinline__ float get(int i) const { return (float)v[i]; }
+    __device__ __forceinline__ void set(int i, float x) { v[i] = (bf16)x; }
+    __device__ __forceinline__ bf16 raw(int i) const { return v[i]; }
+    __device__ __forceinline__ void setraw(int i, bf16 x) { v[i] = x; }
+};
+template <> struct Vec8<float> {
+    f32x4 lo, hi;
+    __device__ __forceinline__ static Vec8 load(const float* p) {
+        Vec8 r; r.lo = *reinterpret_cast<const f32x4*>(p); r.hi = *reinterpret_cast<const f32x4*>(p + 4); return r; }
+    __device__ __forceinline__ void store(float* p) const {
+        *reinterpret_cast<f32x4*>(p) = lo; *reinterpret_cast<f32x4*>(p + 4) = hi; }
+    __device__ __forceinline__ static Vec8 zero() { Vec8 r; r.lo = f32x4{0, 0, 0, 0}; r.hi = f32x4{0, 0, 0, 0}; return r; }
+    __device__ __forceinline__ float get(int i) const { return i < 4 ? lo[i] : hi[i - 4]; }
+    __device__ __forceinline__ void set(int i, float x) { if (i < 4) lo[i] = x; else hi[i - 4] = x; }
+    __device__ __forceinline__ float raw(int i) const { return get(i); }
+    __device__ __forceinline__ void setraw(int i, float x) { set(i, x); }
+};
+
+// ---- wave / block reductions ----------------------------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+// Sum over a block of up to 1024 threads; result valid in every thread.  `sh` needs 16 slots.
+template <typename A>
+__device__ __forceinline__ A block_sum(A v, A* sh) {
+    v = wave_sum(v);
+    const int w = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) sh[w] = v;
+    __syncthreads();
+    A t = 0;
+    for (int i = 0; i < nw; ++i) t += sh[i];
+    return t;
+}

@@ -1,0 +1,287 @@
+// K6: the 1->64 channel stem of AudioNTT2020Task6 (`src/encoder/audiontt.py:46-50, 74`):
+// Conv2d(1,64,3,pad 1) + BatchNorm2d(train) + ReLU + MaxPool2d(2), forward and backward, without ever
+// materialising the full-resolution 64-channel tensor (1.65 MB per view in fp32).
+//
+// A 3x3 convolution of a single-channel image is linear in 9 shifted copies x_tap of that image, so the
+// batch statistics of every output channel follow from the 9 first and 45 second moments of the taps:
+//   mean_c = w_c . S1 / n + b_c,   var_c = w_c^T Cov w_c            (moments kernel + finalize, fp64)
+// and the forward is ONE pass that recomputes the conv per pooled pixel and writes only the pooled map.
+// The backward never needs dX (the input is data), and BN's correction terms are again linear in the
+// same moments:
+//   dW_c,tap = gamma rstd [ G_c,tap - dbeta_c/n S1_tap - dgamma_c/n * rstd (w_c . S2[:,tap] + (b_c-mean_c) S1_tap) ]
+// with G = sum over pooled pixels of (routed, ReLU-gated) gradient x tap value, so it is ONE more pass.
+// Layouts: image [N][F][T] fp32 (NCHW, C=1); pooled output [N][T/2][F/2][64] (time, mel, channel) in T_.
+#include "common.h"
+
+namespace {
+
+constexpr int NTAP = 9, NMOM = 9 + 45;
+
+__device__ __forceinline__ int tri(int a, int b) {   // index of pair (a<=b) in the packed upper triangle
+    return a * 9 - a * (a - 1) / 2 + (b - a);
+}
+
+__global__ __launch_bounds__(256) void conv1_moments_kernel(const float* __restrict__ img, double* __restrict__ mom,
+                                                            int N, int F, int T) {
+    __shared__ float sh[4][NMOM];
+    float acc[NMOM];
+#pragma unroll
+    for (int i = 0; i < NMOM; ++i) acc[i] = 0.f;
+    const long total = (long)N * F * T;
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+        const int t = (int)(idx % T);
+        const long r = idx / T;
+        const int f = (int)(r % F);
+        const float* im = img + (r / F) * (long)F * T;
+        float x[NTAP];
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw) {
+                const int ff = f + kh - 1, tt = t + kw - 1;
+                x[kh * 3 + kw] = (ff >= 0 && ff < F && tt >= 0 && tt < T) ? im[ff * T + tt] : 0.f;
+            }
+        int q = 9;
+#pragma unroll
+        for (int a = 0; a < 9; ++a) {
+            acc[a] += x[a];
+#pragma unroll
+            for (int b = a; b < 9; ++b) acc[q++] += x[a] * x[b];
+        }
+    }
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+#pragma unroll
+    for (int i = 0; i < NMOM; ++i) {
+        const float v = wave_sum(acc[i]);
+        if (lane == 0) sh[w][i] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < NMOM) {
+        const double v = (double)sh[0][threadIdx.x] + (double)sh[1][threadIdx.x] + (double)sh[2][threadIdx.x] +
+                         (double)sh[3][threadIdx.x];
+        atomicAdd(&mom[threadIdx.x], v);
+    }
+}
+
+// 64 threads, one per output channel.
+__global__ void conv1_finalize_kernel(const double* __restrict__ mom, const float* __restrict__ w,
+                                      const float* __restrict__ bias, const float* __restrict__ gamma,
+                                      const float* __restrict__ beta, float* running_mean, float* running_var,
+                                      float momentum, float eps, double count, float* scale, float* shift,
+                                      float* save_mean, float* save_rstd) {
+    const int c = threadIdx.x;
+    if (c >= 64) return;
+    double mean = 0.0, var = 0.0;
+    for (int a = 0; a < 9; ++a) mean += (double)w[c * 9 + a] * mom[a];
+    mean = mean / count;
+    for (int a = 0; a < 9; ++a)
+        for (int b = 0; b < 9; ++b) {
+            const double s2 = mom[9 + (a <= b ? tri(a, b) : tri(b, a))] / count;
+            const double cov = s2 - (mom[a] / count) * (mom[b] / count);
+            var += (double)w[c * 9 + a] * (double)w[c * 9 + b] * cov;
+        }
+    var = var < 0.0 ? 0.0 : var;
+    mean += (double)bias[c];
+    const double rstd = 1.0 / sqrt(var + (double)eps);
+    const float sc = (float)((double)gamma[c] * rstd);
+    scale[c] = sc;
+    shift[c] = (float)((double)beta[c] - mean * (double)gamma[c] * rstd);
+    save_mean[c] = (float)mean;
+    save_rstd[c] = (float)rstd;
+    if (running_mean) {
+        running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mean;
+        running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)(var * count / (count - 1.0));
+    }
+}
+
+// Stage the 4 time columns x (F+2) mel rows an (n, tp) item needs: patch[f+1][k] = img[n][f][2tp-1+k].
+__device__ __forceinline__ void load_patch(float* patch, const float* __restrict__ img, int n, int tp, int F, int T) {
+    const float* im = img + (long)n * F * T;
+    for (int i = threadIdx.x; i < (F + 2) * 4; i += 256) {
+        const int f = (i >> 2) - 1, t = 2 * tp - 1 + (i & 3);
+        patch[i] = (f >= 0 && f < F && t >= 0 && t < T) ? im[f * T + t] : 0.f;
+    }
+}
+
+// conv outputs of the 2x2 pooling window at pooled mel row fp: y[p], p = 2*df + dt (torch's scan order)
+__device__ __forceinline__ void conv4(const float* patch, int fp, const float* w, float bias, float* y) {
+    float x[4][4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) x[r][k] = patch[(2 * fp + r) * 4 + k];      // rows f = 2fp-1 .. 2fp+2
+#pragma unroll
+    for (int df = 0; df < 2; ++df)
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) {
+            float s = bias;
+#pragma unroll
+            for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+                for (int kw = 0; kw < 3; ++kw) s += w[kh * 3 + kw] * x[df + kh][dt + kw];
+            y[2 * df + dt] = s;
+        }
+}
+
+template <typename T_>
+__global__ __launch_bounds__(256) void conv1_fwd_kernel(const float* __restrict__ img, const float* __restrict__ w,
+                                                        const float* __restrict__ bias, const float* __restrict__ scale,
+                                                        const float* __restrict__ shift, T_* __restrict__ out,
+                                                        int N, int F, int T) {
+    extern __shared__ __attribute__((aligned(16))) float patch[];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int To = T / 2, Fo = F / 2;
+    float wr[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) wr[i] = w[lane * 9 + i];
+    const float b = bias[lane], sc = scale[lane], sh = shift[lane];
+    for (int item = blockIdx.x; item < N * To; item += gridDim.x) {
+        const int n = item / To, tp = item - n * To;
+        __syncthreads();
+        load_patch(patch, img, n, tp, F, T);
+        __syncthreads();
+        for (int fp = wv; fp < Fo; fp += 4) {
+            float y[4];
+            conv4(patch, fp, wr, b, y);
+            float m = fmaxf(sc * y[0] + sh, 0.f);
+#pragma unroll
+            for (int p = 1; p < 4; ++p) m = fmaxf(m, fmaxf(sc * y[p] + sh, 0.f));
+            out[(((long)n * To + tp) * Fo + fp) * 64 + lane] = from_f32<T_>(m);
+        }
+    }
+}
+
+// acc[c][0..8] = G, acc[c][9] = dbeta, acc[c][10] = dgamma   (fp32 atomics, one set per block)
+template <typename T_>
+__global__ __launch_bounds__(256) void conv1_bwd_kernel(const float* __restrict__ img, const float* __restrict__ w,
+                                                        const float* __restrict__ bias, const float* __restrict__ scale,
+                                                        const float* __restrict__ shift, const float* __restrict__ mean,
+                                                        const float* __restrict__ rstd, const T_* __restrict__ dP,
+                                                        const T_* __restrict__ dxl, float inv_To, float* __restrict__ acc,
+                                                        int N, int F, int T) {
+    extern __shared__ __attribute__((aligned(16))) float patch[];
+    __shared__ float red[4][64][11];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int To = T / 2, Fo = F / 2;
+    float wr[9], G[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) { wr[i] = w[lane * 9 + i]; G[i] = 0.f; }
+    const float b = bias[lane], sc = scale[lane], sh = shift[lane], mu = mean[lane], rs = rstd[lane];
+    float dbeta = 0.f, dgamma = 0.f;
+    for (int item = blockIdx.x; item < N * To; item += gridDim.x) {
+        const int n = item / To, tp = item - n * To;
+        __syncthreads();
+        load_patch(patch, img, n, tp, F, T);
+        __syncthreads();
+        for (int fp = wv; fp < Fo; fp += 4) {
+            float y[4];
+            conv4(patch, fp, wr, b, y);
+            int best = 0;
+            float m = sc * y[0] + sh;
+#pragma unroll
+            for (int p = 1; p < 4; ++p) { const float a = sc * y[p] + sh; if (a > m) { m = a; best = p; } }
+            float g = to_f32(dP[(((long)n * To + tp) * Fo + fp) * 64 + lane]);
+            if (dxl) g += to_f32(dxl[(long)n * Fo * 64 + fp * 64 + lane]) * inv_To;
+            const float da = m > 0.f ? g : 0.f;
+            const float ybest = best == 0 ? y[0] : best == 1 ? y[1] : best == 2 ? y[2] : y[3];
+            dbeta += da;
+            dgamma += da * (ybest - mu) * rs;
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                const float dm = (best == p) ? da : 0.f;
+                const int df = p >> 1, dt = p & 1;
+#pragma unroll
+                for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+                    for (int kw = 0; kw < 3; ++kw) G[kh * 3 + kw] += dm * patch[(2 * fp + df + kh) * 4 + dt + kw];
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 9; ++i) red[wv][lane][i] = G[i];
+    red[wv][lane][9] = dbeta;
+    red[wv][lane][10] = dgamma;
+    __syncthreads();
+    for (int i = threadIdx.x; i < 64 * 11; i += 256) {
+        const int c = i / 11, k = i - c * 11;
+        atomicAdd(&acc[i], red[0][c][k] + red[1][c][k] + red[2][c][k] + red[3][c][k]);
+    }
+}
+
+__global__ void conv1_bwd_finalize_kernel(const float* __restrict__ acc, const double* __restrict__ mom,
+                                          const float* __restrict__ w, const float* __restrict__ bias,
+                                          const float* __restrict__ gamma, const float* __restrict__ mean,
+                                          const float* __restrict__ rstd, double count, float* dW, float* dbias,
+                                          float* dgamma, float* dbeta) {
+    const int c = threadIdx.x;
+    if (c >= 64) return;
+    const double db = acc[c * 11 + 9], dg = acc[c * 11 + 10];
+    const double rs = rstd[c], mu = mean[c], gm = gamma[c];
+    for (int t = 0; t < 9; ++t) {
+        double wS2 = 0.0;
+        for (int a = 0; a < 9; ++a) wS2 += (double)w[c * 9 + a] * mom[9 + (a <= t ? tri(a, t) : tri(t, a))];
+        const double yhat_x = rs * (wS2 + ((double)bias[c] - mu) * mom[t]);           // sum_pos yhat_c * x_tap
+        const double v = gm * rs * ((double)acc[c * 11 + t] - db / count * mom[t] - dg / count * yhat_x);
+        dW[c * 9 + t] += (float)v;
+    }
+    dgamma[c] += (float)dg;
+    dbeta[c] += (float)db;
+    (void)dbias;            // d(conv bias) is identically zero under train-mode BN
+}
+
+}  // namespace
+
+extern "C" int audiossl_conv1_stats(const float* img, int N, int F, int T, const float* w, const float* bias,
+                                    const float* gamma, const float* beta, float* running_mean, float* running_var,
+                                    float momentum, float eps, double* mom, float* scale, float* shift,
+                                    float* save_mean, float* save_rstd, void* stream) {
+    ASSL_REQUIRE(img && w && bias && gamma && beta && mom && scale && shift && save_mean && save_rstd);
+    ASSL_REQUIRE(N > 0 && F >= 2 && T >= 2);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (hipMemsetAsync(mom, 0, sizeof(double) * NMOM, s) != hipSuccess) return ASSL_ELAUNCH;
+    const long total = (long)N * F * T;
+    const int grid = (int)min((long)2048, (total + 255) / 256);
+    hipLaunchKernelGGL(conv1_moments_kernel, dim3(grid), dim3(256), 0, s, img, mom, N, F, T);
+    hipLaunchKernelGGL(conv1_finalize_kernel, dim3(1), dim3(64), 0, s, mom, w, bias, gamma, beta, running_mean,
+                       running_var, momentum, eps, (double)total, scale, shift, save_mean, save_rstd);
+    ASSL_LAUNCH_CHECK();
+}
+
+extern "C" int audiossl_conv1_fwd(int dtype, const float* img, int N, int F, int T, const float* w, const float* bias,
+                                  const float* scale, const float* shift, void* out, void* stream) {
+    ASSL_REQUIRE(img && w && bias && scale && shift && out && N > 0 && F >= 2 && T >= 2 && (F % 2) == 0);
+    ASSL_REQUIRE(dtype == 0 || dtype == 1);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int grid = min(N * (T / 2), 2048);
+    const size_t lds = sizeof(float) * (F + 2) * 4;
+    if (dtype == 0)
+        hipLaunchKernelGGL(conv1_fwd_kernel<float>, dim3(grid), dim3(256), lds, s, img, w, bias, scale, shift,
+                           static_cast<float*>(out), N, F, T);
+    else
+        hipLaunchKernelGGL(conv1_fwd_kernel<bf16>, dim3(grid), dim3(256), lds, s, img, w, bias, scale, shift,
+                           static_cast<bf16*>(out), N, F, T);
+    ASSL_LAUNCH_CHECK();
+}
+
+// acc: 64*11 floats of scratch (zeroed here).  dxl may be null.  Grad outputs are accumulated (+=).
+extern "C" int audiossl_conv1_bwd(int dtype, const float* img, int N, int F, int T, const float* w, const float* bias,
+                                  const float* gamma, const float* scale, const float* shift, const float* mean,
+                                  const float* rstd, const double* mom, const void* dP, const void* dxl, float* acc,
+                                  float* dW, float* dbias, float* dgamma, float* dbeta, void* stream) {
+    ASSL_REQUIRE(img && w && bias && gamma && scale && shift && mean && rstd && mom && dP && acc && dW && dgamma && dbeta);
+    ASSL_REQUIRE(N > 0 && F >= 2 && T >= 2 && (F % 2) == 0 && (dtype == 0 || dtype == 1));
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (hipMemsetAsync(acc, 0, sizeof(float) * 64 * 11, s) != hipSuccess) return ASSL_ELAUNCH;
+    const int grid = min(N * (T / 2), 1024);
+    const size_t lds = sizeof(float) * (F + 2) * 4;
+    const float inv_To = 1.f / (float)(T / 2);
+    if (dtype == 0)
+        hipLaunchKernelGGL(conv1_bwd_kernel<float>, dim3(grid), dim3(256), lds, s, img, w, bias, scale, shift, mean, rstd,
+                           static_cast<const float*>(dP), static_cast<const float*>(dxl), inv_To, acc, N, F, T);
+    else
+        hipLaunchKernelGGL(conv1_bwd_kernel<bf16>, dim3(grid), dim3(256), lds, s, img, w, bias, scale, shift, mean, rstd,
+                           static_cast<const bf16*>(dP), static_cast<const bf16*>(dxl), inv_To, acc, N, F, T);
+    hipLaunchKernelGGL(conv1_bwd_finalize_kernel, dim3(1), dim3(64), 0, s, acc, mom, w, bias, gamma, mean, rstd,
+                       (double)N * F * T, dW, dbias, dgamma, dbeta);
+    ASSL_LAUNCH_CHECK();
+}

@@ -1,0 +1,222 @@
+// MFMA GEMM for gfx950 (CDNA4): C[M,N] (+)= alpha * op(A)[M,K] * op(B)[K,N] with fused epilogue.
+//
+// One 256-thread workgroup (4 waves, 2x2) owns a 128x128 output tile; each wave a 64x64 sub-tile =
+// 2x2 MFMA 32x32 accumulators.  K is walked in steps of 32 through double-buffered LDS with register
+// prefetch (global loads of step k+1 are issued before the MFMAs of step k; their LDS write lands after).
+//   T = bf16 : v_mfma_f32_32x32x16_bf16  (fp32 accumulate)
+//   T = float: v_mfma_f32_32x32x2_f32    (exact fp32 fma chain) - the validation / high-precision path
+// Operand storage ("row" = the M index of A or the N index of B):
+//   TRANS=false : [row][K]  K contiguous  -> LDS image [row][K], fragments by one 16/32-byte read
+//   TRANS=true  : [K][row]  row contiguous -> LDS image [K][row], fragments by 8 strided reads
+// so  NT (Linear fwd: X*W^T) = <false,false>, NN (dX = dY*W) = <false,true>, TN (dW = dY^T*X) = <true,true>.
+// Fragment K-order: lane half h owns k in [8h, 8h+8) of every 16-wide k-step for both operands; for
+// bf16 that is the hardware map of 32x32x16, for f32 the 8 k's are fed to 8 successive 32x32x2 MFMAs
+// (any bijection k->(step,half) is valid as long as A and B agree).
+#include "common.h"
+
+namespace {
+
+constexpr int BM = 128, BN = 128, BK = 32;
+constexpr int NT_PITCH = BK + 8;      // elements; [row][k] image, conflict-free 16-byte row reads
+constexpr int TR_PITCH = 128 + 8;     // elements; [k][row] image
+
+struct GemmArgs {
+    const void* A; const void* B; void* C;
+    int M, N, K;
+    long lda, ldb, ldc;
+    float alpha;
+    const float* bias;        // [N] fp32 or null
+    int relu;
+    const uint8_t* keep;      // [M][ldk] keep-mask (1 = keep) or null
+    long ldk;
+    float keep_scale;
+    const void* gate;         // T [M][ldg]: out = gate > 0 ? out : 0
+    long ldg;
+    int out_f32;              // C is float even when T is bf16
+    int atomic;               // C (float) += via atomicAdd (split-K / multi-source accumulation)
+    int ksplit;               // gridDim.z
+};
+
+template <typename T> struct Mma;
+template <> struct Mma<bf16> {
+    __device__ __forceinline__ static void run(f32x16& acc, const Vec8<bf16>& a, const Vec8<bf16>& b) {
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.v, b.v, acc, 0, 0, 0);
+    }
+};
+template <> struct Mma<float> {
+    __device__ __forceinline__ static void run(f32x16& acc, const Vec8<float>& a, const Vec8<float>& b) {
+#pragma unroll
+        for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.lo[s], b.lo[s], acc, 0, 0, 0);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.hi[s], b.hi[s], acc, 0, 0, 0);
+    }
+};
+
+// One operand's staging: 128 rows x 32 k per step, two Vec8 per thread.
+template <typename T, bool TRANS>
+struct Stage {
+    Vec8<T> r[2];
+    // rows = extent of the row dimension (M or N); kend = exclusive K bound of this split
+    __device__ __forceinline__ void load(const T* __restrict__ base, long ld, int row0, int rows, int k0, int kend) {
+        const int t = threadIdx.x;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int v = t + i * 256;
+            if (!TRANS) {
+                const int row = row0 + (v >> 2), k = k0 + (v & 3) * 8;
+                r[i] = (row < rows && k < kend) ? Vec8<T>::load(base + (long)row * ld + k) : Vec8<T>::zero();
+            } else {
+                const int k = k0 + (v >> 4), row = row0 + (v & 15) * 8;
+                r[i] = (row < rows && k < kend) ? Vec8<T>::load(base + (long)k * ld + row) : Vec8<T>::zero();
+            }
+        }
+    }
+    __device__ __forceinline__ void put(T* lds) const {
+        const int t = threadIdx.x;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int v = t + i * 256;
+            if (!TRANS) r[i].store(lds + (v >> 2) * NT_PITCH + (v & 3) * 8);
+            else        r[i].store(lds + (v >> 4) * TR_PITCH + (v & 15) * 8);
+        }
+    }
+    // fragment of 32 rows starting at `row`, k-step `kk` (0 or 16) for this lane
+    __device__ __forceinline__ static Vec8<T> frag(const T* lds, int row, int kk, int lane) {
+        const int r_ = row + (lane & 31), kb = kk + 8 * (lane >> 5);
+        if (!TRANS) return Vec8<T>::load(lds + r_ * NT_PITCH + kb);
+        Vec8<T> f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) f.setraw(j, lds[(kb + j) * TR_PITCH + r_]);
+        return f;
+    }
+    static constexpr int LDS_ELEMS = TRANS ? BK * TR_PITCH : BM * NT_PITCH;
+};
+
+template <typename T, bool TA, bool TB>
+__global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
+    using SA = Stage<T, TA>;
+    using SB = Stage<T, TB>;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    T* const ldsA0 = reinterpret_cast<T*>(smem);                 // two A buffers, then two B buffers
+    T* const ldsB0 = ldsA0 + 2 * SA::LDS_ELEMS;
+
+    const int tiles_n = (g.N + BN - 1) / BN;
+    const int bm = (blockIdx.x / tiles_n) * BM, bn = (blockIdx.x % tiles_n) * BN;
+    // split-K range, in whole BK steps
+    const int ksteps = (g.K + BK - 1) / BK;
+    const int per = (ksteps + g.ksplit - 1) / g.ksplit;
+    const int ks0 = blockIdx.z * per, ks1 = min(ksteps, ks0 + per);
+    if (ks0 >= ks1) return;
+    const int kend = min(g.K, ks1 * BK);
+
+    const T* A = static_cast<const T*>(g.A);
+    const T* B = static_cast<const T*>(g.B);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    SA sa; SB sb;
+    sa.load(A, g.lda, bm, g.M, ks0 * BK, kend);
+    sb.load(B, g.ldb, bn, g.N, ks0 * BK, kend);
+    sa.put(ldsA0); sb.put(ldsB0);
+    __syncthreads();
+
+    int cur = 0;
+    for (int ks = ks0; ks < ks1; ++ks) {
+        const bool more = ks + 1 < ks1;
+        if (more) {
+            sa.load(A, g.lda, bm, g.M, (ks + 1) * BK, kend);
+            sb.load(B, g.ldb, bn, g.N, (ks + 1) * BK, kend);
+        }
+        const T* la = ldsA0 + cur * SA::LDS_ELEMS;
+        const T* lb = ldsB0 + cur * SB::LDS_ELEMS;
+#pragma unroll
+        for (int kk = 0; kk < BK; kk += 16) {
+            Vec8<T> fa[2], fb[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) fa[i] = SA::frag(la, wm + i * 32, kk, lane);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) fb[j] = SB::frag(lb, wn + j * 32, kk, lane);
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) Mma<T>::run(acc[i][j], fa[i], fb[j]);
+        }
+        if (more) { sa.put(ldsA0 + (cur ^ 1) * SA::LDS_ELEMS); sb.put(ldsB0 + (cur ^ 1) * SB::LDS_ELEMS); }
+        __syncthreads();
+        cur ^= 1;
+    }
+
+    // ---- epilogue: C/D map of 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+    const T* gate = static_cast<const T*>(g.gate);
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int col = bn + wn + j * 32 + (lane & 31);
+            if (col >= g.N) continue;
+            const float bias = g.bias ? g.bias[col] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = bm + wm + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                if (row >= g.M) continue;
+                float v = g.alpha * acc[i][j][r] + bias;
+                if (g.relu) v = fmaxf(v, 0.f);
+                if (g.keep) v = g.keep[(long)row * g.ldk + col] ? v * g.keep_scale : 0.f;
+                if (gate) v = to_f32(gate[(long)row * g.ldg + col]) > 0.f ? v : 0.f;
+                const long o = (long)row * g.ldc + col;
+                if (g.atomic)       atomicAdd(static_cast<float*>(g.C) + o, v);
+                else if (g.out_f32) static_cast<float*>(g.C)[o] = v;
+                else                static_cast<T*>(g.C)[o] = from_f32<T>(v);
+            }
+        }
+}
+
+template <typename T, bool TA, bool TB>
+int launch(const GemmArgs& g, hipStream_t s) {
+    const size_t lds = sizeof(T) * 2 * (Stage<T, TA>::LDS_ELEMS + Stage<T, TB>::LDS_ELEMS);
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<T, TA, TB>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return ASSL_ELAUNCH;
+        attr_set = true;
+    }
+    const int tiles = ceil_div(g.M, BM) * ceil_div(g.N, BN);
+    hipLaunchKernelGGL((gemm_kernel<T, TA, TB>), dim3(tiles, 1, g.ksplit), dim3(256), lds, s, g);
+    ASSL_LAUNCH_CHECK();
+}
+
+template <typename T>
+int dispatch(const GemmArgs& g, int ta, int tb, hipStream_t s) {
+    if (!ta && !tb) return launch<T, false, false>(g, s);
+    if (!ta && tb) return launch<T, false, true>(g, s);
+    if (ta && tb) return launch<T, true, true>(g, s);
+    return launch<T, true, false>(g, s);
+}
+
+}  // namespace
+
+// dtype: 0 = fp32 operands (exact f32 MFMA), 1 = bf16 operands.  See include/audiossl_hip.h.
+extern "C" int audiossl_gemm(int dtype, int trans_a, int trans_b, int M, int N, int K, float alpha,
+                             const void* A, long lda, const void* B, long ldb, void* C, long ldc,
+                             const float* bias, int relu, const uint8_t* keep, long ldk, float keep_scale,
+                             const void* gate, long ldg, int out_f32, int atomic, int ksplit, void* stream) {
+    ASSL_REQUIRE(A && B && C && M > 0 && N > 0 && K > 0 && ksplit >= 1);
+    ASSL_REQUIRE(dtype == 0 || dtype == 1);
+    ASSL_REQUIRE(!atomic || out_f32 || dtype == 0);
+    ASSL_REQUIRE(ksplit == 1 || atomic);
+    // vector (8-element) dimension of each operand must be a multiple of 8 and its rows 16-byte aligned
+    ASSL_REQUIRE((trans_a ? M : K) % 8 == 0 && (trans_b ? N : K) % 8 == 0);
+    if (!ASSL_ALIGNED16(A) || !ASSL_ALIGNED16(B) || lda % 8 || ldb % 8) return ASSL_EALIGN;
+    GemmArgs g{A, B, C, M, N, K, lda, ldb, ldc, alpha, bias, relu, keep, ldk, keep_scale, gate, ldg,
+               (dtype == 0) ? 1 : out_f32, atomic, ksplit};
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    return dtype == 0 ? dispatch<float>(g, trans_a, trans_b, s) : dispatch<bf16>(g, trans_a, trans_b, s);
+}

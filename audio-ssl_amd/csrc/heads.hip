@@ -1,0 +1,473 @@
+// Encoder tail, loss heads and optimiser kernels (everything that is not a GEMM or a conv block).
+//   maxmean   : `upstream_encoder.py:26-28`   max_T(x) + mean_T(x) and its backward (ReLU-gated)
+//   colbn_*   : BatchNorm1d(train) of the Barlow projector (`upstream_expert.py:15-32`), apply + backward
+//   barlow_*  : cross-correlation loss and its gradient (`upstream_expert.py:36-45`, `utils.py:185-189`)
+//   l2norm / moco_ce / enqueue : MoCo InfoNCE head (`delores_m/upstream_expert.py:156-172, 231-264`)
+//   sgd / ema / cast / dropout_mask : optimiser + parameter plumbing on flat buffers
+#include "common.h"
+
+namespace {
+
+// --------------------------------------------------------------------------------------------- max + mean over time
+// H [N][Tt][D] -> y [N][D] = max_t + mean_t ; arg [N][D] = first argmax
+template <typename T_>
+__global__ __launch_bounds__(256) void maxmean_fwd_kernel(const T_* __restrict__ H, T_* __restrict__ y, uint8_t* __restrict__ arg,
+                                                          int N, int Tt, int D) {
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;          // over N * D/8
+    const int D8 = D / 8;
+    if (idx >= (long)N * D8) return;
+    const int d8 = (int)(idx % D8);
+    const long n = idx / D8;
+    float mx[8], sm[8];
+    int am[8];
+    for (int t = 0; t < Tt; ++t) {
+        const Vec8<T_> v = Vec8<T_>::load(H + ((n * Tt + t) * D + d8 * 8));
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const float f = v.get(i);
+            if (t == 0) { mx[i] = f; sm[i] = f; am[i] = 0; }
+            else { sm[i] += f; if (f > mx[i]) { mx[i] = f; am[i] = t; } }
+        }
+    }
+    Vec8<T_> o;
+    const float inv = 1.f / (float)Tt;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { o.set(i, mx[i] + sm[i] * inv); arg[n * D + d8 * 8 + i] = (uint8_t)am[i]; }
+    o.store(y + n * D + d8 * 8);
+}
+
+// dA[n][t][d] = (dy[n][d]/Tt + dy[n][d]*[t==arg]) * (H[n][t][d] > 0)
+template <typename T_>
+__global__ __launch_bounds__(256) void maxmean_bwd_kernel(const T_* __restrict__ dy, const uint8_t* __restrict__ arg,
+                                                          const T_* __restrict__ H, T_* __restrict__ dA, int N, int Tt, int D) {
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;          // over N * Tt * D/8
+    const int D8 = D / 8;
+    if (idx >= (long)N * Tt * D8) return;
+    const int d8 = (int)(idx % D8);
+    const long r = idx / D8;
+    const int t = (int)(r % Tt);
+    const long n = r / Tt;
+    const Vec8<T_> g = Vec8<T_>::load(dy + n * D + d8 * 8);
+    const Vec8<T_> h = Vec8<T_>::load(H + idx * 8);
+    Vec8<T_> o;
+    const float inv = 1.f / (float)Tt;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const float gi = g.get(i);
+        const float v = gi * inv + (arg[n * D + d8 * 8 + i] == t ? gi : 0.f);
+        o.set(i, h.get(i) > 0.f ? v : 0.f);
+    }
+    o.store(dA + idx * 8);
+}
+
+// --------------------------------------------------------------------------------------------- BatchNorm1d pieces
+// h = act(scale*a + shift), elementwise over [M][C]
+template <typename T_>
+__global__ __launch_bounds__(256) void colbn_fwd_kernel(const T_* __restrict__ a, const float* __restrict__ scale,
+                                                        const float* __restrict__ shift, int relu, T_* __restrict__ h, long M, int C) {
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    const int C8 = C / 8;
+    if (idx >= M * C8) return;
+    const int c8 = (int)(idx % C8);
+    const Vec8<T_> v = Vec8<T_>::load(a + idx * 8);
+    Vec8<T_> o;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        float f = scale[c8 * 8 + i] * v.get(i) + shift[c8 * 8 + i];
+        o.set(i, relu ? fmaxf(f, 0.f) : f);
+    }
+    o.store(h + idx * 8);
+}
+
+// stats: sg[c] = sum_b g, sgx[c] = sum_b g*xhat with g = dh * (act > 0 if relu), xhat = (a-mean)*rstd   (fp64 atomics)
+template <typename T_>
+__global__ __launch_bounds__(256) void colbn_bwd_stats_kernel(const T_* __restrict__ a, const T_* __restrict__ dh,
+                                                              const float* __restrict__ scale, const float* __restrict__ shift,
+                                                              const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                              int relu, long M, int C, int rows_per_block,
+                                                              double* __restrict__ sg, double* __restrict__ sgx) {
+    __shared__ float red[256][17];
+    const int G = C / 8 > 256 ? 256 : C / 8, RPI = 256 / G;
+    const int cg = threadIdx.x % G + blockIdx.y * 256, r0 = threadIdx.x / G;
+    const long rb = (long)blockIdx.x * rows_per_block, re = min(M, rb + rows_per_block);
+    float s[8], q[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { s[i] = 0.f; q[i] = 0.f; }
+    for (long r = rb + r0; r < re; r += RPI) {
+        const Vec8<T_> va = Vec8<T_>::load(a + r * C + cg * 8);
+        const Vec8<T_> vg = Vec8<T_>::load(dh + r * C + cg * 8);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int c = cg * 8 + i;
+            const float x = va.get(i);
+            float g = vg.get(i);
+            if (relu && !(scale[c] * x + shift[c] > 0.f)) g = 0.f;
+            s[i] += g;
+            q[i] += g * (x - mean[c]) * rstd[c];
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { red[threadIdx.x][i] = s[i]; red[threadIdx.x][8 + i] = q[i]; }
+    __syncthreads();
+    for (int o = threadIdx.x; o < G * 16; o += 256) {
+        const int g = o / 16, k = o % 16;
+        double t = 0.0;
+        for (int r = 0; r < RPI; ++r) t += (double)red[r * G + g][k];
+        const int c = (g + blockIdx.y * 256) * 8 + (k & 7);
+        if (k < 8) atomicAdd(&sg[c], t); else atomicAdd(&sgx[c], t);
+    }
+}
+
+// da = scale * (g - sg/M - xhat*sgx/M); rows handled by block 0 also accumulate the parameter grads.
+template <typename T_>
+__global__ __launch_bounds__(256) void colbn_bwd_apply_kernel(const T_* __restrict__ a, const T_* __restrict__ dh,
+                                                              const float* __restrict__ scale, const float* __restrict__ shift,
+                                                              const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                              int relu, long M, int C, const double* __restrict__ sg,
+                                                              const double* __restrict__ sgx, T_* __restrict__ da,
+                                                              float* dgamma, float* dbeta) {
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    const int C8 = C / 8;
+    if (idx >= M * C8) return;
+    const int c8 = (int)(idx % C8);
+    const long row = idx / C8;
+    const Vec8<T_> va = Vec8<T_>::load(a + idx * 8);
+    const Vec8<T_> vg = Vec8<T_>::load(dh + idx * 8);
+    Vec8<T_> o;
+    const float invM = 1.f / (float)M;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int c = c8 * 8 + i;
+        const float x = va.get(i);
+        float g = vg.get(i);
+        if (relu && !(scale[c] * x + shift[c] > 0.f)) g = 0.f;
+        const float xhat = (x - mean[c]) * rstd[c];
+        const float mg = (float)sg[c] * invM, mgx = (float)sgx[c] * invM;
+        o.set(i, scale[c] * (g - mg - xhat * mgx));
+        if (row == 0 && dgamma) { dgamma[c] += (float)sgx[c]; dbeta[c] += (float)sg[c]; }
+    }
+    o.store(da + idx * 8);
+}
+
+__global__ void add_d2f_kernel(const double* __restrict__ src, float* __restrict__ dst, int n) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) dst[i] += (float)src[i];
+}
+
+// --------------------------------------------------------------------------------------------- Barlow loss on c
+// c [D][D] fp32 (already divided by the batch).  loss_out[0] += coef * sum (c - I)^2 ; dc = dscale * (c - I) as T_
+template <typename T_>
+__global__ __launch_bounds__(256) void barlow_loss_kernel(const float* __restrict__ c, int D, float coef, float dscale,
+                                                          T_* __restrict__ dc, float* __restrict__ loss_out) {
+    __shared__ float sh[16];
+    const long total = (long)D * D;
+    float acc = 0.f;
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+        const int i = (int)(idx / D), j = (int)(idx - (long)i * D);
+        const float v = c[idx] - (i == j ? 1.f : 0.f);
+        acc += v * v;
+        dc[idx] = from_f32<T_>(dscale * v);
+    }
+    acc = block_sum(acc, sh);
+    if (threadIdx.x == 0) atomicAdd(loss_out, coef * acc);
+}
+
+// --------------------------------------------------------------------------------------------- MoCo head
+// one wave per row: qn = q / max(||q||, 1e-12)
+template <typename T_>
+__global__ __launch_bounds__(64) void l2norm_fwd_kernel(const float* __restrict__ q, int D, T_* __restrict__ qn,
+                                                        float* __restrict__ qn32, float* __restrict__ inv_norm) {
+    const long b = blockIdx.x;
+    float s = 0.f;
+    for (int d = threadIdx.x; d < D; d += 64) { const float v = q[b * D + d]; s += v * v; }
+    s = wave_sum(s);
+    const float inv = 1.f / fmaxf(sqrtf(s), 1e-12f);
+    for (int d = threadIdx.x; d < D; d += 64) {
+        const float v = q[b * D + d] * inv;
+        qn32[b * D + d] = v;
+        qn[b * D + d] = from_f32<T_>(v);
+    }
+    if (threadIdx.x == 0) inv_norm[b] = inv;
+}
+
+// lpos[b] = <qn_b, kn_b> / temp
+__global__ __launch_bounds__(64) void rowdot_kernel(const float* __restrict__ a, const float* __restrict__ bb, int D, float scale,
+                                                    float* __restrict__ out) {
+    const long b = blockIdx.x;
+    float s = 0.f;
+    for (int d = threadIdx.x; d < D; d += 64) s += a[b * D + d] * bb[b * D + d];
+    s = wave_sum(s);
+    if (threadIdx.x == 0) out[b] = s * scale;
+}
+
+// logits row = [lpos, lneg[0..K)] (already divided by temp); CE with label 0, mean over the batch.
+__global__ __launch_bounds__(256) void moco_ce_fwd_kernel(const float* __restrict__ lpos, const float* __restrict__ lneg, int K,
+                                                          float inv_B, float* __restrict__ lse, float* __restrict__ loss_out) {
+    __shared__ float sh[16];
+    const long b = blockIdx.x;
+    const float* row = lneg + b * K;
+    float m = lpos[b];
+    for (int k = threadIdx.x; k < K; k += 256) m = fmaxf(m, row[k]);
+    m = wave_max(m);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = m;
+    __syncthreads();
+    m = fmaxf(fmaxf(sh[0], sh[1]), fmaxf(sh[2], sh[3]));
+    float s = 0.f;
+    for (int k = threadIdx.x; k < K; k += 256) s += expf(row[k] - m);
+    s = block_sum(s, sh);
+    if (threadIdx.x == 0) {
+        s += expf(lpos[b] - m);
+        const float l = m + logf(s);
+        lse[b] = l;
+        atomicAdd(loss_out, (l - lpos[b]) * inv_B);
+    }
+}
+
+// P[b][k] = softmax_neg * gscale (T_), dlpos[b] = (softmax_pos - 1) * gscale;  gscale = 1/(B*temp)
+template <typename T_>
+__global__ __launch_bounds__(256) void moco_ce_bwd_kernel(const float* __restrict__ lpos, const float* __restrict__ lneg,
+                                                          const float* __restrict__ lse, int K, float gscale,
+                                                          T_* __restrict__ P, float* __restrict__ dlpos) {
+    const long b = blockIdx.y;
+    const float l = lse[b];
+    const long k = (long)blockIdx.x * 256 + threadIdx.x;
+    if (k < K) P[b * K + k] = from_f32<T_>(expf(lneg[b * K + k] - l) * gscale);
+    if (k == 0) dlpos[b] = (expf(lpos[b] - l) - 1.f) * gscale;
+}
+
+// dq = (g - qn <qn, g>) * inv_norm with g = dqn + dlpos * kn
+template <typename T_>
+__global__ __launch_bounds__(64) void l2norm_bwd_kernel(const float* __restrict__ dqn, const float* __restrict__ dlpos,
+                                                        const float* __restrict__ kn32, const float* __restrict__ qn32,
+                                                        const float* __restrict__ inv_norm, int D, T_* __restrict__ dq) {
+    const long b = blockIdx.x;
+    const float dl = dlpos[b];
+    float s = 0.f;
+    for (int d = threadIdx.x; d < D; d += 64) s += qn32[b * D + d] * (dqn[b * D + d] + dl * kn32[b * D + d]);
+    s = wave_sum(s);
+    const float inv = inv_norm[b];
+    for (int d = threadIdx.x; d < D; d += 64) {
+        const float g = dqn[b * D + d] + dl * kn32[b * D + d];
+        dq[b * D + d] = from_f32<T_>((g - qn32[b * D + d] * s) * inv);
+    }
+}
+
+// queue[:, ptr:ptr+B] = keys^T  (fp32 master [D][K] + T_ shadow)
+template <typename T_>
+__global__ __launch_bounds__(256) void enqueue_kernel(const float* __restrict__ keys, int B, int D, int K, int ptr,
+                                                      float* __restrict__ queue, T_* __restrict__ shadow) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= B * D) return;
+    const int d = idx / B, b = idx % B;
+    const float v = keys[(long)b * D + d];
+    queue[(long)d * K + ptr + b] = v;
+    if (shadow) shadow[(long)d * K + ptr + b] = from_f32<T_>(v);
+}
+
+// --------------------------------------------------------------------------------------------- flat-buffer plumbing
+// torch.optim.SGD: g += wd*p; buf = first ? g : mom*buf + g; p -= lr*buf
+__global__ __launch_bounds__(256) void sgd_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ buf,
+                                                  long n, float lr, float mom, float wd, int first, float gscale) {
+    for (long i = ((long)blockIdx.x * 256 + threadIdx.x) * 4; i < n; i += (long)gridDim.x * 1024) {
+        if (i + 4 <= n) {
+            f32x4 pv = *reinterpret_cast<f32x4*>(p + i);
+            const f32x4 gv = *reinterpret_cast<const f32x4*>(g + i);
+            f32x4 bv = first ? f32x4{0, 0, 0, 0} : *reinterpret_cast<f32x4*>(buf + i);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float gg = gv[k] * gscale + wd * pv[k];
+                bv[k] = first ? gg : mom * bv[k] + gg;
+                pv[k] -= lr * bv[k];
+            }
+            *reinterpret_cast<f32x4*>(buf + i) = bv;
+            *reinterpret_cast<f32x4*>(p + i) = pv;
+        } else {
+            for (long j = i; j < n; ++j) {
+                const float gg = g[j] * gscale + wd * p[j];
+                const float b = first ? gg : mom * buf[j] + gg;
+                buf[j] = b;
+                p[j] -= lr * b;
+            }
+        }
+    }
+}
+
+// pk = pk*m + pq*(1-m)
+__global__ __launch_bounds__(256) void ema_kernel(float* __restrict__ pk, const float* __restrict__ pq, long n, float m) {
+    const float om = 1.f - m;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) pk[i] = pk[i] * m + pq[i] * om;
+}
+
+template <typename T_>
+__global__ __launch_bounds__(256) void cast_kernel(const float* __restrict__ src, T_* __restrict__ dst, long n) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) dst[i] = from_f32<T_>(src[i]);
+}
+
+template <typename T_>
+__global__ __launch_bounds__(256) void cast_back_kernel(const T_* __restrict__ src, float* __restrict__ dst, long n) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) dst[i] = to_f32(src[i]);
+}
+
+// counter-based keep mask: keep iff hash(seed, index) >= p * 2^32  (splitmix64 finaliser)
+__global__ __launch_bounds__(256) void dropout_mask_kernel(uint8_t* __restrict__ keep, long n, unsigned long long seed, float p) {
+    const unsigned int thr = (unsigned int)fminf(p * 4294967296.f, 4294967295.f);
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        unsigned long long z = seed + 0x9E3779B97F4A7C15ull * (unsigned long long)(i + 1);
+        z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+        z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+        z = z ^ (z >> 31);
+        keep[i] = ((unsigned int)(z >> 32) >= thr) ? 1 : 0;
+    }
+}
+
+}  // namespace
+
+#define S_(stream) static_cast<hipStream_t>(stream)
+#define GRID1(n) dim3((unsigned)(((long)(n) + 255) / 256))
+
+extern "C" int audiossl_maxmean_fwd(int dtype, const void* H, void* y, uint8_t* arg, int N, int Tt, int D, void* stream) {
+    ASSL_REQUIRE(H && y && arg && N > 0 && Tt > 0 && Tt < 256 && D > 0 && (D % 8) == 0 && (dtype == 0 || dtype == 1));
+    const long total = (long)N * D / 8;
+    if (dtype == 0) hipLaunchKernelGGL(maxmean_fwd_kernel<float>, GRID1(total), dim3(256), 0, S_(stream), (const float*)H, (float*)y, arg, N, Tt, D);
+    else            hipLaunchKernelGGL(maxmean_fwd_kernel<bf16>, GRID1(total), dim3(256), 0, S_(stream), (const bf16*)H, (bf16*)y, arg, N, Tt, D);
+    ASSL_LAUNCH_CHECK();
+}
+
+extern "C" int audiossl_maxmean_bwd(int dtype, const void* dy, const uint8_t* arg, const void* H, void* dA, int N, int Tt, int D,
+                                    void* stream) {
+    ASSL_REQUIRE(dy && arg && H && dA && N > 0 && Tt > 0 && D > 0 && (D % 8) == 0 && (dtype == 0 || dtype == 1));
+    const long total = (long)N * Tt * D / 8;
+    if (dtype == 0) hipLaunchKernelGGL(maxmean_bwd_kernel<float>, GRID1(total), dim3(256), 0, S_(stream), (const float*)dy, arg, (const float*)H, (float*)dA, N, Tt, D);
+    else            hipLaunchKernelGGL(maxmean_bwd_kernel<bf16>, GRID1(total), dim3(256), 0, S_(stream), (const bf16*)dy, arg, (const bf16*)H, (bf16*)dA, N, Tt, D);
+    ASSL_LAUNCH_CHECK();
+}
+
+extern "C" int audiossl_colbn_fwd(int dtype, const void* a, const float* scale, const float* shift, int relu, void* h, long M,
+                                  int C, void* stream) {
+    ASSL_REQUIRE(a && scale && shift && h && M > 0 && C > 0 && (C % 8) == 0 && (dtype == 0 || dtype == 1));
+    const long total = M * C / 8;
+    if (dtype == 0) hipLaunchKernelGGL(colbn_fwd_kernel<float>, GRID1(total), dim3(256), 0, S_(stream), (const float*)a, scale, shift, relu, (float*)h, M, C);
+    else            hipLaunchKernelGGL(colbn_fwd_kernel<bf16>, GRID1(total), dim3(256), 0, S_(stream), (const bf16*)a, scale, shift, relu, (bf16*)h, M, C);
+    ASSL_LAUNCH_CHECK();
+}
+
+// tmp: 2*C doubles of scratch.  dgamma/dbeta may be null (affine=False); otherwise accumulated (+=).
+extern "C" int audiossl_colbn_bwd(int dtype, const void* a, const void* dh, const float* scale, const float* shift,
+                                  const float* mean, const float* rstd, int relu, long M, int C, double* tmp, void* da,
+                                  float* dgamma, float* dbeta, void* stream) {
+    ASSL_REQUIRE(a && dh && scale && shift && mean && rstd && tmp && da && M > 0 && C > 0 && (C % 8) == 0);
+    ASSL_REQUIRE((dtype == 0 || dtype == 1) && ((C / 8 <= 256 && 256 % (C / 8) == 0) || C % 2048 == 0));
+    hipStream_t s = S_(stream);
+    if (hipMemsetAsync(tmp, 0, sizeof(double) * 2 * C, s) != hipSuccess) return ASSL_ELAUNCH;
+    const int G = C / 8 > 256 ? 256 : C / 8, RPI = 256 / G;
+    const int rpb = RPI * 32;
+    dim3 grid(ceil_div(M, rpb), C / 8 > 256 ? C / 2048 : 1);
+    const long total = M * C / 8;
+#define CB(TT) do {                                                                                                                  \
+    hipLaunchKernelGGL(colbn_bwd_stats_kernel<TT>, grid, dim3(256), 0, s, (const TT*)a, (const TT*)dh, scale, shift, mean, rstd, relu, \
+                       M, C, rpb, tmp, tmp + C);                                                                                      \
+    hipLaunchKernelGGL(colbn_bwd_apply_kernel<TT>, GRID1(total), dim3(256), 0, s, (const TT*)a, (const TT*)dh, scale, shift, mean,     \
+                       rstd, relu, M, C, tmp, tmp + C, (TT*)da, dgamma, dbeta); } while (0)
+    if (dtype == 0) CB(float); else CB(bf16);
+#undef CB
+    ASSL_LAUNCH_CHECK();
+}
+
+extern "C" int audiossl_add_d2f(const double* src, float* dst, int n, void* stream) {
+    ASSL_REQUIRE(src && dst && n > 0);
+    hipLaunchKernelGGL(add_d2f_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, S_(stream), src, dst, n);
+    ASSL_LAUNCH_CHECK();
+}
+
+extern "C" int audiossl_barlow_loss(int dtype, const float* c, int D, float coef, float dscale, void* dc, float* loss_out,
+                                    void* stream) {
+    ASSL_REQUIRE(c && dc && loss_out && D > 0 && (dtype == 0 || dtype == 1));
+    const int grid = min(2048, ceil_div((long)D * D, 256));
+    if (dtype == 0) hipLaunchKernelGGL(barlow_loss_kernel<float>, dim3(grid), dim3(256), 0, S_(stream), c, D, coef, dscale, (float*)dc, loss_out);
+    else            hipLaunchKernelGGL(barlow_loss_kernel<bf16>, dim3(grid), dim3(256), 0, S_(stream), c, D, coef, dscale, (bf16*)dc, loss_out);
+    ASSL_LAUNCH_CHECK();
+}
+
+extern "C" int audiossl_l2norm_fwd(int dtype, const float* q, int B, int D, void* qn, float* qn32, float* inv_norm, void* stream) {
+    ASSL_REQUIRE(q && qn && qn32 && inv_norm && B > 0 && D > 0 && (dtype == 0 || dtype == 1));
+    if (dtype == 0) hipLaunchKernelGGL(l2norm_fwd_kernel<float>, dim3(B), dim3(64), 0, S_(stream), q, D, (float*)qn, qn32, inv_norm);
+    else            hipLaunchKernelGGL(l2norm_fwd_kernel<bf16>, dim3(B), dim3(64), 0, S_(stream), q, D, (bf16*)qn, qn32, inv_norm);
+    ASSL_LAUNCH_CHECK();
+}
+
+extern "C" int audiossl_rowdot(const float* a, const float* b, int B, int D, float scale, float* out, void* stream) {
+    ASSL_REQUIRE(a && b && out && B > 0 && D > 0);
+    hipLaunchKernelGGL(rowdot_kernel, dim3(B), dim3(64), 0, S_(stream), a, b, D, scale, out);
+    ASSL_LAUNCH_CHECK();
+}
+
+extern "C" int audiossl_moco_ce_fwd(const float* lpos, const float* lneg, int B, int K, float* lse, float* loss_out, void* stream) {
+    ASSL_REQUIRE(lpos && lneg && lse && loss_out && B > 0 && K > 0);
+    hipLaunchKernelGGL(moco_ce_fwd_kernel, dim3(B), dim3(256), 0, S_(stream), lpos, lneg, K, 1.f / (float)B, lse, loss_out);
+    ASSL_LAUNCH_CHECK();
+}
+
+extern "C" int audiossl_moco_ce_bwd(int dtype, const float* lpos, const float* lneg, const float* lse, int B, int K, float gscale,
+                                    void* P, float* dlpos, void* stream) {
+    ASSL_REQUIRE(lpos && lneg && lse && P && dlpos && B > 0 && K > 0 && (dtype == 0 || dtype == 1));
+    dim3 grid(ceil_div(K, 256), B);
+    if (dtype == 0) hipLaunchKernelGGL(moco_ce_bwd_kernel<float>, grid, dim3(256), 0, S_(stream), lpos, lneg, lse, K, gscale, (float*)P, dlpos);
+    else            hipLaunchKernelGGL(moco_ce_bwd_kernel<bf16>, grid, dim3(256), 0, S_(stream), lpos, lneg, lse, K, gscale, (bf16*)P, dlpos);
+    ASSL_LAUNCH_CHECK();
+}
+
+extern "C" int audiossl_l2norm_bwd(int dtype, const float* dqn, const float* dlpos, const float* kn32, const float* qn32,
+                                   const float* inv_norm, int B, int D, void* dq, void* stream) {
+    ASSL_REQUIRE(dqn && dlpos && kn32 && qn32 && inv_norm && dq && B > 0 && D > 0 && (dtype == 0 || dtype == 1));
+    if (dtype == 0) hipLaunchKernelGGL(l2norm_bwd_kernel<float>, dim3(B), dim3(64), 0, S_(stream), dqn, dlpos, kn32, qn32, inv_norm, D, (float*)dq);
+    else            hipLaunchKernelGGL(l2norm_bwd_kernel<bf16>, dim3(B), dim3(64), 0, S_(stream), dqn, dlpos, kn32, qn32, inv_norm, D, (bf16*)dq);
+    ASSL_LAUNCH_CHECK();
+}
+
+extern "C" int audiossl_enqueue(int dtype, const float* keys, int B, int D, int K, int ptr, float* queue, void* shadow, void* stream) {
+    ASSL_REQUIRE(keys && queue && B > 0 && D > 0 && K > 0 && ptr >= 0 && ptr + B <= K && (dtype == 0 || dtype == 1));
+    const int grid = ceil_div((long)B * D, 256);
+    if (dtype == 0) hipLaunchKernelGGL(enqueue_kernel<float>, dim3(grid), dim3(256), 0, S_(stream), keys, B, D, K, ptr, queue, (float*)shadow);
+    else            hipLaunchKernelGGL(enqueue_kernel<bf16>, dim3(grid), dim3(256), 0, S_(stream), keys, B, D, K, ptr, queue, (bf16*)shadow);
+    ASSL_LAUNCH_CHECK();
+}
+
+extern "C" int audiossl_sgd_momentum(float* p, const float* g, float* buf, long n, float lr, float momentum, float weight_decay,
+                                     int first, float grad_scale, void* stream) {
+    ASSL_REQUIRE(p && g && buf && n > 0);
+    if (!ASSL_ALIGNED16(p) || !ASSL_ALIGNED16(g) || !ASSL_ALIGNED16(buf)) return ASSL_EALIGN;
+    const int grid = (int)min((long)2048, (n + 1023) / 1024);
+    hipLaunchKernelGGL(sgd_kernel, dim3(grid), dim3(256), 0, S_(stream), p, g, buf, n, lr, momentum, weight_decay, first, grad_scale);
+    ASSL_LAUNCH_CHECK();
+}
+
+extern "C" int audiossl_ema_update(float* pk, const float* pq, long n, float m, void* stream) {
+    ASSL_REQUIRE(pk && pq && n > 0);
+    const int grid = (int)min((long)2048, (n + 255) / 256);
+    hipLaunchKernelGGL(ema_kernel, dim3(grid), dim3(256), 0, S_(stream), pk, pq, n, m);
+    ASSL_LAUNCH_CHECK();
+}
+
+extern "C" int audiossl_cast(int dtype, const float* src, void* dst, long n, void* stream) {
+    ASSL_REQUIRE(src && dst && n > 0 && (dtype == 0 || dtype == 1));
+    const int grid = (int)min((long)4096, (n + 255) / 256);
+    if (dtype == 0) hipLaunchKernelGGL(cast_kernel<float>, dim3(grid), dim3(256), 0, S_(stream), src, (float*)dst, n);
+    else            hipLaunchKernelGGL(cast_kernel<bf16>, dim3(grid), dim3(256), 0, S_(stream), src, (bf16*)dst, n);
+    ASSL_LAUNCH_CHECK();
+}
+
+extern "C" int audiossl_cast_back(int dtype, const void* src, float* dst, long n, void* stream) {
+    ASSL_REQUIRE(src && dst && n > 0 && (dtype == 0 || dtype == 1));
+    const int grid = (int)min((long)4096, (n + 255) / 256);
+    if (dtype == 0) hipLaunchKernelGGL(cast_back_kernel<float>, dim3(grid), dim3(256), 0, S_(stream), (const float*)src, dst, n);
+    else            hipLaunchKernelGGL(cast_back_kernel<bf16>, dim3(grid), dim3(256), 0, S_(stream), (const bf16*)src, dst, n);
+    ASSL_LAUNCH_CHECK();
+}
+
+extern "C" int audiossl_dropout_mask(uint8_t* keep, long n, unsigned long long seed, float p, void* stream) {
+    ASSL_REQUIRE(keep && n > 0 && p >= 0.f && p < 1.f);
+    const int grid = (int)min((long)4096, (n + 255) / 256);
+    hipLaunchKernelGGL(dropout_mask_kernel, dim3(grid), dim3(256), 0, S_(stream), keep, n, seed, p);
+    ASSL_LAUNCH_CHECK();
+}

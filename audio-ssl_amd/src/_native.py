@@ -1,0 +1,91 @@
+"""ctypes binding of libaudiossl_hip.so - the only door from Python into the HIP kernels.
+
+The prototypes are parsed from `include/audiossl_hip.h` (single source of truth for the C ABI).  There is
+NO fallback: if the shared object is missing or a call fails, a RuntimeError is raised.
+PyTorch is used above this layer for device memory and streams only.
+"""
+import ctypes
+import os
+import re
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_PKG = os.path.dirname(_HERE)
+LIB_PATH = os.path.join(_PKG, "lib", "libaudiossl_hip.so")
+HEADER_PATH = os.path.join(os.path.dirname(_PKG), "include", "audiossl_hip.h")
+
+F32, BF16 = 0, 1
+ERRORS = {-1: "AUDIOSSL_EINVAL (bad shape / null pointer / unsupported configuration)",
+          -2: "AUDIOSSL_ELAUNCH (HIP launch error)",
+          -3: "AUDIOSSL_EALIGN (pointer or leading dimension not 16-byte aligned)"}
+
+_SCALARS = {"int": ctypes.c_int, "long": ctypes.c_long, "float": ctypes.c_float, "double": ctypes.c_double,
+            "unsigned long long": ctypes.c_ulonglong, "long long": ctypes.c_longlong}
+
+
+def parse_header(path=HEADER_PATH):
+    """-> {name: [(argname, ctype), ...]} for every `int audiossl_*(...)` prototype."""
+    text = open(path).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    protos = {}
+    for m in re.finditer(r"\bint\s+(audiossl_\w+)\s*\((.*?)\)\s*;", text, flags=re.S):
+        args = []
+        for a in m.group(2).split(","):
+            a = " ".join(a.split())
+            if "*" in a:
+                args.append((a.split("*")[-1].strip(), ctypes.c_void_p))
+            else:
+                ty, nm = a.rsplit(" ", 1)
+                args.append((nm, _SCALARS[ty.replace("const ", "").strip()]))
+        protos[m.group(1)] = args
+    return protos
+
+
+PROTOS = parse_header()
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(f"{LIB_PATH} is missing - build it with `python audio-ssl_amd/build.py` "
+                               "(the audiossl HIP path has no CPU fallback)")
+        _lib = ctypes.CDLL(LIB_PATH)
+        for name, args in PROTOS.items():
+            fn = getattr(_lib, name)            # AttributeError here = header / library mismatch
+            fn.restype = ctypes.c_int
+            fn.argtypes = [t for _, t in args]
+    return _lib
+
+
+def _ptr(x):
+    if x is None:
+        return None
+    if isinstance(x, torch.Tensor):
+        if not x.is_cuda:
+            raise RuntimeError("audiossl HIP kernels need device tensors (no CPU fallback exists)")
+        if not x.is_contiguous():
+            raise RuntimeError("audiossl HIP kernels need contiguous tensors")
+        return x.data_ptr()
+    return int(x)
+
+
+def call(name, *args):
+    """Call `audiossl_<name>`; the trailing `stream` argument is filled with torch's current HIP stream."""
+    full = name if name.startswith("audiossl_") else "audiossl_" + name
+    proto = PROTOS[full]
+    if len(args) != len(proto) - 1:
+        raise TypeError(f"{full} takes {len(proto) - 1} arguments (+stream), got {len(args)}")
+    conv = []
+    for (an, ty), v in zip(proto, args):
+        conv.append(_ptr(v) if ty is ctypes.c_void_p else v)
+    conv.append(torch.cuda.current_stream().cuda_stream)
+    rc = getattr(lib(), full)(*conv)
+    if rc != 0:
+        raise RuntimeError(f"{full} failed: {ERRORS.get(rc, rc)}")
+
+
+def torch_dtype(dtype):
+    return torch.float32 if dtype == F32 else torch.bfloat16

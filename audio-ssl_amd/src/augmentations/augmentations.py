@@ -1,0 +1,271 @@
+"""Two-view augmentation front end: host planner + HIP kernels.
+
+Mirror of the reference's `src/augmentations/__init__.py:5-35` (AugmentationModule) and
+`augmentations.py` (RunningNorm :215-286, MixupBYOLA :82-116, RandomResizeCrop :14-61), re-designed for
+the GPU: the per-clip Python chain of the reference becomes, per *batch*,
+
+  host   : draw every random parameter with the SAME generators in the SAME order as the reference
+           (global `numpy.random` and python `random`; SURVEY a8') -> two small tables
+  device : clip_moments -> runnorm_scan (sequential recurrence, one thread) -> aug_normalize (writes the
+           normalised clips into a device ring that doubles as MixupBYOLA's 2048-entry FIFO) ->
+           aug_views (mix + bicubic random-resize-crop, one block per (clip, view))
+           [-> mask_fill for the optional SpecAugment band masks]
+
+The reference's FIFO receives every clip twice (once per view).  Entry g of that virtual sequence is
+clip g//2, so `bank[k]` resolves to a clip index and the device ring only keeps the last 1025 + B
+distinct normalised clips.  Semantics are those of one sequential stream (DataLoader worker count 0).
+"""
+import random
+
+import numpy as np
+import torch
+from torch import nn
+
+from src import _native as N
+
+__all__ = ["AugmentationModule", "RunningNorm", "MixupBYOLA", "RandomResizeCrop", "SpecAugment", "log_mixup_exp",
+           "PrecomputedNorm", "NormalizeBatch"]
+
+_F32 = np.float32
+
+
+def log_mixup_exp(xa, xb, alpha):
+    """Reference formula (augmentations.py:8-12), torch ops; kept for API parity / small host-side use."""
+    x = alpha * xa.exp() + (1.0 - alpha) * xb.exp()
+    return torch.log(x + torch.finfo(x.dtype).eps)
+
+
+class RunningNorm(nn.Module):
+    """Configuration + device state of the running normaliser (statistics live on the GPU)."""
+
+    def __init__(self, epoch_samples, max_update_epochs=10, axis=(1, 2)):
+        super().__init__()
+        self.max_update = int(epoch_samples * max_update_epochs)
+        self.axis = list(axis)
+        self.state_i = None      # int64 [2] = {n_seen, max_update}
+        self.state_f = None      # float32 [2] = {mu, s2}
+
+    def device_state(self, device):
+        if self.state_i is None:
+            self.state_i = torch.tensor([0, self.max_update], dtype=torch.int64, device=device)
+            self.state_f = torch.zeros(2, dtype=torch.float32, device=device)
+        return self.state_i, self.state_f
+
+    def __len__(self):
+        return 0 if self.state_i is None else int(self.state_i[0])
+
+    @property
+    def mean(self):
+        return None if self.state_f is None else self.state_f[0]
+
+    @property
+    def std(self):
+        if self.state_f is None:
+            return None
+        return torch.clamp(torch.sqrt(self.state_f[1]), torch.finfo().eps, torch.finfo().max)
+
+    def __repr__(self):
+        return self.__class__.__name__ + f"(max_update={self.max_update},axis={self.axis})"
+
+
+class MixupBYOLA(nn.Module):
+    def __init__(self, ratio=0.4, n_memory=2048, log_mixup_exp=True):
+        super().__init__()
+        self.ratio, self.n, self.log_mixup_exp = ratio, n_memory, log_mixup_exp
+
+    def __repr__(self):
+        return self.__class__.__name__ + f"(ratio={self.ratio},n={self.n},log_mixup_exp={self.log_mixup_exp})"
+
+
+class RandomResizeCrop(nn.Module):
+    def __init__(self, virtual_crop_scale=(1.0, 1.5), freq_scale=(0.6, 1.5), time_scale=(0.6, 1.5)):
+        super().__init__()
+        assert time_scale[1] >= 1.0 and freq_scale[1] >= 1.0
+        self.virtual_crop_scale, self.freq_scale, self.time_scale = virtual_crop_scale, freq_scale, time_scale
+        self.interpolation = "bicubic"
+
+    @staticmethod
+    def get_params(virtual_crop_size, in_size, time_scale, freq_scale):
+        canvas_h, canvas_w = virtual_crop_size
+        src_h, src_w = in_size
+        h = int(np.clip(int(np.random.uniform(*freq_scale) * src_h), 1, canvas_h))
+        w = int(np.clip(int(np.random.uniform(*time_scale) * src_w), 1, canvas_w))
+        i = random.randint(0, canvas_h - h) if canvas_h > h else 0
+        j = random.randint(0, canvas_w - w) if canvas_w > w else 0
+        return i, j, h, w
+
+    def __repr__(self):
+        s = self.__class__.__name__ + f"(virtual_crop_size={self.virtual_crop_scale}"
+        s += ", time_scale={0}".format(tuple(round(v, 4) for v in self.time_scale))
+        return s + ", freq_scale={0})".format(tuple(round(v, 4) for v in self.freq_scale))
+
+
+class SpecAugment(nn.Module):
+    """Frequency / time band masks of `extras/delores-s/specaugment.py:68-122` (time_warp excluded: it calls the
+    removed torch.solve).  Draw order per view: all frequency masks, then all time masks."""
+
+    def __init__(self, F=30, T=40, num_freq_masks=2, num_time_masks=2, replace_with_zero=False):
+        super().__init__()
+        self.F, self.T, self.nf, self.nt, self.zero = F, T, num_freq_masks, num_time_masks, replace_with_zero
+
+    def plan(self, n_mel, n_time):
+        """-> list of (axis, start, end); axis 1 = frequency rows, 0 = time columns."""
+        out = []
+        for axis, width, size, count in ((1, self.F, n_mel, self.nf), (0, self.T, n_time, self.nt)):
+            for _ in range(count):
+                f = random.randrange(0, width)
+                f0 = random.randrange(0, size - f)
+                if f == 0:
+                    break                                   # the reference returns out of this mask family
+                end = random.randrange(f0, f0 + f)
+                out.append((axis, f0, end))
+        return out
+
+    @property
+    def max_masks(self):
+        return self.nf + self.nt
+
+
+class PrecomputedNorm(nn.Module):
+    def __init__(self, stats, axis=(1, 2)):
+        super().__init__()
+        self.axis = list(axis)
+        self.mean, self.std = stats
+
+    def forward(self, X):
+        return (X - self.mean) / self.std
+
+
+class NormalizeBatch(nn.Module):
+    def __init__(self, axis=(0, 2, 3)):
+        super().__init__()
+        self.axis = list(axis)
+
+    def forward(self, X):
+        m = X.mean(dim=self.axis, keepdims=True)
+        s = torch.clamp(X.std(dim=self.axis, keepdims=True), torch.finfo().eps, torch.finfo().max)
+        return (X - m) / s
+
+
+class AugmentationModule:
+    """The Augmentation Module (same constructor and per-sample call as the reference; batched on the GPU)."""
+
+    def __init__(self, config, len_of_files, max_batch=1024):
+        aug = config["pretrain"]["augmentations"]
+        self.mix = self.rrc = self.spec = None
+        if "MixupBYOLA" in aug:
+            self.mix = MixupBYOLA(ratio=aug["MixupBYOLA"]["ratio"], log_mixup_exp=aug["MixupBYOLA"]["log_mixup_exp"])
+        if "RandomResizeCrop" in aug:
+            r = aug["RandomResizeCrop"]
+            self.rrc = RandomResizeCrop(virtual_crop_scale=r["virtual_crop_scale"], freq_scale=r["freq_crop_scale"],
+                                        time_scale=r["time_crop_scale"])
+        if "SpecAugment" in aug:
+            self.spec = SpecAugment(**aug["SpecAugment"])
+        for unsupported in ("Kmix", "PatchDrop"):
+            if unsupported in aug:
+                raise NotImplementedError(f"{unsupported} is not part of the HIP two-view path (SURVEY 2.4); drop the key")
+        self.train_transform = nn.Sequential(*[m for m in (self.mix, self.rrc, self.spec) if m is not None])
+        self.pre_norm = None
+        if config["pretrain"]["normalization"] == "mean_var":
+            self.pre_norm = RunningNorm(epoch_samples=2 * len_of_files)
+        self.n_memory = self.mix.n if self.mix is not None else 0
+        self.max_batch = max_batch
+        self.n_entries = 0        # entries appended to the reference's virtual FIFO so far
+        self.clips_seen = 0
+        self.bank = None          # [R][F*T] ring of normalised clips
+        self.R = 0
+        self.last_plan = None
+
+    # ------------------------------------------------------------------ host planner (bit-exact RNG order)
+    def plan(self, B, F, T):
+        ip = np.zeros((B, 2, 8), np.int32)
+        fp = np.zeros((B, 2, 2), _F32)
+        masks = []
+        ch = cw = 0
+        if self.rrc is not None:
+            ch, cw = int(F * self.rrc.virtual_crop_scale[0]), int(T * self.rrc.virtual_crop_scale[1])
+        for b in range(B):
+            c = self.clips_seen + b
+            for v in range(2):
+                e = ip[b, v]
+                e[0] = c % self.R
+                e[1] = -1
+                if self.mix is not None:
+                    alpha = self.mix.ratio * np.random.random()
+                    n_bank = min(self.n_entries, self.n_memory)
+                    if n_bank > 0:
+                        k = np.random.randint(n_bank)
+                        g = self.n_entries - n_bank + k
+                        e[1] = (g // 2) % self.R
+                        a1 = 1.0 - alpha
+                        fp[b, v, 0] = _F32(a1)
+                        fp[b, v, 1] = _F32(1.0 - a1)
+                    self.n_entries += 1
+                if self.rrc is not None:
+                    i, j, h, w = RandomResizeCrop.get_params((ch, cw), (F, T), self.rrc.time_scale, self.rrc.freq_scale)
+                    e[2:7] = (i, j, h, w, 1)
+                if self.spec is not None:
+                    masks.append(self.spec.plan(F, T))
+        self.clips_seen += B
+        return ip, fp, (ch, cw), masks
+
+    def _ensure_bank(self, B, n, device):
+        need = 1025 + max(B, self.max_batch)
+        if self.bank is None:
+            self.R = need
+            self.bank = torch.zeros(self.R, n, dtype=torch.float32, device=device)
+        elif need > self.R:
+            old, old_R = self.bank, self.R
+            self.R = need
+            self.bank = torch.zeros(self.R, n, dtype=torch.float32, device=device)
+            lo = max(0, self.clips_seen - 1025)
+            for c in range(lo, self.clips_seen):
+                self.bank[c % self.R].copy_(old[c % old_R])
+
+    # ------------------------------------------------------------------ batched device path
+    @torch.no_grad()
+    def augment_batch(self, lms):
+        """lms [B, F, T] or [B, 1, F, T] log-mel (device) -> (view1, view2), each [B, 1, F, T] float32."""
+        if lms.dim() == 4:
+            lms = lms[:, 0]
+        lms = lms.contiguous().float()
+        if not lms.is_cuda:
+            raise RuntimeError("AugmentationModule runs on the GPU only (no CPU fallback)")
+        B, F, T = lms.shape
+        n = F * T
+        dev = lms.device
+        self._ensure_bank(B, n, dev)
+        mu = torch.zeros(B, dtype=torch.float32, device=dev)
+        sd = torch.ones(B, dtype=torch.float32, device=dev)
+        if self.pre_norm is not None:
+            mom = torch.empty(B, 2, dtype=torch.float64, device=dev)
+            si, sf = self.pre_norm.device_state(dev)
+            N.call("clip_moments", lms, mom, B, n)
+            N.call("runnorm_scan", mom, B, n, si, sf, mu, sd)
+        slot0 = self.clips_seen % self.R
+        N.call("aug_normalize", lms, mu, sd, self.bank, slot0, self.R, B, n)
+        ip, fp, (ch, cw), masks = self.plan(B, F, T)
+        self.last_plan = (ip, fp, masks)
+        ip_d = torch.from_numpy(ip).to(dev, non_blocking=True)
+        fp_d = torch.from_numpy(fp).to(dev, non_blocking=True)
+        v1 = torch.empty(B, 1, F, T, dtype=torch.float32, device=dev)
+        v2 = torch.empty(B, 1, F, T, dtype=torch.float32, device=dev)
+        log_mix = 1 if (self.mix is None or self.mix.log_mixup_exp) else 0
+        N.call("aug_views", self.bank, self.R, ip_d, fp_d, v1, v2, B, F, T, max(ch, F), max(cw, T), log_mix)
+        if self.spec is not None:
+            K = self.spec.max_masks
+            tab = np.full((B, 2, K, 4), -1, np.int32)
+            for idx, ms in enumerate(masks):
+                for k, (axis, st, en) in enumerate(ms):
+                    tab[idx // 2, idx % 2, k] = (axis, st, en, 0)
+            for v, view in enumerate((v1, v2)):
+                t = torch.from_numpy(np.ascontiguousarray(tab[:, v])).to(dev)
+                N.call("mask_fill", view, t, B, K, F, T, int(self.spec.zero))
+        return v1, v2
+
+    def __call__(self, x):
+        """Per-sample form of the reference: x [1, F, T] -> (view1 [1, F, T], view2 [1, F, T])."""
+        src = x.device
+        v1, v2 = self.augment_batch(x.cuda() if not x.is_cuda else x)
+        v1, v2 = v1[0], v2[0]
+        return (v1, v2) if src.type == "cuda" else (v1.to(src), v2.to(src))

@@ -1,0 +1,146 @@
+/* audiossl_hip.h - C ABI of libaudiossl_hip.so (AMD MI355X / gfx950 only).
+ *
+ * The reference (Sreyan88/audio-ssl) has no native layer: its hot path is ATen ops called from
+ * Python.  This header is therefore the boundary a reference maintainer would bind with ctypes
+ * (see INTEGRATION.md); each entry point names the reference code it replaces (file:line under
+ * the reference root).
+ *
+ * Conventions
+ *   - every function returns 0 on success, <0 on error (AUDIOSSL_E*); nothing throws;
+ *   - all pointers are DEVICE pointers owned by the caller (no allocation, no ownership transfer),
+ *     16-byte aligned, contiguous unless a leading dimension is given;
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream); launches are asynchronous;
+ *   - `dtype` selects the storage/MFMA type of activations: 0 = fp32 (exact f32 MFMA, validation /
+ *     high-precision path), 1 = bf16 (fp32 accumulate; master weights, statistics and losses stay fp32);
+ *   - activations of the conv encoder are channels-last [N][T][F][64] (time, mel, channel), i.e. the
+ *     reference's x.permute(0,3,2,1) (src/encoder/audiontt.py:76,83,90,95), so its feature index d*64+c
+ *     is contiguous;
+ *   - gradient outputs named d* are ACCUMULATED (+=) into caller-zeroed buffers.
+ */
+#ifndef AUDIOSSL_HIP_H
+#define AUDIOSSL_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define AUDIOSSL_OK 0
+#define AUDIOSSL_EINVAL (-1)   /* bad shape / null pointer / unsupported configuration */
+#define AUDIOSSL_ELAUNCH (-2)  /* HIP reported an error at launch */
+#define AUDIOSSL_EALIGN (-3)   /* pointer / leading dimension not 16-byte aligned */
+
+/* ---- K1 front end: src/utils/utils.py:20-28 (MelSpectrogramLibrosa.__call__), :43-49 (log) ------------
+ * wave [B][L] f32 -> out [B][n_mels][T] f32, T = 1 + L/hop, centre reflect pad, periodic Hann `win`[1024],
+ * `tw` = exp(-2 pi i k/1024) as [1024][2], `melw` [n_mels][taps] = packed non-zero run of each filterbank
+ * row starting at bin mel_start[m]; out = mel(|X|^2 + eps_pow), or log(. + eps_log) when apply_log.  n_fft must be 1024. */
+int audiossl_logmel_fwd(const float* wave, float* out, int B, int L, int T, int n_fft, int hop, int n_mels, int taps,
+                        const float* win, const float* tw, const float* melw, const int* mel_start, float eps_pow,
+                        float eps_log, int apply_log, void* stream);
+
+/* ---- K2 RunningNorm: src/augmentations/augmentations.py:215-282 ----------------------------------------
+ * clip_moments: mom[c] = {sum x, sum x^2} (fp64) of clip c over n = F*T elements.
+ * runnorm_scan: sequential recurrence over the batch; state_i = {n_seen, max_update}, state_f = {mu, s2};
+ *               writes the (mean, std) each clip is normalised with. */
+int audiossl_clip_moments(const float* x, double* mom, int B, int n, void* stream);
+int audiossl_runnorm_scan(const double* mom, int B, int n_elem, long long* state_i, float* state_f, float* mu_out,
+                          float* sd_out, void* stream);
+/* bank[(slot0 + c) % R][:] = (x[c] - mu[c]) / sd[c]; the ring is also the MixupBYOLA memory bank. */
+int audiossl_aug_normalize(const float* x, const float* mu, const float* sd, float* bank, long slot0, int R, int B, int n,
+                           void* stream);
+/* ---- K3+K4 MixupBYOLA + RandomResizeCrop: augmentations.py:8-12, 97-111 and :40-55 ---------------------
+ * ip [B][2][8] = {self_slot, partner_slot | -1, i, j, h, w, do_rrc, 0}; fp [B][2][2] = {coef_self, coef_partner}.
+ * out1/out2 [B][F][T] f32 = the two views. */
+int audiossl_aug_views(const float* bank, int R, const int* ip, const float* fp, float* out1, float* out2, int B, int F,
+                       int T, int canvas_h, int canvas_w, int log_mix, void* stream);
+/* ---- K5 SpecAugment band masks: extras/delores-s/specaugment.py:68-122 ---------------------------------
+ * tab [n_img][max_masks][4] = {axis (0 time, 1 freq, -1 stop), start, end, 0}; in place on x [n_img][F][T]. */
+int audiossl_mask_fill(float* x, const int* tab, int n_img, int max_masks, int F, int T, int zero_fill, void* stream);
+
+/* ---- K6 stem: src/encoder/audiontt.py:46-50 (features_1) ------------------------------------------------
+ * conv1_stats: batch statistics of Conv2d(1,64,3,p=1) output from 54 tap moments (`mom`, fp64 scratch, kept for
+ *   the backward); updates running stats; writes scale = gamma*rstd, shift = beta - mean*scale, mean, rstd.
+ * conv1_fwd : img [N][F][T] f32 -> pooled [N][T/2][F/2][64] (dtype), conv recomputed, nothing else stored.
+ * conv1_bwd : dP (+ dxl [N][F/2*64] / (T/2), may be NULL) -> dW [64][9], dgamma, dbeta (dbias == 0). */
+int audiossl_conv1_stats(const float* img, int N, int F, int T, const float* w, const float* bias, const float* gamma,
+                         const float* beta, float* running_mean, float* running_var, float momentum, float eps,
+                         double* mom, float* scale, float* shift, float* save_mean, float* save_rstd, void* stream);
+int audiossl_conv1_fwd(int dtype, const float* img, int N, int F, int T, const float* w, const float* bias,
+                       const float* scale, const float* shift, void* out, void* stream);
+int audiossl_conv1_bwd(int dtype, const float* img, int N, int F, int T, const float* w, const float* bias,
+                       const float* gamma, const float* scale, const float* shift, const float* mean, const float* rstd,
+                       const double* mom, const void* dP, const void* dxl, float* acc, float* dW, float* dbias,
+                       float* dgamma, float* dbeta, void* stream);
+
+/* ---- K7/K8 conv blocks 2,3: audiontt.py:52-60, 76-93 ----------------------------------------------------
+ * colstats : per-column sum / sum of squares of x [M][C] (ld) in fp64.
+ * bn_finalize: train-mode BatchNorm statistics -> scale/shift/mean/rstd (+ running stats, momentum 0.1).
+ * bn_relu_pool_fwd: Y [N][Ti][Fi][64] -> P [N][Ti/2][Fi/2][64].   tmean_fwd: P -> xl [N][Fo*64] (x_1/x_2/x_3).
+ * bn_relu_pool_bwd: dP (+dxl/To) -> dY at every position, dgamma, dbeta (stat = 128 floats scratch).
+ * im2col3x3 / pack_conv_w / unpack_conv_dw: implicit-GEMM plumbing, tap = kh*3+kw, kh on mel, kw on time. */
+int audiossl_colstats(int dtype, const void* x, long M, int C, long ld, int want_sq, double* sum, double* sumsq,
+                      void* stream);
+int audiossl_bn_finalize(const double* sum, const double* sumsq, double count, int C, const float* gamma,
+                         const float* beta, float* running_mean, float* running_var, float momentum, float eps,
+                         float* scale, float* shift, float* save_mean, float* save_rstd, void* stream);
+int audiossl_bn_relu_pool_fwd(int dtype, const void* Y, const float* scale, const float* shift, void* P, int N, int Ti,
+                              int Fi, void* stream);
+int audiossl_tmean_fwd(int dtype, const void* P, void* xl, int N, int To, int Fo, void* stream);
+int audiossl_bn_relu_pool_bwd(int dtype, const void* Y, const void* dP, const void* dxl, const float* scale,
+                              const float* shift, const float* mean, const float* rstd, float* stat, void* dY,
+                              float* dgamma, float* dbeta, int N, int Ti, int Fi, void* stream);
+int audiossl_im2col3x3(int dtype, const void* X, void* col, int N, int Ti, int Fi, void* stream);
+int audiossl_pack_conv_w(int dtype, const float* W, void* Wf, void* Wd, void* stream);
+int audiossl_unpack_conv_dw(const float* dWp, float* dW, void* stream);
+
+/* ---- K9-K12 GEMM: every nn.Linear / matmul / einsum of the path ------------------------------------------
+ * (audiontt.py:62-68; delores_s/upstream_expert.py:15-22, 36; delores_m/upstream_expert.py:250-252)
+ * C[M,N] (+)= alpha * op(A) * op(B), operands of `dtype`, fp32 accumulate.
+ *   trans_a = 0: A is [M][K] (lda)   trans_a = 1: A is [K][M] (lda)
+ *   trans_b = 0: B is [N][K] (ldb)   trans_b = 1: B is [K][N] (ldb)     (torch Linear weights are [N][K])
+ * Epilogue, in order: + bias[N]; ReLU; * keep[M][ldk] * keep_scale (dropout); zero where gate[M][ldg] <= 0;
+ * store as dtype, or fp32 (out_f32), or fp32 atomicAdd (atomic; required when ksplit > 1). */
+int audiossl_gemm(int dtype, int trans_a, int trans_b, int M, int N, int K, float alpha, const void* A, long lda,
+                  const void* B, long ldb, void* C, long ldc, const float* bias, int relu, const uint8_t* keep, long ldk,
+                  float keep_scale, const void* gate, long ldg, int out_f32, int atomic, int ksplit, void* stream);
+
+/* ---- encoder tail: delores_s/upstream_encoder.py:26-28 ---------------------------------------------------- */
+int audiossl_maxmean_fwd(int dtype, const void* H, void* y, uint8_t* arg, int N, int Tt, int D, void* stream);
+int audiossl_maxmean_bwd(int dtype, const void* dy, const uint8_t* arg, const void* H, void* dA, int N, int Tt, int D,
+                         void* stream);
+
+/* ---- K10/K11 Barlow head: delores_s/upstream_expert.py:11-46, src/utils/utils.py:185-189 ------------------
+ * colbn_fwd: h = act(scale*a+shift).  colbn_bwd: BatchNorm1d(train) backward (tmp = 2*C doubles scratch).
+ * barlow_loss: loss += coef * sum (c - I)^2 ; dc = dscale * (c - I). */
+int audiossl_colbn_fwd(int dtype, const void* a, const float* scale, const float* shift, int relu, void* h, long M, int C,
+                       void* stream);
+int audiossl_colbn_bwd(int dtype, const void* a, const void* dh, const float* scale, const float* shift, const float* mean,
+                       const float* rstd, int relu, long M, int C, double* tmp, void* da, float* dgamma, float* dbeta,
+                       void* stream);
+int audiossl_add_d2f(const double* src, float* dst, int n, void* stream);
+int audiossl_barlow_loss(int dtype, const float* c, int D, float coef, float dscale, void* dc, float* loss_out,
+                         void* stream);
+
+/* ---- K12/K13 MoCo head: delores_m/upstream_expert.py:147-172, 231-264, 270 -------------------------------- */
+int audiossl_l2norm_fwd(int dtype, const float* q, int B, int D, void* qn, float* qn32, float* inv_norm, void* stream);
+int audiossl_rowdot(const float* a, const float* b, int B, int D, float scale, float* out, void* stream);
+int audiossl_moco_ce_fwd(const float* lpos, const float* lneg, int B, int K, float* lse, float* loss_out, void* stream);
+int audiossl_moco_ce_bwd(int dtype, const float* lpos, const float* lneg, const float* lse, int B, int K, float gscale,
+                         void* P, float* dlpos, void* stream);
+int audiossl_l2norm_bwd(int dtype, const float* dqn, const float* dlpos, const float* kn32, const float* qn32,
+                        const float* inv_norm, int B, int D, void* dq, void* stream);
+int audiossl_enqueue(int dtype, const float* keys, int B, int D, int K, int ptr, float* queue, void* shadow, void* stream);
+int audiossl_ema_update(float* pk, const float* pq, long n, float m, void* stream);
+
+/* ---- K17 optimiser + plumbing: delores_s/upstream_expert.py:236-243 (torch.optim.SGD) ---------------------- */
+int audiossl_sgd_momentum(float* p, const float* g, float* buf, long n, float lr, float momentum, float weight_decay,
+                          int first, float grad_scale, void* stream);
+int audiossl_cast(int dtype, const float* src, void* dst, long n, void* stream);
+int audiossl_cast_back(int dtype, const void* src, float* dst, long n, void* stream);
+int audiossl_dropout_mask(uint8_t* keep, long n, unsigned long long seed, float p, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* AUDIOSSL_HIP_H */

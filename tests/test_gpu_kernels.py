@@ -1,0 +1,239 @@
+"""GPU: every HIP kernel through the C ABI against the CPU oracle (torch fp32 / numpy) on seeded inputs.
+
+Tolerances: fp32 path (exact-f32 MFMA) 1e-4 relative; bf16 path 2e-2 rel-L2 (bf16 has 8 significand bits);
+index / mask outputs bit-exact."""
+import random
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import augment as OA
+from oracle import fill
+from oracle import frontend as FE
+from helpers import rel_l2
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def N():
+    from src import _native
+    _native.lib()
+    assert torch.cuda.is_available()
+    return _native
+
+
+def dev(x):
+    return torch.as_tensor(x).cuda().contiguous()
+
+
+TOL = {0: 1e-4, 1: 2e-2}
+
+
+# ------------------------------------------------------------------------------------------------ GEMM
+@pytest.mark.parametrize("dtype", [0, 1])
+@pytest.mark.parametrize("mode", ["NT", "NN", "TN"])
+@pytest.mark.parametrize("shape", [(8, 2048, 512), (200, 136, 72), (512, 128, 2048), (1000, 264, 40), (64, 576, 1600)])
+def test_gemm_modes(N, dtype, mode, shape):
+    M, Nn, K = shape
+    ta, tb = {"NT": (0, 0), "NN": (0, 1), "TN": (1, 1)}[mode]
+    if (ta and M % 8) or (tb and Nn % 8) or ((not ta or not tb) and K % 8):
+        pytest.skip("vector dimension must be a multiple of 8")
+    td = N.torch_dtype(dtype)
+    A = torch.from_numpy(fill.uniform((K, M) if ta else (M, K), 11 + M))
+    B = torch.from_numpy(fill.uniform((K, Nn) if tb else (Nn, K), 12 + Nn))
+    Ad, Bd = dev(A).to(td), dev(B).to(td)
+    Aq, Bq = Ad.float().cpu(), Bd.float().cpu()               # operands as the kernel sees them
+    ref = (Aq.T if ta else Aq).double() @ (Bq if tb else Bq.T).double()
+    C = torch.full((M, Nn), float("nan"), device="cuda", dtype=torch.float32)
+    N.call("gemm", dtype, ta, tb, M, Nn, K, 1.0, Ad, Ad.shape[1], Bd, Bd.shape[1], C, Nn, None, 0, None, 0, 1.0,
+           None, 0, 1, 0, 1)
+    torch.cuda.synchronize()
+    assert torch.isfinite(C).all()
+    assert rel_l2(C.cpu(), ref) < 1e-5                         # fp32 accumulate of exactly-represented operands
+    # split-K + atomic accumulation on top of a non-zero C
+    C2 = torch.ones(M, Nn, device="cuda", dtype=torch.float32)
+    N.call("gemm", dtype, ta, tb, M, Nn, K, 0.5, Ad, Ad.shape[1], Bd, Bd.shape[1], C2, Nn, None, 0, None, 0, 1.0,
+           None, 0, 1, 1, 3)
+    torch.cuda.synchronize()
+    assert rel_l2(C2.cpu(), 1.0 + 0.5 * ref) < 1e-5
+
+
+@pytest.mark.parametrize("dtype", [0, 1])
+def test_gemm_epilogue(N, dtype):
+    M, Nn, K = 72, 200, 64
+    td = N.torch_dtype(dtype)
+    A = dev(fill.uniform((M, K), 21)).to(td)
+    W = dev(fill.uniform((Nn, K), 22)).to(td)
+    bias = dev(fill.uniform((Nn,), 23))
+    keep = dev((fill.uniform01((M, Nn), 24) >= 0.3).astype(np.uint8))
+    gate = dev(fill.uniform((M, Nn), 25)).to(td)
+    out = torch.empty(M, Nn, device="cuda", dtype=td)
+    N.call("gemm", dtype, 0, 0, M, Nn, K, 1.0, A, K, W, K, out, Nn, bias, 1, keep, Nn, 1.0 / 0.7, gate, Nn, 0, 0, 1)
+    torch.cuda.synchronize()
+    ref = torch.relu(A.float() @ W.float().T + bias) * keep.float() / 0.7 * (gate.float() > 0)
+    assert rel_l2(out.float().cpu(), ref.cpu()) < (1e-5 if dtype == 0 else 4e-3)
+
+
+def test_gemm_rejects_bad_arguments(N):
+    a = torch.zeros(16, 16, device="cuda")
+    with pytest.raises(RuntimeError, match="EINVAL"):
+        N.call("gemm", 0, 0, 0, 16, 16, 12, 1.0, a, 16, a, 16, a, 16, None, 0, None, 0, 1.0, None, 0, 1, 0, 1)   # K % 8
+    with pytest.raises(RuntimeError, match="EALIGN"):
+        N.call("gemm", 0, 0, 0, 16, 16, 8, 1.0, a, 12, a, 16, a, 16, None, 0, None, 0, 1.0, None, 0, 1, 0, 1)    # lda % 8
+    with pytest.raises(RuntimeError, match="device tensors"):
+        N.call("gemm", 0, 0, 0, 16, 16, 16, 1.0, a.cpu(), 16, a, 16, a, 16, None, 0, None, 0, 1.0, None, 0, 1, 0, 1)
+
+
+# ------------------------------------------------------------------------------------------------ log-mel
+def _waves(B, L, salt):
+    w = fill.uniform((B, L), salt, -0.1, 0.1)
+    t = np.arange(L) / 16000.0
+    w += (0.3 * np.sin(2 * np.pi * 440 * t) + 0.2 * np.sin(2 * np.pi * 3000 * t)).astype(np.float32)
+    return w
+
+
+@pytest.mark.parametrize("L", [16000, 15200])
+def test_logmel_matches_oracle(N, L):
+    from src.utils import MelSpectrogramLibrosa, extract_log_mel_spectrogram
+    w = _waves(6, L, 31)
+    w[4] = 0.0                 # silence
+    w[5] = 1.0                 # full-scale DC
+    mel = MelSpectrogramLibrosa()
+    got = extract_log_mel_spectrogram(torch.from_numpy(w).cuda(), mel)
+    ref = FE.log_mel_batch(torch.from_numpy(w))
+    assert got.shape == ref.shape == (6, 64, 1 + L // 160)
+    e_got, e_ref = torch.exp(got.cpu().double()), torch.exp(ref.double())
+    # SURVEY 8d tolerance: |d exp(logmel)| <= 1e-5*max + 1e-7, per clip
+    for b in range(6):
+        tol = 1e-5 * float(e_ref[b].max()) + 1e-7
+        assert float((e_got[b] - e_ref[b]).abs().max()) <= tol, b
+    # silence floor is exact: log(eps)
+    assert torch.allclose(got[4].cpu(), ref[4], atol=1e-5)
+    # per-clip API keeps the reference's contract (mel power, [n_mels, T])
+    p = mel(torch.from_numpy(w[0]))
+    assert p.shape == (64, 1 + L // 160) and not p.is_cuda
+    assert rel_l2(p, FE.MelSpectrogram()(w[0])) < 1e-5
+
+
+def test_logmel_tables_match_oracle():
+    from src.utils.utils import slaney_mel_filterbank, pack_filterbank
+    fb = slaney_mel_filterbank(16000, 1024, 64, 60, 7800)
+    assert np.array_equal(fb, FE.mel_filterbank())
+    st, pk = pack_filterbank(fb)
+    assert pk.shape[1] == 45 and int((pk != 0).sum()) == 966
+
+
+# ------------------------------------------------------------------------------------------------ augmentation
+@pytest.mark.parametrize("T", [101, 96])
+def test_aug_two_views_match_reference_goldens(N, golden, cfg_s, T):
+    """Batched GPU path vs (a) the reference's own outputs (golden) and (b) the sequential oracle."""
+    from src.augmentations import AugmentationModule
+    g = golden(f"aug_T{T}")
+    np.random.seed(31)
+    random.seed(31)
+    tf = AugmentationModule(cfg_s, 100, max_batch=8)
+    xs = torch.stack([torch.from_numpy(fill.normalish((1, 64, T), 1000 + c) * 3.0 - 8.0) for c in range(20)])
+    v1s, v2s, ijhw = [], [], []
+    for lo, hi in ((0, 1), (1, 8), (8, 13), (13, 20)):          # ragged batch sizes, state carried across
+        a, b = tf.augment_batch(xs[lo:hi].cuda())
+        v1s.append(a.cpu())
+        v2s.append(b.cpu())
+        ijhw.append(tf.last_plan[0][:, :, 2:6].reshape(-1, 4))
+    v1, v2 = torch.cat(v1s)[:, 0].numpy(), torch.cat(v2s)[:, 0].numpy()
+    assert np.array_equal(np.concatenate(ijhw), g["ijhw"])                      # bit-exact crop indices
+    assert np.random.random() == float(g["np_state_after"]) and random.random() == float(g["py_state_after"])
+    for k, c in enumerate(g["keep"]):
+        np.testing.assert_allclose(v1[c], g["v1"][k], rtol=0, atol=2e-5)
+        np.testing.assert_allclose(v2[c], g["v2"][k], rtol=0, atol=2e-5)
+    dig = np.array([[v.sum(dtype=np.float64), np.abs(v).sum(dtype=np.float64)] for v in list(v1) + list(v2)])
+    np.testing.assert_allclose(dig, g["digest"], rtol=2e-5, atol=2e-2)
+
+
+def test_aug_fifo_wraparound_vs_oracle(N, cfg_s):
+    """More clips than the 2048-entry FIFO holds: partner resolution across the ring wrap, small images."""
+    from src.augmentations import AugmentationModule
+    F_, T_ = 8, 12
+    n_clips = 1100
+    xs = torch.from_numpy(fill.normalish((n_clips, 1, F_, T_), 77) * 2.0 - 3.0)
+    np.random.seed(7); random.seed(7)
+    ref = OA.AugmentationModule(cfg_s, 1000)
+    r1, r2 = zip(*[ref(xs[c]) for c in range(n_clips)])
+    np.random.seed(7); random.seed(7)
+    tf = AugmentationModule(cfg_s, 1000, max_batch=64)
+    o1, o2 = [], []
+    for lo in range(0, n_clips, 50):
+        a, b = tf.augment_batch(xs[lo:lo + 50].cuda())
+        o1.append(a.cpu()); o2.append(b.cpu())
+    o1, o2 = torch.cat(o1), torch.cat(o2)
+    np.testing.assert_allclose(o1[:, 0].numpy(), torch.cat(r1).numpy(), rtol=0, atol=5e-5)
+    np.testing.assert_allclose(o2[:, 0].numpy(), torch.cat(r2).numpy(), rtol=0, atol=5e-5)
+
+
+def test_specaugment_masks_bit_exact(N, golden, cfg_s):
+    import copy
+    from src.augmentations import AugmentationModule
+    g = golden("specaug")
+    for zero in (False, True):
+        cfg = copy.deepcopy(cfg_s)
+        cfg["pretrain"]["augmentations"] = {"SpecAugment": dict(F=30, T=40, num_freq_masks=2, num_time_masks=2,
+                                                                replace_with_zero=zero)}
+        cfg["pretrain"]["normalization"] = "l2"
+        for seed in range(8):
+            x = torch.from_numpy(fill.normalish((101, 64), 3000 + seed))          # (T, dim) as the reference takes it
+            random.seed(1234 + seed)
+            tf = AugmentationModule(cfg, 10, max_batch=4)
+            v1, _ = tf.augment_batch(x.T.contiguous()[None].cuda())              # module layout is [F, T]
+            want = g["outs"][2 * seed + (1 if zero else 0)]
+            got = v1[0, 0].cpu().numpy().T
+            if zero:
+                assert np.array_equal(got, want)
+            else:
+                np.testing.assert_allclose(got, want, rtol=0, atol=1e-6)
+
+
+# ------------------------------------------------------------------------------------------------ stem (conv1)
+@pytest.mark.parametrize("dtype", [0, 1])
+@pytest.mark.parametrize("T", [101, 96])
+def test_conv1_block_fwd_bwd(N, dtype, T):
+    import torch.nn as nn
+    Nimg, F_ = 3, 64
+    td = N.torch_dtype(dtype)
+    blk = nn.Sequential(nn.Conv2d(1, 64, 3, padding=1), nn.BatchNorm2d(64), nn.ReLU(), nn.MaxPool2d(2, 2))
+    fill.fill_state_dict_(blk, seed=5)
+    blk.train()
+    x = torch.from_numpy(fill.normalish((Nimg, 1, F_, T), 41))
+    ref = blk(x)                                                     # [N, 64, F/2, T/2]
+    gP = torch.from_numpy(fill.uniform(tuple(ref.shape), 42))
+    gX1 = torch.from_numpy(fill.uniform((Nimg, 32 * 64), 43))         # grad of the temporal mean x_1
+    x1 = ref.permute(0, 3, 2, 1).reshape(Nimg, T // 2, -1).mean(1)
+    ((ref * gP).sum() + (x1 * gX1).sum()).backward()
+
+    conv, bn = blk[0], blk[1]
+    w = dev(conv.weight.detach().reshape(64, 9)); b = dev(conv.bias.detach())
+    gamma, beta = dev(bn.weight.detach()), dev(bn.bias.detach())
+    rm, rv = torch.zeros(64, device="cuda"), torch.ones(64, device="cuda")
+    mom = torch.empty(54, dtype=torch.float64, device="cuda")
+    scale, shift, mean, rstd = (torch.empty(64, device="cuda") for _ in range(4))
+    img = dev(x[:, 0])
+    N.call("conv1_stats", img, Nimg, F_, T, w, b, gamma, beta, rm, rv, 0.1, 1e-5, mom, scale, shift, mean, rstd)
+    P = torch.empty(Nimg, T // 2, F_ // 2, 64, device="cuda", dtype=td)
+    N.call("conv1_fwd", dtype, img, Nimg, F_, T, w, b, scale, shift, P)
+    torch.cuda.synchronize()
+    ref_cl = ref.detach().permute(0, 3, 2, 1)                       # [N, T/2, F/2, 64]
+    assert rel_l2(P.float().cpu(), ref_cl) < (1e-5 if dtype == 0 else 4e-3)
+    np.testing.assert_allclose(rm.cpu().numpy(), bn.running_mean.numpy(), rtol=1e-4, atol=1e-6)
+    np.testing.assert_allclose(rv.cpu().numpy(), bn.running_var.numpy(), rtol=1e-4, atol=1e-6)
+
+    dP = dev(gP.permute(0, 3, 2, 1)).to(td)
+    dxl = dev(gX1).to(td)
+    acc = torch.empty(64 * 11, device="cuda")
+    dW, db, dg, dbt = (torch.zeros(s, device="cuda") for s in ((64, 9), (64,), (64,), (64,)))
+    N.call("conv1_bwd", dtype, img, Nimg, F_, T, w, b, gamma, scale, shift, mean, rstd, mom, dP, dxl, acc, dW, db, dg, dbt)
+    torch.cuda.synchronize()
+    tol = 2e-4 if dtype == 0 else 1e-2
+    assert rel_l2(dW.cpu(), conv.weight.grad.reshape(64, 9)) < tol
+    assert rel_l2(dg.cpu(), bn.weight.grad) < tol
+    assert rel_l2(dbt.cpu(), bn.bias.grad) < tol
+    assert float(conv.bias.grad.abs().max()) < 1e-3 and float(db.abs().max()) == 0.0
