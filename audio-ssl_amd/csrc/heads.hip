@@ -268,7 +268,9 @@ __global__ __launch_bounds__(256) void enqueue_kernel(const float* __restrict__ 
 // --------------------------------------------------------------------------------------------- flat-buffer plumbing
 // torch.optim.SGD: g += wd*p; buf = first ? g : mom*buf + g; p -= lr*buf
 __global__ __launch_bounds__(256) void sgd_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ buf,
-                                                  long n, float lr, float mom, float wd, int first, float gscale) {
+                                                  long n, float lr, float mom, float wd, int first, float gscale_host,
+                                                  const float* __restrict__ gscale_dev) {
+    const float gscale = gscale_dev ? gscale_host * gscale_dev[0] : gscale_host;
     for (long i = ((long)blockIdx.x * 256 + threadIdx.x) * 4; i < n; i += (long)gridDim.x * 1024) {
         if (i + 4 <= n) {
             f32x4 pv = *reinterpret_cast<f32x4*>(p + i);
@@ -434,11 +436,11 @@ extern "C" int audiossl_enqueue(int dtype, const float* keys, int B, int D, int 
 }
 
 extern "C" int audiossl_sgd_momentum(float* p, const float* g, float* buf, long n, float lr, float momentum, float weight_decay,
-                                     int first, float grad_scale, void* stream) {
+                                     int first, float grad_scale, const float* grad_scale_dev, void* stream) {
     ASSL_REQUIRE(p && g && buf && n > 0);
     if (!ASSL_ALIGNED16(p) || !ASSL_ALIGNED16(g) || !ASSL_ALIGNED16(buf)) return ASSL_EALIGN;
     const int grid = (int)min((long)2048, (n + 1023) / 1024);
-    hipLaunchKernelGGL(sgd_kernel, dim3(grid), dim3(256), 0, S_(stream), p, g, buf, n, lr, momentum, weight_decay, first, grad_scale);
+    hipLaunchKernelGGL(sgd_kernel, dim3(grid), dim3(256), 0, S_(stream), p, g, buf, n, lr, momentum, weight_decay, first, grad_scale, grad_scale_dev);
     ASSL_LAUNCH_CHECK();
 }
 
@@ -469,5 +471,54 @@ extern "C" int audiossl_dropout_mask(uint8_t* keep, long n, unsigned long long s
     ASSL_REQUIRE(keep && n > 0 && p >= 0.f && p < 1.f);
     const int grid = (int)min((long)4096, (n + 255) / 256);
     hipLaunchKernelGGL(dropout_mask_kernel, dim3(grid), dim3(256), 0, S_(stream), keep, n, seed, p);
+    ASSL_LAUNCH_CHECK();
+}
+
+// ---- small extras -----------------------------------------------------------------------------------------------
+namespace {
+template <typename T_>
+__global__ __launch_bounds__(256) void relu_bwd_kernel(const T_* __restrict__ g, const T_* __restrict__ h, T_* __restrict__ out, long n8) {
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= n8) return;
+    const Vec8<T_> vg = Vec8<T_>::load(g + idx * 8), vh = Vec8<T_>::load(h + idx * 8);
+    Vec8<T_> o;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) o.set(i, vh.get(i) > 0.f ? vg.get(i) : 0.f);
+    o.store(out + idx * 8);
+}
+// eval-mode BatchNorm as an affine map: scale = gamma / sqrt(running_var + eps), shift = beta - running_mean * scale
+__global__ void bn_eval_affine_kernel(const float* gamma, const float* beta, const float* rm, const float* rv, float eps, int C,
+                                      float* scale, float* shift) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
+    const float s = g / sqrtf(rv[c] + eps);
+    scale[c] = s;
+    shift[c] = b - rm[c] * s;
+}
+__global__ void axpy_kernel(float* __restrict__ y, const float* __restrict__ x, float a, long n) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) y[i] += a * x[i];
+}
+}  // namespace
+
+extern "C" int audiossl_relu_bwd(int dtype, const void* g, const void* h, void* out, long n, void* stream) {
+    ASSL_REQUIRE(g && h && out && n > 0 && (n % 8) == 0 && (dtype == 0 || dtype == 1));
+    if (dtype == 0) hipLaunchKernelGGL(relu_bwd_kernel<float>, GRID1(n / 8), dim3(256), 0, S_(stream), (const float*)g, (const float*)h, (float*)out, n / 8);
+    else            hipLaunchKernelGGL(relu_bwd_kernel<bf16>, GRID1(n / 8), dim3(256), 0, S_(stream), (const bf16*)g, (const bf16*)h, (bf16*)out, n / 8);
+    ASSL_LAUNCH_CHECK();
+}
+
+extern "C" int audiossl_bn_eval_affine(const float* gamma, const float* beta, const float* running_mean, const float* running_var,
+                                       float eps, int C, float* scale, float* shift, void* stream) {
+    ASSL_REQUIRE(running_mean && running_var && scale && shift && C > 0);
+    hipLaunchKernelGGL(bn_eval_affine_kernel, dim3(ceil_div(C, 256)), dim3(256), 0, S_(stream), gamma, beta, running_mean,
+                       running_var, eps, C, scale, shift);
+    ASSL_LAUNCH_CHECK();
+}
+
+extern "C" int audiossl_axpy(float* y, const float* x, float a, long n, void* stream) {
+    ASSL_REQUIRE(y && x && n > 0);
+    const int grid = (int)min((long)2048, (n + 255) / 256);
+    hipLaunchKernelGGL(axpy_kernel, dim3(grid), dim3(256), 0, S_(stream), y, x, a, n);
     ASSL_LAUNCH_CHECK();
 }

@@ -1,0 +1,366 @@
+"""Launch sequences of the upstream step on one GPU (host orchestration of libaudiossl_hip.so).
+
+Explicit forward / backward of
+  * AudioNTT2020Task6            (`src/encoder/audiontt.py:72-104`)
+  * max_T + mean_T pooling       (`src/upstream/delores_s/upstream_encoder.py:26-28`)
+  * the Barlow projector + loss  (`src/upstream/delores_s/upstream_expert.py:11-46`)
+  * the MoCo InfoNCE head        (`src/upstream/delores_m/upstream_expert.py:231-264, 270`)
+as sequences of C-ABI calls.  torch is used for device buffers and streams only; no ATen arithmetic sits on
+the path.  Gradients are ACCUMULATED into the tensors handed in (flat-buffer views in training).
+
+Activation layout [N][T][F][64] (time, mel, channel); `dtype` 0 = fp32 storage / exact-f32 MFMA,
+1 = bf16 storage / bf16 MFMA with fp32 accumulate (parameters, statistics, losses stay fp32).
+"""
+import torch
+
+from src import _native as N
+
+BN_MOMENTUM = 0.1
+BN_EPS = 1e-5
+
+
+def _empty(shape, dtype, like=None, device=None):
+    return torch.empty(shape, dtype=dtype, device=device if device is not None else like.device)
+
+
+def _ksplit(M, Nn, K, target=512):
+    tiles = ((M + 127) // 128) * ((Nn + 127) // 128)
+    ks = max(1, min(target // max(tiles, 1), (K + 127) // 128))
+    return int(ks)
+
+
+def gemm(dtype, ta, tb, M, Nn, K, A, lda, B, ldb, C, ldc, alpha=1.0, bias=None, relu=0, keep=None, ldk=0, keep_scale=1.0,
+         gate=None, ldg=0, out_f32=0, atomic=0, ksplit=1):
+    N.call("gemm", dtype, ta, tb, M, Nn, K, float(alpha), A, lda, B, ldb, C, ldc, bias, relu, keep, ldk, float(keep_scale),
+           gate, ldg, out_f32, atomic, ksplit)
+
+
+def linear_fwd(dtype, X, W, M, Nout, K, bias=None, relu=0, keep=None, keep_scale=1.0, out=None, out_f32=0):
+    """X [M,K] @ W[Nout,K]^T (+bias) -> [M,Nout]"""
+    if out is None:
+        out = _empty((M, Nout), torch.float32 if (out_f32 or dtype == 0) else torch.bfloat16, like=X)
+    gemm(dtype, 0, 0, M, Nout, K, X, K, W, K, out, Nout, bias=bias, relu=relu, keep=keep, ldk=Nout, keep_scale=keep_scale,
+         out_f32=out_f32)
+    return out
+
+
+def linear_bwd_w(dtype, dY, X, dW, M, Nout, K):
+    """dW[Nout,K] += dY[M,Nout]^T @ X[M,K]   (split-K, fp32 atomics)"""
+    gemm(dtype, 1, 1, Nout, K, M, dY, Nout, X, K, dW, K, out_f32=1, atomic=1, ksplit=_ksplit(Nout, K, M))
+
+
+def linear_bwd_x(dtype, dY, W, M, Nout, K, alpha=1.0, gate=None, out=None):
+    """dX[M,K] = alpha * dY[M,Nout] @ W[Nout,K]   (optionally zeroed where gate <= 0)"""
+    if out is None:
+        out = _empty((M, K), N.torch_dtype(dtype), like=dY)
+    gemm(dtype, 0, 1, M, K, Nout, dY, Nout, W, K, out, K, alpha=alpha, gate=gate, ldg=K)
+    return out
+
+
+def colsum_add(dtype, X, M, C, dst, tmp=None):
+    """dst[C] += column sums of X [M,C]"""
+    tmp = tmp if tmp is not None else _empty((C,), torch.float64, like=X)
+    N.call("colstats", dtype, X, M, C, C, 0, tmp, None)
+    N.call("add_d2f", tmp, dst, C)
+
+
+def cast(dtype, src, n=None):
+    """fp32 parameter -> tensor of the activation dtype (identity for fp32)."""
+    if dtype == N.F32:
+        return src
+    out = torch.empty(src.shape, dtype=torch.bfloat16, device=src.device)
+    N.call("cast", dtype, src, out, src.numel())
+    return out
+
+
+# =============================================================================================== encoder
+class EncoderCtx:
+    """Everything the backward needs from one forward call."""
+    pass
+
+
+def _bn_train(dtype, Y, M, C, gamma, beta, rm, rv, update_running):
+    s = _empty((C,), torch.float64, like=Y)
+    q = _empty((C,), torch.float64, like=Y)
+    N.call("colstats", dtype, Y, M, C, C, 1, s, q)
+    scale, shift, mean, rstd = (_empty((C,), torch.float32, like=Y) for _ in range(4))
+    N.call("bn_finalize", s, q, float(M), C, gamma, beta, rm if update_running else None, rv if update_running else None,
+           BN_MOMENTUM, BN_EPS, scale, shift, mean, rstd)
+    return scale, shift, mean, rstd
+
+
+def _bn_eval(like, C, gamma, beta, rm, rv):
+    scale, shift = _empty((C,), torch.float32, like=like), _empty((C,), torch.float32, like=like)
+    N.call("bn_eval_affine", gamma, beta, rm, rv, BN_EPS, C, scale, shift)
+    return scale, shift
+
+
+def _conv_block_fwd(dtype, Pin, Nimg, Ti, Fi, W, bias, bn, train, update_running, col):
+    """3x3 conv (im2col + MFMA GEMM) -> BN -> ReLU -> pool.  Returns (Y, Pout, stats, Wf, Wd)."""
+    td = N.torch_dtype(dtype)
+    Wf, Wd = _empty((64, 576), td, like=Pin), _empty((64, 576), td, like=Pin)
+    N.call("pack_conv_w", dtype, W, Wf, Wd)
+    M = Nimg * Ti * Fi
+    N.call("im2col3x3", dtype, Pin, col, Nimg, Ti, Fi)
+    Y = _empty((M, 64), td, like=Pin)
+    gemm(dtype, 0, 0, M, 64, 576, col, 576, Wf, 576, Y, 64, bias=bias)
+    gamma, beta, rm, rv = bn
+    if train:
+        scale, shift, mean, rstd = _bn_train(dtype, Y, M, 64, gamma, beta, rm, rv, update_running)
+    else:
+        scale, shift = _bn_eval(Y, 64, gamma, beta, rm, rv)
+        mean = rstd = None
+    Pout = _empty((Nimg, Ti // 2, Fi // 2, 64), td, like=Pin)
+    N.call("bn_relu_pool_fwd", dtype, Y, scale, shift, Pout, Nimg, Ti, Fi)
+    return Y, Pout, (scale, shift, mean, rstd), Wf, Wd
+
+
+def _col_buffer(dtype, Nimg, T1, F1, like):
+    return _empty((Nimg * T1 * F1, 576), N.torch_dtype(dtype), like=like)
+
+
+def encoder_forward(P, x, dtype, keep=None, p_drop=0.3, train=True, update_running=True, want_layers=True):
+    """P: dict of fp32 device tensors with the reference's state_dict keys (features_1.0.weight, ...).
+    x [N,1,F,T] fp32.  keep: uint8 [N*T3, d] dropout keep-mask or None (no dropout).
+    Returns (x1, x2, x3, H2 [N,T3,d]) in the activation dtype and the ctx for the backward."""
+    Nimg, _, F, T = x.shape
+    assert F == 64, "the HIP encoder is built for n_mels = 64 (the reference's only setting)"
+    td = N.torch_dtype(dtype)
+    c = EncoderCtx()
+    c.P = P
+    c.dtype, c.N, c.F, c.T, c.train, c.p_drop = dtype, Nimg, F, T, train, p_drop
+    img = x.reshape(Nimg, F, T).contiguous()
+    c.img = img
+    w1 = P["features_1.0.weight"].reshape(64, 9)
+    b1 = P["features_1.0.bias"]
+    g1, be1 = P["features_1.1.weight"], P["features_1.1.bias"]
+    if train:
+        c.mom1 = _empty((54,), torch.float64, like=x)
+        c.sc1, c.sh1, c.mean1, c.rstd1 = (_empty((64,), torch.float32, like=x) for _ in range(4))
+        N.call("conv1_stats", img, Nimg, F, T, w1, b1, g1, be1, P["features_1.1.running_mean"] if update_running else None,
+               P["features_1.1.running_var"] if update_running else None, BN_MOMENTUM, BN_EPS, c.mom1, c.sc1, c.sh1, c.mean1,
+               c.rstd1)
+    else:
+        c.sc1, c.sh1 = _bn_eval(x, 64, g1, be1, P["features_1.1.running_mean"], P["features_1.1.running_var"])
+    T1, F1 = T // 2, F // 2
+    c.P1 = _empty((Nimg, T1, F1, 64), td, like=x)
+    N.call("conv1_fwd", dtype, img, Nimg, F, T, w1, b1, c.sc1, c.sh1, c.P1)
+    col = _col_buffer(dtype, Nimg, T1, F1, x)
+    bn2 = (P["features_2.1.weight"], P["features_2.1.bias"], P["features_2.1.running_mean"], P["features_2.1.running_var"])
+    c.Y2, c.P2, c.st2, c.W2f, c.W2d = _conv_block_fwd(dtype, c.P1, Nimg, T1, F1, P["features_2.0.weight"],
+                                                       P["features_2.0.bias"], bn2, train, update_running, col)
+    T2, F2 = T1 // 2, F1 // 2
+    bn3 = (P["features_3.1.weight"], P["features_3.1.bias"], P["features_3.1.running_mean"], P["features_3.1.running_var"])
+    c.Y3, c.P3, c.st3, c.W3f, c.W3d = _conv_block_fwd(dtype, c.P2, Nimg, T2, F2, P["features_3.0.weight"],
+                                                       P["features_3.0.bias"], bn3, train, update_running, col)
+    del col
+    T3, F3 = T2 // 2, F2 // 2
+    c.dims = (T1, F1, T2, F2, T3, F3)
+    x1 = x2 = x3 = None
+    if want_layers:
+        x1, x2, x3 = (_empty((Nimg, f * 64), td, like=x) for f in (F1, F2, F3))
+        N.call("tmean_fwd", dtype, c.P1, x1, Nimg, T1, F1)
+        N.call("tmean_fwd", dtype, c.P2, x2, Nimg, T2, F2)
+        N.call("tmean_fwd", dtype, c.P3, x3, Nimg, T3, F3)
+    d = P["fc.0.weight"].shape[0]
+    kin = F3 * 64
+    M = Nimg * T3
+    c.d, c.kin, c.M = d, kin, M
+    c.fw1, c.fw2 = cast(dtype, P["fc.0.weight"]), cast(dtype, P["fc.3.weight"])
+    c.keep = keep if train else None
+    scale = 1.0 / (1.0 - p_drop) if c.keep is not None else 1.0
+    c.H1 = linear_fwd(dtype, c.P3, c.fw1, M, d, kin, bias=P["fc.0.bias"], relu=1, keep=c.keep, keep_scale=scale)
+    c.H2 = linear_fwd(dtype, c.H1, c.fw2, M, d, d, bias=P["fc.3.bias"], relu=1)
+    return x1, x2, x3, c.H2.view(Nimg, T3, d), c
+
+
+def _conv_block_bwd(dtype, Y, dP, dxl, st, Nimg, Ti, Fi, Pin, Wd, G_w, G_gamma, G_beta, need_dx, col):
+    """BN/ReLU/pool backward + conv wgrad (+ dgrad).  Returns dPin or None."""
+    td = N.torch_dtype(dtype)
+    scale, shift, mean, rstd = st
+    M = Nimg * Ti * Fi
+    dY = _empty((M, 64), td, like=Y)
+    stat = _empty((128,), torch.float32, like=Y)
+    N.call("bn_relu_pool_bwd", dtype, Y, dP, dxl, scale, shift, mean, rstd, stat, dY, G_gamma, G_beta, Nimg, Ti, Fi)
+    # wgrad: dWp[co][tap*64+ci] = sum_pix dY[pix][co] * col(Pin)[pix][tap*64+ci]
+    N.call("im2col3x3", dtype, Pin, col, Nimg, Ti, Fi)
+    dWp = torch.zeros(64, 576, dtype=torch.float32, device=Y.device)
+    gemm(dtype, 1, 1, 64, 576, M, dY, 64, col, 576, dWp, 576, out_f32=1, atomic=1, ksplit=_ksplit(64, 576, M, 1024))
+    N.call("unpack_conv_dw", dWp, G_w)
+    if not need_dx:
+        return None
+    # dgrad: dPin[pix][ci] = sum_{tap,co} dY[pix + off(tap)][co] * W[co][ci][8 - tap]
+    N.call("im2col3x3", dtype, dY, col, Nimg, Ti, Fi)
+    dPin = _empty((Nimg, Ti, Fi, 64), td, like=Y)
+    gemm(dtype, 0, 0, M, 64, 576, col, 576, Wd, 576, dPin, 64)
+    return dPin
+
+
+def encoder_backward(c, G, dA2=None, dH2=None, dx1=None, dx2=None, dx3=None):
+    """Accumulate parameter gradients of one encoder_forward call into G (dict keyed like P, fp32).
+    dA2: grad w.r.t. the pre-ReLU output of fc.3 (already ReLU-gated), or dH2: grad w.r.t. H2.
+    dx1..dx3: grads w.r.t. the temporal layer means (activation dtype) or None."""
+    dtype, Nimg, M, d, kin = c.dtype, c.N, c.M, c.d, c.kin
+    T1, F1, T2, F2, T3, F3 = c.dims
+    td = N.torch_dtype(dtype)
+    assert c.train, "backward needs a train-mode forward (batch statistics)"
+    if dA2 is None:
+        dA2 = _empty((M, d), td, like=c.H2)
+        N.call("relu_bwd", dtype, dH2.contiguous(), c.H2, dA2, M * d)
+    # fc.3
+    linear_bwd_w(dtype, dA2, c.H1, G["fc.3.weight"], M, d, d)
+    colsum_add(dtype, dA2, M, d, G["fc.3.bias"])
+    scale = 1.0 / (1.0 - c.p_drop) if c.keep is not None else 1.0
+    dA1 = linear_bwd_x(dtype, dA2, c.fw2, M, d, d, alpha=scale, gate=c.H1)
+    # fc.0
+    linear_bwd_w(dtype, dA1, c.P3, G["fc.0.weight"], M, d, kin)
+    colsum_add(dtype, dA1, M, d, G["fc.0.bias"])
+    dP3 = linear_bwd_x(dtype, dA1, c.fw1, M, d, kin)
+    del dA1, dA2
+    col = _col_buffer(dtype, Nimg, T1, F1, c.H2)
+    dP2 = _conv_block_bwd(dtype, c.Y3, dP3, dx3, c.st3, Nimg, T2, F2, c.P2, c.W3d, G["features_3.0.weight"],
+                          G["features_3.1.weight"], G["features_3.1.bias"], True, col)
+    dP1 = _conv_block_bwd(dtype, c.Y2, dP2, dx2, c.st2, Nimg, T1, F1, c.P1, c.W2d, G["features_2.0.weight"],
+                          G["features_2.1.weight"], G["features_2.1.bias"], True, col)
+    del col
+    acc = _empty((64 * 11,), torch.float32, like=c.H2)
+    P = c.P
+    N.call("conv1_bwd", dtype, c.img, Nimg, c.F, c.T, P["features_1.0.weight"].reshape(64, 9), P["features_1.0.bias"],
+           P["features_1.1.weight"], c.sc1, c.sh1, c.mean1, c.rstd1, c.mom1, dP1, dx1, acc,
+           G["features_1.0.weight"].view(64, 9), G["features_1.0.bias"], G["features_1.1.weight"], G["features_1.1.bias"])
+
+
+# =============================================================================================== max + mean pooling
+def maxmean_forward(dtype, H2):
+    """H2 [N,T3,d] -> y [N,d] = max_T + mean_T, plus the argmax needed by the backward."""
+    Nimg, T3, d = H2.shape
+    y = _empty((Nimg, d), N.torch_dtype(dtype), like=H2)
+    arg = _empty((Nimg, d), torch.uint8, like=H2)
+    N.call("maxmean_fwd", dtype, H2, y, arg, Nimg, T3, d)
+    return y, arg
+
+
+def maxmean_backward(dtype, dy, arg, H2):
+    """-> dA2 [N*T3, d]: gradient w.r.t. the pre-ReLU fc.3 output (ReLU gate fused)."""
+    Nimg, T3, d = H2.shape
+    dA2 = _empty((Nimg * T3, d), N.torch_dtype(dtype), like=H2)
+    N.call("maxmean_bwd", dtype, dy, arg, H2, dA2, Nimg, T3, d)
+    return dA2
+
+
+# =============================================================================================== Barlow projector
+class ProjCtx:
+    pass
+
+
+def projector_forward(PP, y, dtype, update_running=True, Wc=None):
+    """Lin-BN-ReLU-Lin-BN-ReLU-Lin then affine-free BN.  PP keys: projector.{0,3,6}.weight, projector.{1,4}.{weight,bias,
+    running_mean,running_var}, bn.{running_mean,running_var}.  y [B,in] activation dtype.  Returns zn [B,D], ctx."""
+    B, kin = y.shape
+    c = ProjCtx()
+    c.dtype, c.B, c.kin, c.y = dtype, B, kin, y
+    W = Wc if Wc is not None else tuple(cast(dtype, PP[f"projector.{i}.weight"]) for i in (0, 3, 6))
+    c.W = W
+    D = W[0].shape[0]
+    c.D = D
+
+    def bn(a, prefix, affine):
+        g = PP[prefix + ".weight"] if affine else None
+        b = PP[prefix + ".bias"] if affine else None
+        return _bn_train(dtype, a, B, D, g, b, PP[prefix + ".running_mean"], PP[prefix + ".running_var"], update_running)
+    td = N.torch_dtype(dtype)
+    c.a1 = linear_fwd(dtype, y, W[0], B, D, kin)
+    c.st1 = bn(c.a1, "projector.1", True)
+    c.h1 = _empty((B, D), td, like=y)
+    N.call("colbn_fwd", dtype, c.a1, c.st1[0], c.st1[1], 1, c.h1, B, D)
+    c.a2 = linear_fwd(dtype, c.h1, W[1], B, D, D)
+    c.st2 = bn(c.a2, "projector.4", True)
+    c.h2 = _empty((B, D), td, like=y)
+    N.call("colbn_fwd", dtype, c.a2, c.st2[0], c.st2[1], 1, c.h2, B, D)
+    c.z = linear_fwd(dtype, c.h2, W[2], B, D, D)
+    c.st0 = bn(c.z, "bn", False)
+    c.zn = _empty((B, D), td, like=y)
+    N.call("colbn_fwd", dtype, c.z, c.st0[0], c.st0[1], 0, c.zn, B, D)
+    return c.zn, c
+
+
+def projector_backward(c, PP, G, dzn, need_dy=True):
+    """dzn [B,D] (activation dtype) -> accumulates projector grads into G, returns dy [B,in] (or None)."""
+    dtype, B, D, kin = c.dtype, c.B, c.D, c.kin
+    td = N.torch_dtype(dtype)
+    tmp = _empty((2 * D,), torch.float64, like=dzn)
+    dz = _empty((B, D), td, like=dzn)
+    N.call("colbn_bwd", dtype, c.z, dzn, *c.st0, 0, B, D, tmp, dz, None, None)
+    linear_bwd_w(dtype, dz, c.h2, G["projector.6.weight"], B, D, D)
+    dh2 = linear_bwd_x(dtype, dz, c.W[2], B, D, D)
+    da2 = _empty((B, D), td, like=dzn)
+    N.call("colbn_bwd", dtype, c.a2, dh2, *c.st2, 1, B, D, tmp, da2, G["projector.4.weight"], G["projector.4.bias"])
+    linear_bwd_w(dtype, da2, c.h1, G["projector.3.weight"], B, D, D)
+    dh1 = linear_bwd_x(dtype, da2, c.W[1], B, D, D)
+    da1 = _empty((B, D), td, like=dzn)
+    N.call("colbn_bwd", dtype, c.a1, dh1, *c.st1, 1, B, D, tmp, da1, G["projector.1.weight"], G["projector.1.bias"])
+    linear_bwd_w(dtype, da1, c.y, G["projector.0.weight"], B, D, kin)
+    if not need_dy:
+        return None
+    return linear_bwd_x(dtype, da1, c.W[0], B, D, kin)
+
+
+def barlow_forward_backward(PP, G, y1, y2, dtype, lambd, scale_loss, loss_out, need_dy1=True, need_dy2=True,
+                            update_running=True, all_reduce=None, global_batch=None, backward=True):
+    """Projection.forward + its whole backward.  loss_out: fp32 device scalar, accumulated (+=).
+    all_reduce: optional callable summing the [D,D] fp32 correlation over ranks in place (cross-GPU Barlow,
+    `extras/delores-s/models_byol.py:108-112`); the divisor is then `global_batch`.
+    Returns (dy1, dy2) in the activation dtype (None where not requested)."""
+    B = y1.shape[0]
+    W = tuple(cast(dtype, PP[f"projector.{i}.weight"]) for i in (0, 3, 6))
+    zn1, c1 = projector_forward(PP, y1, dtype, update_running, W)
+    zn2, c2 = projector_forward(PP, y2, dtype, update_running, W)
+    D = c1.D
+    denom = float(global_batch if global_batch else B)
+    cmat = _empty((D, D), torch.float32, like=y1)
+    gemm(dtype, 1, 1, D, D, B, zn1, D, zn2, D, cmat, D, alpha=1.0 / denom, out_f32=1)         # c = zn1^T zn2 / B
+    if all_reduce is not None:
+        all_reduce(cmat)
+    coef = (lambd if lambd else 1.0) * scale_loss
+    dc = _empty((D, D), N.torch_dtype(dtype), like=y1)
+    N.call("barlow_loss", dtype, cmat, D, coef, 2.0 * coef / denom, dc, loss_out)
+    if not backward:
+        return None, None
+    td = N.torch_dtype(dtype)
+    dzn1 = _empty((B, D), td, like=y1)
+    dzn2 = _empty((B, D), td, like=y1)
+    gemm(dtype, 0, 0, B, D, D, zn2, D, dc, D, dzn1, D)      # dzn1[b,i] = sum_j zn2[b,j] dc[i,j]
+    gemm(dtype, 0, 1, B, D, D, zn1, D, dc, D, dzn2, D)      # dzn2[b,j] = sum_i zn1[b,i] dc[i,j]
+    dy1 = projector_backward(c1, PP, G, dzn1, need_dy1)
+    dy2 = projector_backward(c2, PP, G, dzn2, need_dy2)
+    return dy1, dy2
+
+
+# =============================================================================================== MoCo head
+def moco_forward_backward(dtype, q, k, queue, queue_shadow, temperature, loss_out, backward=True):
+    """q, k: fp32 [B,dim] pre-normalisation embeddings (k carries no gradient).  queue fp32 [dim,K]; queue_shadow the
+    same in the activation dtype.  loss_out += CE(logits, 0).  Returns (dq in the activation dtype or None, kn fp32)."""
+    B, dim = q.shape
+    K = queue.shape[1]
+    td = N.torch_dtype(dtype)
+    qn, kn = _empty((B, dim), td, like=q), _empty((B, dim), td, like=q)
+    qn32, kn32 = _empty((B, dim), torch.float32, like=q), _empty((B, dim), torch.float32, like=q)
+    qinv, kinv = _empty((B,), torch.float32, like=q), _empty((B,), torch.float32, like=q)
+    N.call("l2norm_fwd", dtype, q, B, dim, qn, qn32, qinv)
+    N.call("l2norm_fwd", dtype, k, B, dim, kn, kn32, kinv)
+    lpos = _empty((B,), torch.float32, like=q)
+    N.call("rowdot", qn32, kn32, B, dim, 1.0 / temperature, lpos)
+    lneg = _empty((B, K), torch.float32, like=q)
+    gemm(dtype, 0, 1, B, K, dim, qn, dim, queue_shadow, K, lneg, K, alpha=1.0 / temperature, out_f32=1)
+    lse = _empty((B,), torch.float32, like=q)
+    N.call("moco_ce_fwd", lpos, lneg, B, K, lse, loss_out)
+    if not backward:
+        return None, kn32
+    Pm = _empty((B, K), td, like=q)
+    dlpos = _empty((B,), torch.float32, like=q)
+    N.call("moco_ce_bwd", dtype, lpos, lneg, lse, B, K, 1.0 / (B * temperature), Pm, dlpos)
+    dqn = torch.zeros(B, dim, dtype=torch.float32, device=q.device)
+    gemm(dtype, 0, 0, B, dim, K, Pm, K, queue_shadow, K, dqn, dim, out_f32=1, atomic=1, ksplit=_ksplit(B, dim, K, 256))
+    dq = _empty((B, dim), td, like=q)
+    N.call("l2norm_bwd", dtype, dqn, dlpos, kn32, qn32, qinv, B, dim, dq)
+    return dq, kn32

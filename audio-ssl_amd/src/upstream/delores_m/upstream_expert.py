@@ -1,0 +1,172 @@
+"""DeLoRes-M expert on MI355X: MoCo-v2 (query/key encoders, EMA, negatives queue, InfoNCE) plus three Barlow heads on
+the intermediate layer means.
+
+Same class name, constructor, buffers (`queue`, `queue_ptr`) and parameter names as
+`src/upstream/delores_m/upstream_expert.py:51-317` of the reference.  `training_step` is one fused sequence of HIP
+launches: q-encoder fwd, EMA of the key encoder (one launch over the flat parameter buffer), k-encoder fwd,
+InfoNCE against the queue, enqueue, three projector heads, and the complete backward.
+Multi-GPU (torch.distributed over RCCL): batch shuffle / unshuffle for the key encoder's BatchNorm, key all-gather
+before the enqueue (`:156-219`), keyed off the process group instead of the removed `trainer.use_ddp`.
+"""
+import torch
+import torch.nn as nn
+
+from src import _native as N
+from src import engine as E
+from src.encoder.audiontt import default_precision
+from src.flat import FlatGroup
+from src.module_base import UpstreamModule
+from src.upstream.common import FusedExpertMixin, FusedStepFn, Projection
+from src.upstream.delores_m.upstream_encoder import DELORES_M as DELORES_M_ENCODER
+from src.utils import concat_all_gather
+
+
+def _world():
+    import torch.distributed as dist
+    return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+
+
+class Upstream_Expert(FusedExpertMixin, UpstreamModule):
+    def __init__(self, config, base_encoder, datamodule=None, emb_dim: int = 128, num_negatives: int = 65536,
+                 encoder_momentum: float = 0.999, softmax_temperature: float = 0.07, learning_rate: float = 0.03,
+                 momentum: float = 0.9, weight_decay: float = 1e-4, data_dir: str = './', batch_size: int = 256,
+                 use_mlp: bool = False, num_workers: int = 8, *args, **kwargs):
+        super().__init__()
+        self.save_hyperparameters()
+        if use_mlp:
+            raise NotImplementedError("use_mlp is not part of the HIP path")
+        self.config = config
+        self.base_encoder = base_encoder
+        self.datamodule = datamodule
+        self.encoder_q, self.encoder_k = self.init_encoders(self.base_encoder)
+        for param_q, param_k in zip(self.encoder_q.parameters(), self.encoder_k.parameters()):
+            param_k.data.copy_(param_q.data)
+            param_k.requires_grad = False
+        self.register_buffer("queue", nn.functional.normalize(torch.randn(emb_dim, num_negatives), dim=0))
+        self.register_buffer("queue_ptr", torch.zeros(1, dtype=torch.long))
+        lam, scale = self.config["pretrain"]["lambda_barlow"], self.config["pretrain"]["loss_scale"]
+        self.p1 = Projection(2048, lam[0], scale)
+        self.p2 = Projection(1024, lam[1], scale)
+        self.p3 = Projection(512, lam[2], scale)
+        self.precision = {"fp32": N.F32, "bf16": N.BF16}.get(config.get("run", {}).get("precision"), default_precision())
+        self.encoder_q.encoder.precision = self.encoder_k.encoder.precision = self.precision
+        self.flat_k = None
+        self._ptr = 0                      # host mirror of queue_ptr (no device sync in the step)
+
+    def init_encoders(self, base_encoder):
+        return DELORES_M_ENCODER(self.config, base_encoder), DELORES_M_ENCODER(self.config, base_encoder)
+
+    # ------------------------------------------------------------------ flat storage
+    def trainable_named(self):
+        # encoder_q first, in the same order as encoder_k's parameters, so that one EMA launch covers both
+        named = [(n, p) for n, p in self.named_parameters() if n.startswith("encoder_q.")]
+        named += [(n, p) for n, p in self.named_parameters() if n.startswith(("p1.", "p2.", "p3."))]
+        return named
+
+    def on_reflatten(self):
+        self.flat_k = FlatGroup([(n, p) for n, p in self.encoder_k.named_parameters()])
+
+    def _load_from_state_dict(self, state_dict, prefix, *args, **kwargs):
+        super()._load_from_state_dict(state_dict, prefix, *args, **kwargs)
+        self._ptr = int(self.queue_ptr[0])
+
+    @torch.no_grad()
+    def _momentum_update_key_encoder(self):
+        self.ensure_flat()
+        N.call("ema_update", self.flat_k.data, self.flat.data, self.flat_k.numel, float(self.hparams.encoder_momentum))
+
+    @torch.no_grad()
+    def _dequeue_and_enqueue(self, keys32, shadow):
+        if _world() > 1:
+            keys32 = concat_all_gather(keys32)
+        batch_size = keys32.shape[0]
+        K = self.hparams.num_negatives
+        assert K % batch_size == 0  # for simplicity
+        N.call("enqueue", self.precision, keys32, batch_size, keys32.shape[1], K, self._ptr, self.queue, shadow)
+        self._ptr = (self._ptr + batch_size) % K
+        self.queue_ptr.fill_(self._ptr)
+
+    @torch.no_grad()
+    def _batch_shuffle_ddp(self, x):
+        import torch.distributed as dist
+        batch_size_this = x.shape[0]
+        x_gather = concat_all_gather(x)
+        batch_size_all = x_gather.shape[0]
+        num_gpus = batch_size_all // batch_size_this
+        idx_shuffle = torch.randperm(batch_size_all, device=x.device)
+        dist.broadcast(idx_shuffle, src=0)
+        idx_unshuffle = torch.argsort(idx_shuffle)
+        idx_this = idx_shuffle.view(num_gpus, -1)[dist.get_rank()]
+        return x_gather[idx_this], idx_unshuffle
+
+    @torch.no_grad()
+    def _batch_unshuffle_ddp(self, x, idx_unshuffle):
+        import torch.distributed as dist
+        batch_size_this = x.shape[0]
+        x_gather = concat_all_gather(x)
+        num_gpus = x_gather.shape[0] // batch_size_this
+        idx_this = idx_unshuffle.view(num_gpus, -1)[dist.get_rank()]
+        return x_gather[idx_this]
+
+    # ------------------------------------------------------------------ fused step
+    def fused_loss(self, img_q, img_k, need_grad=True, parts=None):
+        dt = self.precision
+        flat = self.ensure_flat()
+        if need_grad:
+            flat.zero_grad()
+        dev = img_q.device
+        B = img_q.shape[0]
+        loss = torch.zeros(4, dtype=torch.float32, device=dev)          # [ce, barlow1, barlow2, barlow3]
+        eq, ek = self.encoder_q, self.encoder_k
+        # ---- query encoder
+        img_q = img_q.float().contiguous()
+        keep = eq.encoder.next_keep_mask(B, img_q.shape[-1])
+        q1, q2, q3, Hq, cq = E.encoder_forward(eq.encoder.param_dict(), img_q, dt, keep=keep, p_drop=0.3, train=self.training)
+        yq, argq = E.maxmean_forward(dt, Hq)
+        Wq = E.cast(dt, eq.fc.weight.data)
+        q = E.linear_fwd(dt, yq, Wq, B, Wq.shape[0], Wq.shape[1], bias=eq.fc.bias.data, out_f32=1)
+        # ---- key encoder (no gradient): EMA first, then forward on (shuffled) keys
+        self._momentum_update_key_encoder()
+        img_k = img_k.float().contiguous()
+        ddp = _world() > 1
+        if ddp:
+            img_k, idx_unshuffle = self._batch_shuffle_ddp(img_k)
+        keepk = ek.encoder.next_keep_mask(B, img_k.shape[-1])
+        k1, k2, k3, Hk, _ = E.encoder_forward(ek.encoder.param_dict(), img_k, dt, keep=keepk, p_drop=0.3, train=self.training)
+        yk, _ = E.maxmean_forward(dt, Hk)
+        k = E.linear_fwd(dt, yk, E.cast(dt, ek.fc.weight.data), B, Wq.shape[0], Wq.shape[1], bias=ek.fc.bias.data, out_f32=1)
+        if ddp:
+            k = self._batch_unshuffle_ddp(k, idx_unshuffle)
+        # ---- InfoNCE against the queue, then enqueue the keys
+        shadow = E.cast(dt, self.queue) if dt != N.F32 else self.queue
+        dq, kn32 = E.moco_forward_backward(dt, q, k, self.queue, shadow, float(self.hparams.softmax_temperature),
+                                           loss[0:1], backward=need_grad)
+        self._dequeue_and_enqueue(kn32, None)
+        # ---- Barlow heads on the layer means
+        G = flat.grad_dict
+        dys = []
+        for i, (p, xq, xk) in enumerate(((self.p1, q1, k1), (self.p2, q2, k2), (self.p3, q3, k3))):
+            dy, _ = E.barlow_forward_backward(p.param_dict(), G(f"p{i + 1}."), xq, xk, dt, p.lambd, p.scale_loss,
+                                              loss[i + 1:i + 2], need_dy1=True, need_dy2=False,
+                                              update_running=self.training, backward=need_grad)
+            dys.append(dy)
+        if need_grad:
+            Gq = G("encoder_q.")
+            E.linear_bwd_w(dt, dq, yq, Gq["fc.weight"], B, Wq.shape[0], Wq.shape[1])
+            E.colsum_add(dt, dq, B, Wq.shape[0], Gq["fc.bias"])
+            dyq = E.linear_bwd_x(dt, dq, Wq, B, Wq.shape[0], Wq.shape[1])
+            E.encoder_backward(cq, G("encoder_q.encoder."), dA2=E.maxmean_backward(dt, dyq, argq, Hq), dx1=dys[0],
+                               dx2=dys[1], dx3=dys[2])
+        if parts is not None:
+            parts["losses"] = loss
+        return loss.sum()
+
+    def forward(self, img_q=None, img_k=None):
+        raise NotImplementedError("the HIP expert fuses forward and loss; call training_step((img_1, img_2), i)")
+
+    def training_step(self, batch, batch_idx):
+        img_1, img_2 = batch
+        params = [p for _, p in self.trainable_named()]
+        loss = FusedStepFn.apply(self, torch.is_grad_enabled(), img_1, img_2, *params)
+        self.log_dict({'train_loss': loss})
+        return loss

@@ -1,0 +1,83 @@
+"""DeLoRes-S expert on MI355X: one encoder, two views, Barlow-Twins style cross-correlation loss.
+
+Same class name, constructor and methods as `src/upstream/delores_s/upstream_expert.py:52-243` of the reference
+(`Upstream_Expert(config, base_encoder, datamodule=...)`, `forward`, `training_step`, `configure_optimizers`,
+attribute `encoder`; `encoder_q` is an alias so `load_pretrained_encoder` works).
+`training_step` runs the whole step - both encoder passes, the projector, the loss and the complete backward - as
+one fused sequence of HIP launches (`src.engine`); `loss.backward()` only publishes the gradients.
+"""
+import torch
+
+from src import _native as N
+from src import engine as E
+from src.encoder.audiontt import default_precision
+from src.module_base import UpstreamModule
+from src.upstream.common import FusedExpertMixin, FusedStepFn, Projection
+from src.upstream.delores_s.upstream_encoder import DELORES_S as DELORES_S_ENCODER
+
+
+class Upstream_Expert(FusedExpertMixin, UpstreamModule):
+    def __init__(self, config, base_encoder, datamodule=None, emb_dim: int = 128, num_negatives: int = 65536,
+                 encoder_momentum: float = 0.999, softmax_temperature: float = 0.07, learning_rate: float = 0.03,
+                 momentum: float = 0.9, weight_decay: float = 1e-4, data_dir: str = './', batch_size: int = 256,
+                 use_mlp: bool = False, num_workers: int = 8, *args, **kwargs):
+        super().__init__()
+        self.save_hyperparameters()
+        self.config = config
+        self.base_encoder = base_encoder
+        self.datamodule = datamodule
+        self.encoder = self.init_encoders(self.base_encoder)
+        self.p = Projection(self.config["pretrain"]["projection_dim"], self.config["pretrain"]["lambda_barlow"])
+        self.precision = {"fp32": N.F32, "bf16": N.BF16}.get(config.get("run", {}).get("precision"), default_precision())
+        self.encoder.encoder.precision = self.precision
+        self.cross_gpu_barlow = bool(config.get("run", {}).get("cross_gpu_barlow", False))
+
+    def init_encoders(self, base_encoder):
+        return DELORES_S_ENCODER(self.config, base_encoder)
+
+    @property
+    def encoder_q(self):
+        return self.encoder
+
+    def forward(self, img_q=None, img_k=None):
+        return self.encoder(img_q), self.encoder(img_k)
+
+    # ------------------------------------------------------------------ fused step
+    def fused_loss(self, img_1, img_2, need_grad=True):
+        dt = self.precision
+        enc = self.encoder.encoder
+        flat = self.ensure_flat()
+        if need_grad:
+            flat.zero_grad()
+        loss = torch.zeros(1, dtype=torch.float32, device=img_1.device)
+        P = enc.param_dict()
+        G = flat.grad_dict("encoder.encoder.")
+        views = []
+        for img in (img_1, img_2):
+            img = img.float().contiguous()
+            keep = enc.next_keep_mask(img.shape[0], img.shape[-1])
+            _, _, _, H, c = E.encoder_forward(P, img, dt, keep=keep, p_drop=enc.fc[2].p, train=self.training,
+                                              want_layers=False)
+            y, arg = E.maxmean_forward(dt, H)
+            views.append((c, H, y, arg))
+        ar, gb = self._barlow_reduce()
+        dy1, dy2 = E.barlow_forward_backward(self.p.param_dict(), flat.grad_dict("p."), views[0][2], views[1][2], dt,
+                                             self.p.lambd, self.p.scale_loss, loss, update_running=self.training,
+                                             all_reduce=ar, global_batch=gb(img_1.shape[0]), backward=need_grad)
+        if need_grad:
+            for (c, H, y, arg), dy in zip(views, (dy1, dy2)):
+                E.encoder_backward(c, G, dA2=E.maxmean_backward(dt, dy, arg, H))
+        return loss[0]
+
+    def _barlow_reduce(self):
+        import torch.distributed as dist
+        if self.cross_gpu_barlow and dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            return (lambda c: dist.all_reduce(c)), (lambda b: b * dist.get_world_size())
+        return None, (lambda b: None)
+
+    def training_step(self, batch, batch_idx):
+        img_1, img_2 = batch
+        params = [p for _, p in self.trainable_named()]
+        loss = FusedStepFn.apply(self, torch.is_grad_enabled(), img_1, img_2, *params)
+        self.log_dict({'train_loss': loss})
+        return loss

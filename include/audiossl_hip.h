@@ -135,10 +135,16 @@ int audiossl_ema_update(float* pk, const float* pq, long n, float m, void* strea
 
 /* ---- K17 optimiser + plumbing: delores_s/upstream_expert.py:236-243 (torch.optim.SGD) ---------------------- */
 int audiossl_sgd_momentum(float* p, const float* g, float* buf, long n, float lr, float momentum, float weight_decay,
-                          int first, float grad_scale, void* stream);
+                          int first, float grad_scale, const float* grad_scale_dev, void* stream);
 int audiossl_cast(int dtype, const float* src, void* dst, long n, void* stream);
 int audiossl_cast_back(int dtype, const void* src, float* dst, long n, void* stream);
 int audiossl_dropout_mask(uint8_t* keep, long n, unsigned long long seed, float p, void* stream);
+/* out = g where h > 0 else 0 (nn.ReLU backward on the stored activation); eval-mode BatchNorm folded to scale/shift
+ * (audiontt.py:47,53,58 under model.eval()); y += a*x on fp32 buffers. */
+int audiossl_relu_bwd(int dtype, const void* g, const void* h, void* out, long n, void* stream);
+int audiossl_bn_eval_affine(const float* gamma, const float* beta, const float* running_mean, const float* running_var,
+                            float eps, int C, float* scale, float* shift, void* stream);
+int audiossl_axpy(float* y, const float* x, float a, long n, void* stream);
 
 #ifdef __cplusplus
 }

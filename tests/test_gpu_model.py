@@ -1,0 +1,215 @@
+"""GPU: encoder, loss heads and full training steps of the HIP path against
+  (a) the fixtures produced by the reference's own code (tests/golden/*.npz), and
+  (b) the CPU oracle on larger seeded inputs.
+Stated tolerances: fp32 path (exact-f32 MFMA): activations / loss rel 2e-4, gradient norms rel 2e-3;
+bf16 path (bf16 storage + MFMA, fp32 accumulate): activations rel-L2 2e-2, loss rel 2e-2, gradient norms rel 6e-2."""
+import copy
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import fill
+from oracle import model as OM
+from helpers import closed_queue, drop_mask, grad_digest, rel_l2, views
+
+pytestmark = pytest.mark.gpu
+
+ACT_TOL = {"fp32": 2e-4, "bf16": 2e-2}
+LOSS_TOL = {"fp32": 2e-4, "bf16": 2e-2}
+GRAD_TOL = {"fp32": 2e-3, "bf16": 6e-2}
+
+
+def _cfg(base, prec):
+    c = copy.deepcopy(base)
+    c["run"]["precision"] = prec
+    return c
+
+
+def _prec_id(prec):
+    from src import _native as N
+    return {"fp32": N.F32, "bf16": N.BF16}[prec]
+
+
+# ------------------------------------------------------------------------------------------------ encoder
+@pytest.mark.parametrize("prec", ["fp32", "bf16"])
+@pytest.mark.parametrize("T", [101, 96])
+def test_encoder_vs_reference_golden(golden, prec, T):
+    from src.encoder import AudioNTT2020Task6
+    g = golden(f"encoder_T{T}")
+    enc = AudioNTT2020Task6(64, 2048, True)
+    fill.fill_state_dict_(enc, seed=1)
+    enc = enc.cuda()
+    enc.precision = _prec_id(prec)
+    x = views(2, T, 4000 + T).cuda()
+    enc.eval()
+    with torch.no_grad():
+        e = enc(x)
+    for got, key in zip(e, ("eval_x1", "eval_x2", "eval_x3", "eval_x")):
+        assert rel_l2(got.float().cpu(), g[key]) < ACT_TOL[prec], key
+    enc.train()
+    enc.dropout_masks.queue = [drop_mask((2, T // 8, 2048), 4100 + T)]
+    a = enc(x)
+    for got, key in zip(a, ("x1", "x2", "x3", "x")):
+        assert rel_l2(got.float().cpu(), g[key]) < ACT_TOL[prec], key
+    r = [torch.from_numpy(fill.uniform(tuple(v.shape), 4200 + i)).cuda() for i, v in enumerate(a)]
+    loss = sum((v.float() * w).sum() for v, w in zip(a, r))
+    loss.backward()
+    assert abs(float(loss) - float(g["loss"])) <= LOSS_TOL[prec] * abs(float(g["loss"])) + (1e-3 if prec == "fp32" else 0.5)
+    names, norms, heads = grad_digest(enc)
+    assert names == [str(s) for s in g["g_names"]]
+    for n, got, want in zip(names, norms, g["g_norms"]):
+        if n.endswith("0.bias") and n.startswith("features"):
+            assert got <= 1e-3 + 1e-3 * want            # conv bias under train-mode BN: identically zero gradient
+            continue
+        assert abs(got - want) <= GRAD_TOL[prec] * want, (n, got, want)
+    np.testing.assert_allclose(enc.features_1[1].running_mean.cpu().numpy(), g["bn1_rm"], rtol=1e-3, atol=1e-5)
+    np.testing.assert_allclose(enc.features_3[1].running_var.cpu().numpy(), g["bn3_rv"], rtol=2e-2 if prec == "bf16" else 1e-3,
+                               atol=1e-5)
+
+
+# ------------------------------------------------------------------------------------------------ Barlow head
+@pytest.mark.parametrize("prec", ["fp32", "bf16"])
+@pytest.mark.parametrize("in_dim", [2048, 1024, 512])
+def test_barlow_head_vs_reference_golden(golden, prec, in_dim):
+    from src.upstream.common import Projection
+    g = golden("barlow")
+    p = Projection(in_dim, 5e-5)
+    fill.fill_state_dict_(p, seed=in_dim)
+    p = p.cuda().train()
+    td = torch.float32 if prec == "fp32" else torch.bfloat16
+    y1 = torch.from_numpy(fill.uniform((8, in_dim), 5000 + in_dim, 0.0, 2.0)).cuda().to(td).requires_grad_()
+    y2 = torch.from_numpy(fill.uniform((8, in_dim), 5001 + in_dim, 0.0, 2.0)).cuda().to(td).requires_grad_()
+    loss = p(y1, y2)
+    loss.backward()
+    want = float(g[f"loss_{in_dim}"])
+    assert abs(float(loss) - want) <= LOSS_TOL[prec] * want
+    assert rel_l2(y1.grad.float().cpu(), g[f"dy1_{in_dim}"]) < (5e-3 if prec == "fp32" else 0.15)
+    assert rel_l2(y2.grad.float().cpu(), g[f"dy2_{in_dim}"]) < (5e-3 if prec == "fp32" else 0.15)
+    _, norms, _ = grad_digest(p)
+    np.testing.assert_allclose(norms, g[f"gn_{in_dim}"], rtol=GRAD_TOL[prec])
+    np.testing.assert_allclose(p.bn.running_var.cpu().numpy()[:64], g[f"bn_rv_{in_dim}"], rtol=1e-3 if prec == "fp32" else 5e-2)
+
+
+# ------------------------------------------------------------------------------------------------ training steps
+def _run_steps(ex, batches, masks_fn, n_steps):
+    opt = ex.configure_optimizers()
+    losses, digest0 = [], None
+    for s in range(n_steps):
+        masks_fn(s)
+        opt.zero_grad()
+        loss = ex.training_step(batches(s), s)
+        loss.backward()
+        if s == 0:
+            digest0 = grad_digest(ex)
+        opt.step()
+        losses.append(float(loss))
+    return losses, digest0
+
+
+@pytest.mark.parametrize("prec", ["fp32", "bf16"])
+def test_delores_s_steps_vs_reference_golden(golden, cfg_s, prec):
+    from src.encoder import AudioNTT2020Task6
+    from src.upstream.delores_s.upstream_expert import Upstream_Expert
+    g = golden("step_delores_s")
+    ex = Upstream_Expert(_cfg(cfg_s, prec), base_encoder=AudioNTT2020Task6)
+    fill.fill_state_dict_(ex, seed=2)
+    ex = ex.cuda().train()
+    B, T, Tp = 8, 101, 12
+
+    def masks(s):
+        ex.encoder.encoder.dropout_masks.queue = [drop_mask((B, Tp, 2048), 6100 + 2 * s), drop_mask((B, Tp, 2048), 6101 + 2 * s)]
+    losses, (names, norms, heads) = _run_steps(
+        ex, lambda s: (views(B, T, 6000 + 2 * s).cuda(), views(B, T, 6001 + 2 * s).cuda()), masks, 3)
+    assert names == [str(n) for n in g["g_names"]]
+    np.testing.assert_allclose(losses, g["losses"], rtol=LOSS_TOL[prec])
+    for n, got, want in zip(names, norms, g["g_norms"]):
+        if n.endswith(".0.bias") and "features" in n:
+            continue
+        assert abs(got - want) <= GRAD_TOL[prec] * want + 1e-12, (n, got, want)
+    if prec == "fp32":
+        sd = ex.state_dict()
+        np.testing.assert_allclose(sd["encoder.encoder.features_1.0.weight"].cpu().numpy().ravel(), g["w_conv1"], rtol=2e-3, atol=2e-6)
+        np.testing.assert_allclose(sd["p.projector.0.weight"].cpu().numpy().ravel()[:256], g["w_p0_head"], rtol=2e-3, atol=2e-7)
+        np.testing.assert_allclose(sd["p.bn.running_mean"].cpu().numpy()[:64], g["bn_rm"], rtol=2e-3, atol=1e-5)
+
+
+@pytest.mark.parametrize("prec", ["fp32", "bf16"])
+def test_delores_m_steps_vs_reference_golden(golden, cfg_m, prec):
+    from src.encoder import AudioNTT2020Task6
+    from src.upstream.delores_m.upstream_expert import Upstream_Expert
+    g = golden("step_delores_m")
+    K = 1024
+    em = Upstream_Expert(_cfg(cfg_m, prec), base_encoder=AudioNTT2020Task6, num_negatives=K)
+    fill.fill_state_dict_(em, seed=3)
+    for pq, pk in zip(em.encoder_q.parameters(), em.encoder_k.parameters()):
+        pk.data.copy_(pq.data)
+    em.queue.copy_(closed_queue(128, K))
+    em = em.cuda().train()
+    B, T, Tp = 8, 101, 12
+
+    def masks(s):
+        em.encoder_q.encoder.dropout_masks.queue = [drop_mask((B, Tp, 2048), 7100 + 2 * s)]
+        em.encoder_k.encoder.dropout_masks.queue = [drop_mask((B, Tp, 2048), 7101 + 2 * s)]
+    losses, (names, norms, heads) = _run_steps(
+        em, lambda s: (views(B, T, 7000 + 2 * s).cuda(), views(B, T, 7001 + 2 * s).cuda()), masks, 3)
+    assert names == [str(n) for n in g["g_names"]]
+    np.testing.assert_allclose(losses, g["losses"], rtol=LOSS_TOL[prec])
+    for n, got, want in zip(names, norms, g["g_norms"]):
+        if n.endswith(".0.bias") and "features" in n:
+            continue
+        assert abs(got - want) <= GRAD_TOL[prec] * want + 1e-12, (n, got, want)
+    sd = em.state_dict()
+    assert int(sd["queue_ptr"]) == int(g["ptrs"][-1]) == 24
+    tol = 2e-3 if prec == "fp32" else 3e-2
+    assert rel_l2(sd["queue"][:, :24].cpu(), g["queue_cols"]) < tol
+    if prec == "fp32":
+        np.testing.assert_allclose(sd["encoder_k.encoder.features_1.0.weight"].cpu().numpy().ravel(), g["wk_conv1"], rtol=1e-4, atol=1e-6)
+        np.testing.assert_allclose(sd["encoder_q.encoder.features_1.0.weight"].cpu().numpy().ravel(), g["wq_conv1"], rtol=2e-3, atol=2e-6)
+
+
+@pytest.mark.parametrize("prec", ["fp32", "bf16"])
+def test_delores_m_b32_vs_oracle(cfg_m, prec):
+    """Larger batch, T=96 (the shipped YAML's 0.95 s), one step: every loss term and every gradient vs the CPU oracle."""
+    from src.encoder import AudioNTT2020Task6
+    from src.upstream.delores_m.upstream_expert import Upstream_Expert
+    B, T, Tp, K = 32, 96, 12, 2048
+    ref = OM.DeloresMExpert(copy.deepcopy(cfg_m), num_negatives=K)
+    fill.fill_state_dict_(ref, seed=9)
+    for pq, pk in zip(ref.encoder_q.parameters(), ref.encoder_k.parameters()):
+        pk.data.copy_(pq.data)
+    ref.queue.copy_(closed_queue(128, K))
+    ref.train()
+    a, b = views(B, T, 8800), views(B, T, 8801)
+    mq, mk = drop_mask((B, Tp, 2048), 8802), drop_mask((B, Tp, 2048), 8803)
+    parts = {}
+    loss_ref = ref.training_loss(a, b, mq, mk, parts)
+    loss_ref.backward()
+    rn, rnorm, _ = grad_digest(ref)
+
+    em = Upstream_Expert(_cfg(cfg_m, prec), base_encoder=AudioNTT2020Task6, num_negatives=K)
+    fill.fill_state_dict_(em, seed=9)
+    for pq, pk in zip(em.encoder_q.parameters(), em.encoder_k.parameters()):
+        pk.data.copy_(pq.data)
+    em.queue.copy_(closed_queue(128, K))
+    em = em.cuda().train()
+    em.encoder_q.encoder.dropout_masks.queue = [mq]
+    em.encoder_k.encoder.dropout_masks.queue = [mk]
+    got_parts = {}
+    loss = em.fused_loss(a.cuda(), b.cuda(), True, got_parts)
+    em.flat.attach_grads()
+    l4 = got_parts["losses"].cpu().numpy()
+    want4 = np.array([float(parts[k]) for k in ("ce", "b1", "b2", "b3")])
+    np.testing.assert_allclose(l4, want4, rtol=LOSS_TOL[prec])
+    assert abs(float(loss) - float(loss_ref)) <= LOSS_TOL[prec] * float(loss_ref)
+    names, norms, _ = grad_digest(em)
+    assert names == rn
+    for n, got, want in zip(names, norms, rnorm):
+        if n.endswith(".0.bias") and "features" in n:
+            continue
+        assert abs(got - want) <= GRAD_TOL[prec] * want + 1e-12, (n, got, want)
+    # full-tensor gradient check on the two largest weights
+    for n in ("encoder_q.encoder.fc.3.weight", "p1.projector.3.weight", "encoder_q.encoder.features_2.0.weight"):
+        gp = dict(em.named_parameters())[n].grad.float().cpu()
+        gr = dict(ref.named_parameters())[n].grad
+        assert rel_l2(gp, gr) < (5e-3 if prec == "fp32" else 0.12), n
