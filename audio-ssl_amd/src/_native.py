@@ -76,6 +76,8 @@ def call(name, *args):
     """Call `audiossl_<name>`; the trailing `stream` argument is filled with torch's current HIP stream."""
     full = name if name.startswith("audiossl_") else "audiossl_" + name
     proto = PROTOS[full]
+    if proto[-1][0] != "stream":
+        raise TypeError(f"{full} is a host entry point; use call_host")
     if len(args) != len(proto) - 1:
         raise TypeError(f"{full} takes {len(proto) - 1} arguments (+stream), got {len(args)}")
     conv = []
@@ -83,6 +85,17 @@ def call(name, *args):
         conv.append(_ptr(v) if ty is ctypes.c_void_p else v)
     conv.append(torch.cuda.current_stream().cuda_stream)
     rc = getattr(lib(), full)(*conv)
+    if rc != 0:
+        raise RuntimeError(f"{full} failed: {ERRORS.get(rc, rc)}")
+
+
+def call_host(name, *args):
+    """Call a host-side (CPU) entry point: no stream argument, raw host addresses / scalars only."""
+    full = name if name.startswith("audiossl_") else "audiossl_" + name
+    proto = PROTOS[full]
+    if len(args) != len(proto):
+        raise TypeError(f"{full} takes {len(proto)} arguments, got {len(args)}")
+    rc = getattr(lib(), full)(*args)
     if rc != 0:
         raise RuntimeError(f"{full} failed: {ERRORS.get(rc, rc)}")
 

@@ -178,6 +178,44 @@ class AugmentationModule:
 
     # ------------------------------------------------------------------ host planner (bit-exact RNG order)
     def plan(self, B, F, T):
+        """Native planner (csrc/planner.hip): continues numpy's and python's MT19937 states in C."""
+        import ctypes
+        ip = np.zeros((B, 2, 8), np.int32)
+        fp = np.zeros((B, 2, 2), _F32)
+        K = self.spec.max_masks if self.spec is not None else 1
+        mk = np.full((B, 2, K, 4), -1, np.int32)
+        ch = cw = 0
+        if self.rrc is not None:
+            ch, cw = int(F * self.rrc.virtual_crop_scale[0]), int(T * self.rrc.virtual_crop_scale[1])
+        st = np.random.get_state()
+        np_key = np.ascontiguousarray(st[1], dtype=np.uint32)
+        np_pos = ctypes.c_int(int(st[2]))
+        ps = random.getstate()
+        py_key = np.array(ps[1][:624], dtype=np.uint32)
+        py_pos = ctypes.c_int(int(ps[1][624]))
+        ne = ctypes.c_longlong(self.n_entries)
+        fs = self.rrc.freq_scale if self.rrc is not None else (1.0, 1.0)
+        ts = self.rrc.time_scale if self.rrc is not None else (1.0, 1.0)
+        sp = self.spec
+        N.call_host("aug_plan_host", np_key.ctypes.data, ctypes.addressof(np_pos), py_key.ctypes.data,
+                    ctypes.addressof(py_pos), B, F, T, self.clips_seen, ctypes.addressof(ne), self.R, self.n_memory,
+                    int(self.mix is not None), float(self.mix.ratio) if self.mix is not None else 0.0,
+                    int(self.rrc is not None), float(fs[0]), float(fs[1]), float(ts[0]), float(ts[1]), ch, cw,
+                    int(sp is not None), sp.F if sp else 1, sp.T if sp else 1, sp.nf if sp else 0, sp.nt if sp else 0,
+                    ip.ctypes.data, fp.ctypes.data, mk.ctypes.data)
+        np.random.set_state((st[0], np_key, np_pos.value, st[3], st[4]))
+        random.setstate((ps[0], tuple(int(v) for v in py_key) + (py_pos.value,), ps[2]))
+        self.n_entries = ne.value
+        self.clips_seen += B
+        masks = []
+        if sp is not None:
+            for b in range(B):
+                for v in range(2):
+                    masks.append([tuple(int(x) for x in m[:3]) for m in mk[b, v] if m[0] >= 0])
+        return ip, fp, (ch, cw), masks
+
+    def plan_py(self, B, F, T):
+        """Pure-Python planner: the same draws made with numpy / `random` themselves (cross-check of `plan`)."""
         ip = np.zeros((B, 2, 8), np.int32)
         fp = np.zeros((B, 2, 2), _F32)
         masks = []
