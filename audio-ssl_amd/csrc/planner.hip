@@ -74,19 +74,26 @@ inline int clipi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v)
 
 // ip [B][2][8] = {self_slot, partner_slot|-1, i, j, h, w, do_rrc, 0}; fp [B][2][2] = {coef_self, coef_partner};
 // masks [B][2][max_masks][4] = {axis, start, end, 0} (axis -1 = unused), max_masks = spec_nf + spec_nt.
+// lens/unit/starts (optional): clip lengths in samples, window length, and the drawn crop starts (per clip, BEFORE
+// that clip's view draws - the reference's per-clip interleaving of the python stream).
 extern "C" int audiossl_aug_plan_host(uint32_t* np_key, int* np_pos, uint32_t* py_key, int* py_pos, int B, int F, int T,
                                       long long clips_seen, long long* n_entries, int R, int n_memory, int use_mix,
                                       double ratio, int use_rrc, double fs_lo, double fs_hi, double ts_lo, double ts_hi,
                                       int canvas_h, int canvas_w, int use_spec, int spec_F, int spec_T, int spec_nf,
-                                      int spec_nt, int* ip, float* fp, int* masks) {
+                                      int spec_nt, const int* lens, int unit, int* starts, int* ip, float* fp, int* masks) {
     ASSL_REQUIRE(np_key && np_pos && py_key && py_pos && n_entries && ip && fp && B > 0 && R > 0);
     ASSL_REQUIRE(*np_pos >= 0 && *np_pos <= 624 && *py_pos >= 0 && *py_pos <= 624);
     ASSL_REQUIRE(!use_spec || masks);
+    ASSL_REQUIRE(!lens || (starts && unit > 0));
     MT npg{np_key, *np_pos}, pyg{py_key, *py_pos};
     long long ne = *n_entries;
     const int max_masks = spec_nf + spec_nt;
     for (int b = 0; b < B; ++b) {
         const long long c = clips_seen + b;
+        if (lens) {       // extract_window (`src/utils/utils.py:166-182`): one python draw, only when the clip is longer
+            const int over = lens[b] - unit;
+            starts[b] = over > 0 ? (int)py_randbelow(pyg, (uint32_t)(over + 1)) : 0;
+        }
         for (int v = 0; v < 2; ++v) {
             int* e = ip + ((long)b * 2 + v) * 8;
             float* f = fp + ((long)b * 2 + v) * 2;

@@ -44,6 +44,9 @@ def parse_header(path=HEADER_PATH):
 
 PROTOS = parse_header()
 _lib = None
+# Optional per-call timing (bench.py): {full_name: [(start_event, end_event, args), ...]} - HIP events recorded on the
+# stream the kernel is launched on (torch's current stream).
+PROFILE = None
 
 
 def lib():
@@ -84,7 +87,14 @@ def call(name, *args):
     for (an, ty), v in zip(proto, args):
         conv.append(_ptr(v) if ty is ctypes.c_void_p else v)
     conv.append(torch.cuda.current_stream().cuda_stream)
+    prof = PROFILE.get(full) if PROFILE is not None else None
+    if prof is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
     rc = getattr(lib(), full)(*conv)
+    if prof is not None:
+        e1.record()
+        prof.append((e0, e1, tuple(a for a in args if isinstance(a, (int, float)))))
     if rc != 0:
         raise RuntimeError(f"{full} failed: {ERRORS.get(rc, rc)}")
 

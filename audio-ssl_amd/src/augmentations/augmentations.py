@@ -177,8 +177,10 @@ class AugmentationModule:
         self.last_plan = None
 
     # ------------------------------------------------------------------ host planner (bit-exact RNG order)
-    def plan(self, B, F, T):
-        """Native planner (csrc/planner.hip): continues numpy's and python's MT19937 states in C."""
+    def plan(self, B, F, T, lens=None, unit=0):
+        """Native planner (csrc/planner.hip): continues numpy's and python's MT19937 states in C.
+        lens (optional int array [B]) + unit: also draw the random window start of every clip, interleaved per clip
+        as the reference's dataset does; the starts are left in `self.last_starts`."""
         import ctypes
         ip = np.zeros((B, 2, 8), np.int32)
         fp = np.zeros((B, 2, 2), _F32)
@@ -187,6 +189,8 @@ class AugmentationModule:
         ch = cw = 0
         if self.rrc is not None:
             ch, cw = int(F * self.rrc.virtual_crop_scale[0]), int(T * self.rrc.virtual_crop_scale[1])
+        lens_a = None if lens is None else np.ascontiguousarray(lens, dtype=np.int32)
+        starts = np.zeros(B, np.int32)
         st = np.random.get_state()
         np_key = np.ascontiguousarray(st[1], dtype=np.uint32)
         np_pos = ctypes.c_int(int(st[2]))
@@ -202,7 +206,9 @@ class AugmentationModule:
                     int(self.mix is not None), float(self.mix.ratio) if self.mix is not None else 0.0,
                     int(self.rrc is not None), float(fs[0]), float(fs[1]), float(ts[0]), float(ts[1]), ch, cw,
                     int(sp is not None), sp.F if sp else 1, sp.T if sp else 1, sp.nf if sp else 0, sp.nt if sp else 0,
-                    ip.ctypes.data, fp.ctypes.data, mk.ctypes.data)
+                    lens_a.ctypes.data if lens_a is not None else None, int(unit), starts.ctypes.data, ip.ctypes.data,
+                    fp.ctypes.data, mk.ctypes.data)
+        self.last_starts = starts if lens_a is not None else None
         np.random.set_state((st[0], np_key, np_pos.value, st[3], st[4]))
         random.setstate((ps[0], tuple(int(v) for v in py_key) + (py_pos.value,), ps[2]))
         self.n_entries = ne.value
@@ -214,8 +220,9 @@ class AugmentationModule:
                     masks.append([tuple(int(x) for x in m[:3]) for m in mk[b, v] if m[0] >= 0])
         return ip, fp, (ch, cw), masks
 
-    def plan_py(self, B, F, T):
+    def plan_py(self, B, F, T, lens=None, unit=0):
         """Pure-Python planner: the same draws made with numpy / `random` themselves (cross-check of `plan`)."""
+        starts = np.zeros(B, np.int32)
         ip = np.zeros((B, 2, 8), np.int32)
         fp = np.zeros((B, 2, 2), _F32)
         masks = []
@@ -224,6 +231,9 @@ class AugmentationModule:
             ch, cw = int(F * self.rrc.virtual_crop_scale[0]), int(T * self.rrc.virtual_crop_scale[1])
         for b in range(B):
             c = self.clips_seen + b
+            if lens is not None:
+                over = int(lens[b]) - unit
+                starts[b] = random.randint(0, over) if over > 0 else 0
             for v in range(2):
                 e = ip[b, v]
                 e[0] = c % self.R
@@ -245,25 +255,34 @@ class AugmentationModule:
                 if self.spec is not None:
                     masks.append(self.spec.plan(F, T))
         self.clips_seen += B
+        self.last_starts = starts if lens is not None else None
         return ip, fp, (ch, cw), masks
 
-    def _ensure_bank(self, B, n, device):
+    def _ensure_ring(self, B, n=None, device=None):
+        """Size (or grow) the ring of normalised clips; slots are clip_index % R, so R is fixed before planning."""
         need = 1025 + max(B, self.max_batch)
-        if self.bank is None:
+        if self.R == 0:
             self.R = need
-            self.bank = torch.zeros(self.R, n, dtype=torch.float32, device=device)
         elif need > self.R:
-            old, old_R = self.bank, self.R
+            if self.bank is not None:
+                old, old_R = self.bank, self.R
+                self.bank = torch.zeros(need, old.shape[1], dtype=torch.float32, device=old.device)
+                for c in range(max(0, self.clips_seen - 1025), self.clips_seen):
+                    self.bank[c % need].copy_(old[c % old_R])
             self.R = need
+        self.max_batch = max(self.max_batch, B)
+        if self.bank is None and n is not None:
             self.bank = torch.zeros(self.R, n, dtype=torch.float32, device=device)
-            lo = max(0, self.clips_seen - 1025)
-            for c in range(lo, self.clips_seen):
-                self.bank[c % self.R].copy_(old[c % old_R])
+
+    def _ensure_bank(self, B, n, device):
+        self._ensure_ring(B, n, device)
 
     # ------------------------------------------------------------------ batched device path
     @torch.no_grad()
-    def augment_batch(self, lms):
-        """lms [B, F, T] or [B, 1, F, T] log-mel (device) -> (view1, view2), each [B, 1, F, T] float32."""
+    def augment_batch(self, lms, plan=None):
+        """lms [B, F, T] or [B, 1, F, T] log-mel (device) -> (view1, view2), each [B, 1, F, T] float32.
+        plan: result of `self.plan(...)` made earlier for exactly this batch (e.g. at collate time, together with the
+        window crops); by default the draws happen here."""
         if lms.dim() == 4:
             lms = lms[:, 0]
         lms = lms.contiguous().float()
@@ -280,9 +299,13 @@ class AugmentationModule:
             si, sf = self.pre_norm.device_state(dev)
             N.call("clip_moments", lms, mom, B, n)
             N.call("runnorm_scan", mom, B, n, si, sf, mu, sd)
-        slot0 = self.clips_seen % self.R
+        if plan is None:
+            slot0 = self.clips_seen % self.R
+            plan = self.plan(B, F, T)
+        else:
+            slot0 = int(plan[0][0, 0, 0])
         N.call("aug_normalize", lms, mu, sd, self.bank, slot0, self.R, B, n)
-        ip, fp, (ch, cw), masks = self.plan(B, F, T)
+        ip, fp, (ch, cw), masks = plan
         self.last_plan = (ip, fp, masks)
         ip_d = torch.from_numpy(ip).to(dev, non_blocking=True)
         fp_d = torch.from_numpy(fp).to(dev, non_blocking=True)

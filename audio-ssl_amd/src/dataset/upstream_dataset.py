@@ -1,0 +1,146 @@
+"""Upstream data path: CSV of audio files -> waveform batches -> (on the GPU) log-mel + two augmented views.
+
+API mirror of `src/dataset/upstream_dataset.py:36-124` (BaseDataset, BaselineDataModule), re-shaped for the GPU:
+the reference decodes, crops, STFTs and augments ONE clip at a time inside DataLoader workers; here the loader
+only decodes and crops (the window start is drawn with the reference's generator, at the reference's position in the
+python `random` stream), and `UpstreamFrontEnd` turns a whole [B, L] waveform batch into the two [B,1,64,T] views
+with three fused launches (log-mel, normalise, views).
+Decoding: the reference uses librosa.core.load (audioread/soundfile + resampy); neither is in the image, so WAV
+files are read with scipy.io.wavfile (and .npy arrays directly) and resampled with scipy.signal.resample_poly -
+audio ingest is a "next" row of SURVEY 8f, not part of the parity-checked hot path.
+"""
+import numpy as np
+import pandas as pd
+import torch
+import torch.nn.functional as F
+from torch.utils.data import DataLoader, Dataset
+
+from src.utils import MelSpectrogramLibrosa, extract_log_mel_spectrogram, extract_window
+
+AUDIO_SR = 16000
+
+
+def load_audio(path, sr=AUDIO_SR):
+    """-> float32 mono numpy array at `sr`."""
+    if str(path).endswith(".npy"):
+        return np.load(path, allow_pickle=False).astype(np.float32)
+    from scipy.io import wavfile
+    rate, data = wavfile.read(path)
+    if data.dtype.kind == "i":
+        data = data.astype(np.float32) / float(np.iinfo(data.dtype).max + 1)
+    elif data.dtype.kind == "u":
+        data = (data.astype(np.float32) - 128.0) / 128.0
+    data = data.astype(np.float32)
+    if data.ndim > 1:
+        data = data.mean(axis=1)
+    if rate != sr:
+        from math import gcd
+        from scipy.signal import resample_poly
+        g = gcd(int(rate), int(sr))
+        data = resample_poly(data, sr // g, rate // g).astype(np.float32)
+    return data
+
+
+class UpstreamFrontEnd:
+    """waveforms [B, L] (device) -> (img_1, img_2), each [B, 1, n_mels, T] float32, entirely on the GPU."""
+
+    def __init__(self, config, tfms):
+        self.config = config
+        self.tfms = tfms
+        self.to_mel_spec = MelSpectrogramLibrosa()
+        self.l2 = config["pretrain"]["normalization"] == "l2"
+
+    @torch.no_grad()
+    def __call__(self, waves, plan=None):
+        if not waves.is_cuda:
+            waves = waves.cuda(non_blocking=True)
+        if self.l2:
+            waves = F.normalize(waves, dim=-1, p=2)
+        lms = extract_log_mel_spectrogram(waves, self.to_mel_spec)
+        return self.tfms.augment_batch(lms, plan=plan)
+
+
+class BaseDataset(Dataset):
+    def __init__(self, config, args, data_csv, tfms, per_sample=False):
+        self.config = config
+        self.tfms = tfms
+        self.length = self.config["pretrain"]["input"]["length_wave"]
+        self.norm_status = self.config["pretrain"]["normalization"]
+        self.sampling_rate = self.config["pretrain"]["input"]["sampling_rate"]
+        self.upstream = getattr(args, "upstream", None)
+        self.data = pd.read_csv(data_csv)
+        self.per_sample = per_sample
+        self.to_mel_spec = MelSpectrogramLibrosa() if per_sample else None
+        if self.config["pretrain"]["input"]["type"] != "raw_wav":
+            raise NotImplementedError("only input.type == raw_wav is supported (SURVEY 2.4)")
+
+    @property
+    def unit_length(self):
+        return int(self.length * 16000)
+
+    def __getitem__(self, idx):
+        wave = torch.from_numpy(load_audio(self.data["files"][idx], self.sampling_rate))
+        if not self.per_sample:
+            return wave                      # cropped at collate time, with the draws in the reference's order
+        # reference-shaped per-sample path (one clip through the same kernels; slow, for API parity)
+        waveform = extract_window(wave, data_size=self.length)
+        if self.norm_status == "l2":
+            waveform = F.normalize(waveform, dim=-1, p=2)
+        lms = extract_log_mel_spectrogram(waveform.cuda(), self.to_mel_spec).unsqueeze(0)
+        return self.tfms(lms) if self.tfms else lms
+
+    def __len__(self):
+        return len(self.data)
+
+
+class WindowCollate:
+    """Crop every clip of the batch to the training window and plan the augmentations.
+
+    The python `random` stream is consumed exactly as the reference's sequential loader would (per clip: the window
+    start, then that clip's view parameters), so crops and augmentation indices are bit-identical to a reference run
+    with `num_workers=0`."""
+
+    def __init__(self, tfms, unit_length, n_mels, hop=160):
+        self.tfms, self.unit, self.n_mels, self.hop = tfms, unit_length, n_mels, hop
+
+    def __call__(self, waves):
+        B = len(waves)
+        lens = np.array([len(w) for w in waves], np.int32)
+        T = 1 + self.unit // self.hop
+        self.tfms._ensure_ring(B)
+        plan = self.tfms.plan(B, self.n_mels, T, lens=lens, unit=self.unit)
+        starts = self.tfms.last_starts
+        out = torch.zeros(B, self.unit, dtype=torch.float32)
+        for b, w in enumerate(waves):
+            n = len(w)
+            if n >= self.unit:
+                out[b] = w[starts[b]:starts[b] + self.unit]
+            else:
+                left = (self.unit - n) // 2
+                out[b, left:left + n] = w
+        return out, plan
+
+
+class BaselineDataModule:
+    def __init__(self, config, args, tfms, data_csv='./', batch_size=8, num_workers=8):
+        self.config = config
+        self.args = args
+        self.data_dir_train = data_csv
+        self.batch_size = batch_size
+        self.num_workers = num_workers
+        self.transformation = tfms
+        self.dataset_sizes = {}
+        self.name = "audio"
+        self.front_end = UpstreamFrontEnd(config, tfms)
+
+    def setup(self, stage=None):
+        if stage == 'fit' or stage is None:
+            self.train_dataset = BaseDataset(self.config, self.args, self.data_dir_train, self.transformation)
+            self.dataset_sizes['train'] = len(self.train_dataset)
+
+    def train_dataloader(self, sampler=None):
+        unit = self.train_dataset.unit_length
+        collate = WindowCollate(self.transformation, unit, self.config["pretrain"]["input"]["n_mels"])
+        # planning is stateful (one sequential stream): it runs in the main process, decoding may use workers
+        return DataLoader(self.train_dataset, shuffle=sampler is None, sampler=sampler, batch_size=self.batch_size,
+                          num_workers=0, drop_last=True, pin_memory=True, collate_fn=collate)

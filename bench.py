@@ -1,0 +1,196 @@
+#!/usr/bin/env python3
+"""Headline benchmark: upstream clips/s of the DeLoRes-M pre-training step on MI355X (BASELINE.json configs[1]).
+
+One "step" = one pass of the hot path over one synthetic batch already resident in HBM:
+  waveforms [B,16000] -> log-mel -> running norm + two augmented views -> q/k encoders, MoCo InfoNCE (65,536-key
+  queue), three Barlow heads, full backward -> [all-reduce] -> SGD(momentum) step.
+Contract: `python bench.py --gpus N --steps K --warmup W`; for N > 1 launch with torch.distributed.run (one rank per
+GPU, RCCL).  Weak scaling (per-GPU batch fixed).  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import copy
+import json
+import os
+import random
+import sys
+import time
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "audio-ssl_amd")]
+
+CFG = {"run": {"batch_size": 512, "world_size": 1, "num_dataloader_workers": 0, "save_path": "/tmp/audiossl_bench/",
+               "precision": "bf16"},
+       "pretrain": {"base_encoder": {"type": "AudioNTT2020Task6", "output_dim": 2048, "return_all_layers": True},
+                    "projection_dim": 2048, "contrastive_dim": 128, "normalization": "mean_var",
+                    "lambda_barlow": [5e-5, 5e-5, 5e-5], "loss_scale": "1/32",
+                    "input": {"type": "raw_wav", "sampling_rate": 16000, "length_wave": 1.0, "n_mels": 64},
+                    "augmentations": {"MixupBYOLA": {"ratio": 0.4, "log_mixup_exp": True},
+                                      "RandomResizeCrop": {"virtual_crop_scale": [1.0, 1.5], "freq_crop_scale": [0.6, 1.5],
+                                                           "time_crop_scale": [0.6, 1.5]}}}}
+PEAK_TFLOPS = {0: 157.3, 1: 2500.0}          # MI355X_MICROARCH.md: f32-in MFMA = vector peak; bf16 dense MFMA
+GEMM_SYMBOL = {(0, 0): "NT", (0, 1): "NN", (1, 1): "TN", (1, 0): "TT"}
+
+
+def synth_waves(B, L, seed):
+    """Seeded uniform noise x0.1 + 440 Hz + 3 kHz tones; last two clips: silence / full scale."""
+    g = np.random.RandomState(seed)
+    t = np.arange(L) / 16000.0
+    w = g.uniform(-0.1, 0.1, (B, L)) + 0.3 * np.sin(2 * np.pi * 440 * t) + 0.2 * np.sin(2 * np.pi * 3000 * t)
+    if B >= 4:
+        w[-2] = 0.0
+        w[-1] = 1.0
+    return w.astype(np.float32)
+
+
+def cpu_baseline(B, steps, queue):
+    """The CPU oracle (port of the reference path) timed on this host: log-mel + aug + delores_m step."""
+    from oracle import augment as OA, frontend as FE, model as OM
+    torch.set_num_threads(os.cpu_count() or 1)
+    cfg = copy.deepcopy(CFG)
+    np.random.seed(31)
+    random.seed(31)
+    torch.manual_seed(0)
+    ex = OM.DeloresMExpert(cfg, num_negatives=queue).train()
+    tf = OA.AugmentationModule(cfg, 100000)
+    mel = FE.MelSpectrogram()
+    waves = torch.from_numpy(synth_waves(B, 16000, 1234))
+    params = [p for p in ex.parameters() if p.requires_grad]
+    bufs = {}
+
+    def step():
+        lms = FE.log_mel_batch(waves, mel)
+        v = [tf(lms[b][None]) for b in range(B)]
+        a = torch.stack([x[0] for x in v])
+        b = torch.stack([x[1] for x in v])
+        keep_q = (torch.rand(B, 12, 2048) >= 0.3).float()
+        keep_k = (torch.rand(B, 12, 2048) >= 0.3).float()
+        for p in params:
+            p.grad = None
+        loss = ex.training_loss(a, b, keep_q, keep_k)
+        loss.backward()
+        OM.sgd_momentum_step(params, bufs, 0.03, 0.9, 1e-4)
+        return float(loss)
+    step()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    dt = time.perf_counter() - t0
+    return {"value": B * steps / dt, "unit": "clips/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{steps} steps of batch {B} (log-mel + two views + delores_m fwd/bwd/SGD, queue {queue}), fp32, torch-CPU oracle"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=512, help="per-GPU batch (weak scaling)")
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--queue", type=int, default=65536)
+    ap.add_argument("--cpu-batch", type=int, default=32)
+    ap.add_argument("--cpu-steps", type=int, default=4)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank, world = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
+    local = int(os.environ.get("LOCAL_RANK", 0))
+    if world != args.gpus and world == 1 and args.gpus > 1:
+        raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world)
+
+    from src import _native as N
+    from src.augmentations import AugmentationModule
+    from src.dataset import UpstreamFrontEnd
+    from src.encoder import AudioNTT2020Task6
+    from src.upstream.delores_m.upstream_expert import Upstream_Expert
+    N.lib()
+
+    cfg = copy.deepcopy(CFG)
+    cfg["run"]["precision"] = args.precision
+    cfg["run"]["batch_size"] = args.batch
+    B = args.batch
+    np.random.seed(31 + rank)
+    random.seed(31 + rank)
+    torch.manual_seed(0)                                           # identical initial weights on every rank
+    model = Upstream_Expert(cfg, base_encoder=AudioNTT2020Task6, num_negatives=args.queue).to(dev).train()
+    tfms = AugmentationModule(cfg, 100000, max_batch=B)
+    front = UpstreamFrontEnd(cfg, tfms)
+    opt = model.configure_optimizers()
+    waves = torch.from_numpy(synth_waves(B, 16000, 1234 + rank)).to(dev)
+
+    def step(i):
+        img_1, img_2 = front(waves)
+        opt.zero_grad()
+        loss = model.training_step((img_1, img_2), i)
+        loss.backward()
+        model.all_reduce_grads()
+        opt.step()
+        return loss
+
+    for i in range(args.warmup):
+        loss = step(i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    N.PROFILE = {"audiossl_gemm": []}
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        loss = step(args.warmup + i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    prof, N.PROFILE = N.PROFILE, None
+    final_loss = float(loss)
+    if world > 1:
+        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax)
+    if rank != 0:
+        return
+
+    # ---- roofline of the dominant kernel (largest total time among the GEMM instantiations)
+    groups = {}
+    for e0, e1, a in prof["audiossl_gemm"]:
+        dtype, ta, tb, M, Nn, K = a[0], a[1], a[2], a[3], a[4], a[5]
+        g = groups.setdefault((dtype, ta, tb), [0.0, 0.0, 0])
+        g[0] += e0.elapsed_time(e1) * 1e-3
+        g[1] += 2.0 * M * Nn * K
+        g[2] += 1
+    (dtype, ta, tb), (tsec, flops, launches) = max(groups.items(), key=lambda kv: kv[1][0])
+    achieved = flops / tsec / 1e12
+    roofline = {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_TFLOPS[dtype], "unit": "TFLOP/s",
+                "frac": round(achieved / PEAK_TFLOPS[dtype], 4), "traffic": None,
+                "kernel": f"gemm_kernel<{'bf16' if dtype else 'f32'},{GEMM_SYMBOL[(ta, tb)]}>", "launches_per_step": launches / args.steps,
+                "avg_launch_us": round(tsec / launches * 1e6, 2), "flop_per_launch": flops / launches,
+                "share_of_step": round(tsec / dt, 3)}
+    out = {"metric": "upstream clips/sec (1s@16kHz, 64-mel)", "value": round(B * world * args.steps / dt, 1), "unit": "clips/s",
+           "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
+           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
+           "config": {"workload": "delores-m upstream step (log-mel + 2 views + q/k conv encoders + MoCo + 3 Barlow heads + bwd + SGD), "
+                                  f"1 s @ 16 kHz, 64 mel, batch {B}/GPU, queue {args.queue}", "global_batch": B * world,
+                      "parallelism": f"dp{world}"},
+           "final_loss": final_loss, "roofline": roofline}
+    if world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(args.cpu_batch, args.cpu_steps, args.queue)
+    else:
+        out["cpu_baseline"] = None
+    print(json.dumps(out))
+    if world > 1:
+        pass
+
+
+if __name__ == "__main__":
+    main()
+    if dist.is_available() and dist.is_initialized():
+        dist.destroy_process_group()

@@ -57,12 +57,13 @@ int audiossl_aug_views(const float* bank, int R, const int* ip, const float* fp,
 /* ---- host planner (CPU function, HOST pointers, no stream): the reference's per-clip random draws, batched ---------
  * Continues numpy's legacy global MT19937 (np_key[624], *np_pos) and python `random`'s MT19937 (py_key, *py_pos) in
  * the reference's draw order (augmentations.py:32-37, 99-102; specaugment.py:80-88) and fills the aug_views /
- * mask_fill tables.  *n_entries = entries appended so far to MixupBYOLA's virtual FIFO (updated). */
+ * mask_fill tables.  *n_entries = entries appended so far to MixupBYOLA's virtual FIFO (updated).  lens/unit/starts
+ * (optional): the random window crop of src/utils/utils.py:166-182, drawn per clip ahead of that clip's views. */
 int audiossl_aug_plan_host(uint32_t* np_key, int* np_pos, uint32_t* py_key, int* py_pos, int B, int F, int T,
                            long long clips_seen, long long* n_entries, int R, int n_memory, int use_mix, double ratio,
                            int use_rrc, double fs_lo, double fs_hi, double ts_lo, double ts_hi, int canvas_h,
-                           int canvas_w, int use_spec, int spec_F, int spec_T, int spec_nf, int spec_nt, int* ip,
-                           float* fp, int* masks);
+                           int canvas_w, int use_spec, int spec_F, int spec_T, int spec_nf, int spec_nt, const int* lens,
+                           int unit, int* starts, int* ip, float* fp, int* masks);
 
 /* ---- K5 SpecAugment band masks: extras/delores-s/specaugment.py:68-122 ---------------------------------
  * tab [n_img][max_masks][4] = {axis (0 time, 1 freq, -1 stop), start, end, 0}; in place on x [n_img][F][T]. */

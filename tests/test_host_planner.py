@@ -49,8 +49,9 @@ def test_native_planner_bit_exact(seed, sizes, spec, mix, rrc, T):
         m = _module(cfg)
         rec = []
         for B in sizes:
-            ip, fp, canvas, masks = (m.plan if native else m.plan_py)(B, F, T)
-            rec.append((ip.copy(), fp.copy(), canvas, masks))
+            lens = (np.arange(B) * 3571 + seed) % 40000 + 100       # some shorter, some longer than the window
+            ip, fp, canvas, masks = (m.plan if native else m.plan_py)(B, F, T, lens=lens, unit=16000)
+            rec.append((ip.copy(), fp.copy(), canvas, masks + [tuple(int(v) for v in m.last_starts)]))
         outs.append((rec, np.random.random(), random.random(), m.n_entries, m.clips_seen))
     (ra, na, pa, ea, ca), (rb, nb, pb, eb, cb) = outs
     assert na == nb and pa == pb and ea == eb and ca == cb
