@@ -8,33 +8,37 @@
 namespace {
 
 // ---------------------------------------------------------------------------------- column statistics
-// x [M][C] row-major.  sum/sumsq [C] in fp64 (atomics, caller zeroes).  C % 8 == 0; C/8 <= 256 and 256 % (C/8) == 0.
+// x [M][C] row-major (ld).  sum/sumsq [C] in fp64 (atomics, caller zeroes).  C % 64 == 0.
+// A block owns a slab of 64 columns (8 lanes x 8 elements = one 128-byte line per row) and 32 rows per iteration;
+// blockIdx.y picks the slab, blockIdx.x a chunk of rows.
 template <typename T_, bool SQ>
 __global__ __launch_bounds__(256) void colstats_kernel(const T_* __restrict__ x, long M, int C, long ld, int rows_per_block,
                                                        double* __restrict__ sum, double* __restrict__ sumsq) {
     __shared__ float red[256][17];
-    const int G = C / 8, RPI = 256 / G;
-    const int cg = threadIdx.x % G, r0 = threadIdx.x / G;
+    const int cg = threadIdx.x & 7, r0 = threadIdx.x >> 3;
+    const int col0 = blockIdx.y * 64 + cg * 8;
     const long row_begin = (long)blockIdx.x * rows_per_block;
     const long row_end = min(M, row_begin + rows_per_block);
     float s[8], q[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) { s[i] = 0.f; q[i] = 0.f; }
-    for (long r = row_begin + r0; r < row_end; r += RPI) {
-        const Vec8<T_> v = Vec8<T_>::load(x + r * ld + cg * 8);
+    for (long r = row_begin + r0; r < row_end; r += 32) {
+        const Vec8<T_> v = Vec8<T_>::load(x + r * ld + col0);
 #pragma unroll
         for (int i = 0; i < 8; ++i) { const float f = v.get(i); s[i] += f; if (SQ) q[i] += f * f; }
     }
 #pragma unroll
     for (int i = 0; i < 8; ++i) { red[threadIdx.x][i] = s[i]; red[threadIdx.x][8 + i] = q[i]; }
     __syncthreads();
-    for (int o = threadIdx.x; o < G * 16; o += 256) {
-        const int g = o / 16, k = o % 16;
-        if (!SQ && k >= 8) continue;
-        double t = 0.0;
-        for (int r = 0; r < RPI; ++r) t += (double)red[r * G + g][k];
-        if (k < 8) atomicAdd(&sum[g * 8 + k], t);
-        else       atomicAdd(&sumsq[g * 8 + (k - 8)], t);
+    if (threadIdx.x < 128) {
+        const int g = threadIdx.x >> 4, k = threadIdx.x & 15;
+        if (SQ || k < 8) {
+            double t = 0.0;
+            for (int r = 0; r < 32; ++r) t += (double)red[r * 8 + g][k];
+            const int c = blockIdx.y * 64 + g * 8 + (k & 7);
+            if (k < 8) atomicAdd(&sum[c], t);
+            else       atomicAdd(&sumsq[c], t);
+        }
     }
 }
 
@@ -264,17 +268,17 @@ __global__ void unpack_conv_dw_kernel(const float* __restrict__ dWp, float* __re
 
 extern "C" int audiossl_colstats(int dtype, const void* x, long M, int C, long ld, int want_sq, double* sum, double* sumsq,
                                  void* stream) {
-    ASSL_REQUIRE(x && sum && M > 0 && C > 0 && (C % 8) == 0 && C / 8 <= 256 && 256 % (C / 8) == 0 && (ld % 8) == 0);
+    ASSL_REQUIRE(x && sum && M > 0 && C > 0 && (C % 64) == 0 && (ld % 8) == 0);
     ASSL_REQUIRE((dtype == 0 || dtype == 1) && (!want_sq || sumsq));
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (hipMemsetAsync(sum, 0, sizeof(double) * C, s) != hipSuccess) return ASSL_ELAUNCH;
     if (want_sq && hipMemsetAsync(sumsq, 0, sizeof(double) * C, s) != hipSuccess) return ASSL_ELAUNCH;
-    const int RPI = 256 / (C / 8);
-    long it = (M + (long)RPI * 1024 - 1) / ((long)RPI * 1024);      // aim for ~1024 blocks, 1..128 row-iterations each
+    const int slabs = C / 64;
+    long it = (M * slabs + 32L * 2048 - 1) / (32L * 2048);          // aim for ~2048 blocks in total, 1..128 iterations each
     it = it < 1 ? 1 : (it > 128 ? 128 : it);
-    const int rpb = RPI * (int)it;
-    const int grid = ceil_div(M, rpb);
-#define CS(TT, SQ) hipLaunchKernelGGL((colstats_kernel<TT, SQ>), dim3(grid), dim3(256), 0, s, static_cast<const TT*>(x), M, C, ld, rpb, sum, sumsq)
+    const int rpb = 32 * (int)it;
+    const dim3 grid(ceil_div(M, rpb), slabs);
+#define CS(TT, SQ) hipLaunchKernelGGL((colstats_kernel<TT, SQ>), grid, dim3(256), 0, s, static_cast<const TT*>(x), M, C, ld, rpb, sum, sumsq)
     if (dtype == 0) { if (want_sq) CS(float, true); else CS(float, false); }
     else            { if (want_sq) CS(bf16, true);  else CS(bf16, false); }
 #undef CS

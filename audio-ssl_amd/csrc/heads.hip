@@ -80,6 +80,7 @@ __global__ __launch_bounds__(256) void colbn_fwd_kernel(const T_* __restrict__ a
 }
 
 // stats: sg[c] = sum_b g, sgx[c] = sum_b g*xhat with g = dh * (act > 0 if relu), xhat = (a-mean)*rstd   (fp64 atomics)
+// Same slab mapping as colstats: a block = 64 columns x 32 rows per iteration, blockIdx.y = slab.
 template <typename T_>
 __global__ __launch_bounds__(256) void colbn_bwd_stats_kernel(const T_* __restrict__ a, const T_* __restrict__ dh,
                                                               const float* __restrict__ scale, const float* __restrict__ shift,
@@ -87,33 +88,35 @@ __global__ __launch_bounds__(256) void colbn_bwd_stats_kernel(const T_* __restri
                                                               int relu, long M, int C, int rows_per_block,
                                                               double* __restrict__ sg, double* __restrict__ sgx) {
     __shared__ float red[256][17];
-    const int G = C / 8 > 256 ? 256 : C / 8, RPI = 256 / G;
-    const int cg = threadIdx.x % G + blockIdx.y * 256, r0 = threadIdx.x / G;
+    const int cg = threadIdx.x & 7, r0 = threadIdx.x >> 3;
+    const int col0 = blockIdx.y * 64 + cg * 8;
     const long rb = (long)blockIdx.x * rows_per_block, re = min(M, rb + rows_per_block);
-    float s[8], q[8];
+    float s[8], q[8], sc[8], sh[8], mu[8], rs[8];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) { s[i] = 0.f; q[i] = 0.f; }
-    for (long r = rb + r0; r < re; r += RPI) {
-        const Vec8<T_> va = Vec8<T_>::load(a + r * C + cg * 8);
-        const Vec8<T_> vg = Vec8<T_>::load(dh + r * C + cg * 8);
+    for (int i = 0; i < 8; ++i) {
+        s[i] = 0.f; q[i] = 0.f;
+        sc[i] = scale[col0 + i]; sh[i] = shift[col0 + i]; mu[i] = mean[col0 + i]; rs[i] = rstd[col0 + i];
+    }
+    for (long r = rb + r0; r < re; r += 32) {
+        const Vec8<T_> va = Vec8<T_>::load(a + r * C + col0);
+        const Vec8<T_> vg = Vec8<T_>::load(dh + r * C + col0);
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
-            const int c = cg * 8 + i;
             const float x = va.get(i);
             float g = vg.get(i);
-            if (relu && !(scale[c] * x + shift[c] > 0.f)) g = 0.f;
+            if (relu && !(sc[i] * x + sh[i] > 0.f)) g = 0.f;
             s[i] += g;
-            q[i] += g * (x - mean[c]) * rstd[c];
+            q[i] += g * (x - mu[i]) * rs[i];
         }
     }
 #pragma unroll
     for (int i = 0; i < 8; ++i) { red[threadIdx.x][i] = s[i]; red[threadIdx.x][8 + i] = q[i]; }
     __syncthreads();
-    for (int o = threadIdx.x; o < G * 16; o += 256) {
-        const int g = o / 16, k = o % 16;
+    if (threadIdx.x < 128) {
+        const int g = threadIdx.x >> 4, k = threadIdx.x & 15;
         double t = 0.0;
-        for (int r = 0; r < RPI; ++r) t += (double)red[r * G + g][k];
-        const int c = (g + blockIdx.y * 256) * 8 + (k & 7);
+        for (int r = 0; r < 32; ++r) t += (double)red[r * 8 + g][k];
+        const int c = blockIdx.y * 64 + g * 8 + (k & 7);
         if (k < 8) atomicAdd(&sg[c], t); else atomicAdd(&sgx[c], t);
     }
 }
@@ -359,12 +362,11 @@ extern "C" int audiossl_colbn_bwd(int dtype, const void* a, const void* dh, cons
                                   const float* mean, const float* rstd, int relu, long M, int C, double* tmp, void* da,
                                   float* dgamma, float* dbeta, void* stream) {
     ASSL_REQUIRE(a && dh && scale && shift && mean && rstd && tmp && da && M > 0 && C > 0 && (C % 8) == 0);
-    ASSL_REQUIRE((dtype == 0 || dtype == 1) && ((C / 8 <= 256 && 256 % (C / 8) == 0) || C % 2048 == 0));
+    ASSL_REQUIRE((dtype == 0 || dtype == 1) && (C % 64) == 0);
     hipStream_t s = S_(stream);
     if (hipMemsetAsync(tmp, 0, sizeof(double) * 2 * C, s) != hipSuccess) return ASSL_ELAUNCH;
-    const int G = C / 8 > 256 ? 256 : C / 8, RPI = 256 / G;
-    const int rpb = RPI * 32;
-    dim3 grid(ceil_div(M, rpb), C / 8 > 256 ? C / 2048 : 1);
+    const int rpb = M >= 4096 ? 256 : 64;
+    dim3 grid(ceil_div(M, rpb), C / 64);
     const long total = M * C / 8;
 #define CB(TT) do {                                                                                                                  \
     hipLaunchKernelGGL(colbn_bwd_stats_kernel<TT>, grid, dim3(256), 0, s, (const TT*)a, (const TT*)dh, scale, shift, mean, rstd, relu, \

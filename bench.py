@@ -49,7 +49,12 @@ def synth_waves(B, L, seed):
 def cpu_baseline(B, steps, queue):
     """The CPU oracle (port of the reference path) timed on this host: log-mel + aug + delores_m step."""
     from oracle import augment as OA, frontend as FE, model as OM
-    torch.set_num_threads(os.cpu_count() or 1)
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    cores = max(1, min(cores, 16))                 # a 1-GPU box owns a 16-core share of the host
+    torch.set_num_threads(cores)
     cfg = copy.deepcopy(CFG)
     np.random.seed(31)
     random.seed(31)
@@ -74,10 +79,18 @@ def cpu_baseline(B, steps, queue):
         loss.backward()
         OM.sgd_momentum_step(params, bufs, 0.03, 0.9, 1e-4)
         return float(loss)
+    tw = time.perf_counter()
     step()
+    print(f"[bench] cpu_baseline warm-up step: {time.perf_counter() - tw:.1f} s on {cores} threads", file=sys.stderr, flush=True)
     t0 = time.perf_counter()
+    done = 0
     for _ in range(steps):
         step()
+        done += 1
+        print(f"[bench] cpu_baseline step {done}: {time.perf_counter() - t0:.1f} s", file=sys.stderr, flush=True)
+        if time.perf_counter() - t0 > 25.0:
+            break
+    steps = done
     dt = time.perf_counter() - t0
     return {"value": B * steps / dt, "unit": "clips/s", "cores": torch.get_num_threads(), "kind": "port",
             "sample": f"{steps} steps of batch {B} (log-mel + two views + delores_m fwd/bwd/SGD, queue {queue}), fp32, torch-CPU oracle"}
@@ -151,7 +164,9 @@ def main():
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     prof, N.PROFILE = N.PROFILE, None
-    final_loss = float(loss)
+    final_loss = float(loss.detach())
+    if rank == 0:
+        print(f"[bench] gpu: {B * world * args.steps / dt:.1f} clips/s, {dt / args.steps * 1e3:.2f} ms/step", file=sys.stderr, flush=True)
     if world > 1:
         tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)

@@ -1,0 +1,97 @@
+"""CPU: host-side logic of the product (tables, planner-driven window crops, module / state_dict compatibility)."""
+import copy
+import os
+import random
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import CFG_M, CFG_S
+from oracle import frontend as FE
+
+
+def test_filterbank_tables_equal_oracle():
+    from src.utils.utils import pack_filterbank, slaney_mel_filterbank
+    fb = slaney_mel_filterbank(16000, 1024, 64, 60, 7800)
+    assert np.array_equal(fb, FE.mel_filterbank())
+    st, pk = pack_filterbank(fb)
+    assert pk.shape == (64, 45) and int((pk != 0).sum()) == 966
+    for m in range(64):
+        assert np.array_equal(fb[m, st[m]:st[m] + 45][pk[m] != 0], pk[m][pk[m] != 0])
+
+
+def test_extract_window_matches_reference_golden(golden):
+    from src.utils import extract_window
+    for seed, n, first, nz0, last, after in golden("window")["rows"]:
+        random.seed(int(seed))
+        out = extract_window(torch.arange(int(n), dtype=torch.float32), data_size=1.0)
+        assert len(out) == 16000 and float(out[0]) == first and float(out[-1]) == last
+        assert random.random() == after
+
+
+def test_state_dict_keys_match_reference_layout(cfg_s, cfg_m):
+    from src.encoder import AudioNTT2020Task6
+    from src.upstream.delores_m.upstream_expert import Upstream_Expert as M
+    from src.upstream.delores_s.upstream_expert import Upstream_Expert as S
+    from oracle import model as OM
+    s = S(cfg_s, base_encoder=AudioNTT2020Task6)
+    m = M(cfg_m, base_encoder=AudioNTT2020Task6, num_negatives=256)
+    # the oracle modules are restated from the reference's constructors and pinned by its goldens
+    assert list(s.state_dict()) == list(OM.DeloresSExpert(cfg_s).state_dict())
+    assert [(k, tuple(v.shape)) for k, v in m.state_dict().items()] == \
+        [(k, tuple(v.shape)) for k, v in OM.DeloresMExpert(cfg_m, num_negatives=256).state_dict().items()]
+    assert sum(p.numel() for p in s.parameters()) == 17912960
+    assert repr(s.encoder.encoder) == "AudioNTT2020Task6" and s.encoder_q is s.encoder
+    with pytest.raises(AssertionError):
+        from src.augmentations import RandomResizeCrop
+        RandomResizeCrop(time_scale=(0.6, 0.9))
+
+
+def test_flat_group_keeps_views_and_state_dict(cfg_s):
+    from src.encoder import AudioNTT2020Task6
+    from src.flat import FlatGroup
+    from src.upstream.delores_s.upstream_expert import Upstream_Expert as S
+    s = S(cfg_s, base_encoder=AudioNTT2020Task6)
+    before = {k: v.clone() for k, v in s.state_dict().items()}
+    fg = FlatGroup(s.trainable_named())
+    assert all(torch.equal(before[k], v) for k, v in s.state_dict().items())
+    fg.data.mul_(2.0)
+    assert torch.equal(s.state_dict()["p.projector.0.weight"], before["p.projector.0.weight"] * 2)
+    s.load_state_dict(before)                       # copies into the views
+    assert torch.equal(fg.data[:64 * 9].view(64, 1, 3, 3), before["encoder.encoder.features_1.0.weight"])
+    assert all(o % 64 == 0 for o in fg.offsets)
+
+
+def test_window_collate_consumes_python_stream_like_reference(cfg_s, tmp_path):
+    """Crops + augmentation plan made at collate time == the reference's per-clip sequence of draws."""
+    from src.augmentations import AugmentationModule
+    from src.dataset.upstream_dataset import WindowCollate
+    waves = [torch.arange(n, dtype=torch.float32) for n in (100, 16000, 20000, 48000, 16001)]
+    np.random.seed(4); random.seed(4)
+    tf = AugmentationModule(cfg_s, 10, max_batch=8)
+    out, plan = WindowCollate(tf, 16000, 64)(waves)
+    np.random.seed(4); random.seed(4)
+    tf2 = AugmentationModule(cfg_s, 10, max_batch=8)
+    tf2._ensure_ring(5)
+    want = []
+    ips = []
+    for w in waves:                                                   # reference order: window, then both views
+        want.append(FE.extract_window(w, data_size=1.0))
+        ip, fp, _, _ = tf2.plan_py(1, 64, 101)
+        ips.append(ip)
+    assert torch.equal(out, torch.stack(want))
+    assert np.array_equal(plan[0], np.concatenate(ips))
+    assert tf.n_entries == tf2.n_entries == 10
+
+
+def test_train_upstream_cli_and_config(tmp_path):
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("train_upstream_hip", os.path.join(root, "audio-ssl_amd", "train_upstream.py"))
+    tu = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(tu)
+    args = tu.get_args(["--input", "x.csv", "--upstream", "delores_s"])
+    cfg = tu.load_config(args)
+    assert cfg["pretrain"]["base_encoder"]["type"] == "AudioNTT2020Task6" and isinstance(cfg["pretrain"]["lambda_barlow"], float)
+    assert tu.load_config(tu.get_args(["--input", "x.csv"]))["pretrain"]["loss_scale"] == "1/32"
