@@ -27,31 +27,43 @@ __global__ __launch_bounds__(256) void clip_moments_kernel(const float* __restri
     if (threadIdx.x == 0) { mom[2 * blockIdx.x] = s; mom[2 * blockIdx.x + 1] = q; }
 }
 
+// (the moments are staged in LDS first: the scan itself is one thread, ~20 cycles per clip)
 // state_i = {n_seen, max_update}; state_f = {mu, s2}.  Reference recurrence (augmentations.py:222-227):
 // first sample sets, later samples do  v += (new - v) / n  with n the count BEFORE the increment.
 __global__ void runnorm_scan_kernel(const double* __restrict__ mom, int B, int n_elem, long long* state_i,
                                     float* state_f, float* __restrict__ mu_out, float* __restrict__ sd_out) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    long long n = state_i[0];
-    const long long max_update = state_i[1];
-    float mu = state_f[0], s2 = state_f[1];
-    const double inv = 1.0 / (double)n_elem;
-    for (int c = 0; c < B; ++c) {
-        if (n < max_update) {
-            const double ex = mom[2 * c] * inv, ex2 = mom[2 * c + 1] * inv;
-            const float m = (float)ex;
-            mu = (n == 0) ? m : mu + (m - mu) / (float)n;
-            const double mud = (double)mu;
-            const float v = (float)(ex2 - 2.0 * mud * ex + mud * mud);
-            s2 = (n == 0) ? v : s2 + (v - s2) / (float)n;
-            ++n;
+    extern __shared__ __attribute__((aligned(16))) double sm[];           // [2B] moments in, (mu, sd) float pairs out
+    for (int i = threadIdx.x; i < 2 * B; i += blockDim.x) sm[i] = mom[i];
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        long long n = state_i[0];
+        const long long max_update = state_i[1];
+        float mu = state_f[0], s2 = state_f[1];
+        const double inv = 1.0 / (double)n_elem;
+        for (int c = 0; c < B; ++c) {
+            if (n < max_update) {
+                const double ex = sm[2 * c] * inv, ex2 = sm[2 * c + 1] * inv;
+                const float m = (float)ex;
+                mu = (n == 0) ? m : mu + (m - mu) / (float)n;
+                const double mud = (double)mu;
+                const float v = (float)(ex2 - 2.0 * mud * ex + mud * mud);
+                s2 = (n == 0) ? v : s2 + (v - s2) / (float)n;
+                ++n;
+            }
+            float* o = reinterpret_cast<float*>(&sm[2 * c]);
+            o[0] = mu;
+            o[1] = fminf(fmaxf(sqrtf(s2), F32_EPS), F32_MAX);
         }
-        mu_out[c] = mu;
-        sd_out[c] = fminf(fmaxf(sqrtf(s2), F32_EPS), F32_MAX);
+        state_i[0] = n;
+        state_f[0] = mu;
+        state_f[1] = s2;
     }
-    state_i[0] = n;
-    state_f[0] = mu;
-    state_f[1] = s2;
+    __syncthreads();
+    for (int c = threadIdx.x; c < B; c += blockDim.x) {
+        const float* o = reinterpret_cast<const float*>(&sm[2 * c]);
+        mu_out[c] = o[0];
+        sd_out[c] = o[1];
+    }
 }
 
 __global__ __launch_bounds__(256) void aug_normalize_kernel(const float* __restrict__ x, const float* __restrict__ mu,
@@ -183,8 +195,8 @@ extern "C" int audiossl_clip_moments(const float* x, double* mom, int B, int n, 
 
 extern "C" int audiossl_runnorm_scan(const double* mom, int B, int n_elem, long long* state_i, float* state_f,
                                      float* mu_out, float* sd_out, void* stream) {
-    ASSL_REQUIRE(mom && state_i && state_f && mu_out && sd_out && B > 0 && n_elem > 0);
-    hipLaunchKernelGGL(runnorm_scan_kernel, dim3(1), dim3(64), 0, static_cast<hipStream_t>(stream), mom, B, n_elem,
+    ASSL_REQUIRE(mom && state_i && state_f && mu_out && sd_out && B > 0 && B <= 3840 && n_elem > 0);
+    hipLaunchKernelGGL(runnorm_scan_kernel, dim3(1), dim3(256), sizeof(double) * 2 * B, static_cast<hipStream_t>(stream), mom, B, n_elem,
                        state_i, state_f, mu_out, sd_out);
     ASSL_LAUNCH_CHECK();
 }

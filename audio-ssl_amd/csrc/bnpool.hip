@@ -10,7 +10,7 @@ namespace {
 // ---------------------------------------------------------------------------------- column statistics
 // x [M][C] row-major (ld).  sum/sumsq [C] in fp64 (atomics, caller zeroes).  C % 64 == 0.
 // A block owns a slab of 64 columns (8 lanes x 8 elements = one 128-byte line per row) and 32 rows per iteration;
-// blockIdx.y picks the slab, blockIdx.x a chunk of rows.
+// blockIdx.y picks the slab, blockIdx.x a chunk of rows, blockIdx.z the group (x is [G][M][C], outputs [G][C]).
 template <typename T_, bool SQ>
 __global__ __launch_bounds__(256) void colstats_kernel(const T_* __restrict__ x, long M, int C, long ld, int rows_per_block,
                                                        double* __restrict__ sum, double* __restrict__ sumsq) {
@@ -19,6 +19,9 @@ __global__ __launch_bounds__(256) void colstats_kernel(const T_* __restrict__ x,
     const int col0 = blockIdx.y * 64 + cg * 8;
     const long row_begin = (long)blockIdx.x * rows_per_block;
     const long row_end = min(M, row_begin + rows_per_block);
+    x += (long)blockIdx.z * M * ld;
+    sum += (long)blockIdx.z * C;
+    if (SQ) sumsq += (long)blockIdx.z * C;
     float s[8], q[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) { s[i] = 0.f; q[i] = 0.f; }
@@ -43,26 +46,31 @@ __global__ __launch_bounds__(256) void colstats_kernel(const T_* __restrict__ x,
 }
 
 // gamma/beta may be null (affine=False).  running_* may be null.
-__global__ void bn_finalize_kernel(const double* __restrict__ sum, const double* __restrict__ sumsq, double count, int C,
-                                   const float* __restrict__ gamma, const float* __restrict__ beta, float* running_mean,
+// Groups are independent batches normalised by the SAME layer (e.g. the two views of the projector): outputs are
+// [G][C]; the running statistics are updated group after group, like the reference's successive module calls.
+__global__ void bn_finalize_kernel(const double* __restrict__ sum, const double* __restrict__ sumsq, int groups, double count,
+                                   int C, const float* __restrict__ gamma, const float* __restrict__ beta, float* running_mean,
                                    float* running_var, float momentum, float eps, float* scale, float* shift,
                                    float* save_mean, float* save_rstd) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= C) return;
-    const double mean = sum[c] / count;
-    double var = sumsq[c] / count - mean * mean;
-    var = var < 0.0 ? 0.0 : var;
-    const double rstd = 1.0 / sqrt(var + (double)eps);
     const double g = gamma ? (double)gamma[c] : 1.0, b = beta ? (double)beta[c] : 0.0;
-    scale[c] = (float)(g * rstd);
-    shift[c] = (float)(b - mean * g * rstd);
-    save_mean[c] = (float)mean;
-    save_rstd[c] = (float)rstd;
-    if (running_mean) {
-        running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mean;
+    float rm = running_mean ? running_mean[c] : 0.f, rv = running_mean ? running_var[c] : 0.f;
+    for (int k = 0; k < groups; ++k) {
+        const int o = k * C + c;
+        const double mean = sum[o] / count;
+        double var = sumsq[o] / count - mean * mean;
+        var = var < 0.0 ? 0.0 : var;
+        const double rstd = 1.0 / sqrt(var + (double)eps);
+        scale[o] = (float)(g * rstd);
+        shift[o] = (float)(b - mean * g * rstd);
+        save_mean[o] = (float)mean;
+        save_rstd[o] = (float)rstd;
+        rm = (1.f - momentum) * rm + momentum * (float)mean;
         const double unb = count > 1.0 ? var * count / (count - 1.0) : var;
-        running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unb;
+        rv = (1.f - momentum) * rv + momentum * (float)unb;
     }
+    if (running_mean) { running_mean[c] = rm; running_var[c] = rv; }
 }
 
 // ------------------------------------------------------------------------------- BN + ReLU + MaxPool2
@@ -266,18 +274,18 @@ __global__ void unpack_conv_dw_kernel(const float* __restrict__ dWp, float* __re
 
 #define DISPATCH_T(dtype, CALL_F32, CALL_BF16) do { if ((dtype) == 0) { CALL_F32; } else { CALL_BF16; } } while (0)
 
-extern "C" int audiossl_colstats(int dtype, const void* x, long M, int C, long ld, int want_sq, double* sum, double* sumsq,
-                                 void* stream) {
-    ASSL_REQUIRE(x && sum && M > 0 && C > 0 && (C % 64) == 0 && (ld % 8) == 0);
+extern "C" int audiossl_colstats(int dtype, const void* x, int groups, long M, int C, long ld, int want_sq, double* sum,
+                                 double* sumsq, void* stream) {
+    ASSL_REQUIRE(x && sum && groups > 0 && M > 0 && C > 0 && (C % 64) == 0 && (ld % 8) == 0);
     ASSL_REQUIRE((dtype == 0 || dtype == 1) && (!want_sq || sumsq));
     hipStream_t s = static_cast<hipStream_t>(stream);
-    if (hipMemsetAsync(sum, 0, sizeof(double) * C, s) != hipSuccess) return ASSL_ELAUNCH;
-    if (want_sq && hipMemsetAsync(sumsq, 0, sizeof(double) * C, s) != hipSuccess) return ASSL_ELAUNCH;
+    if (hipMemsetAsync(sum, 0, sizeof(double) * C * groups, s) != hipSuccess) return ASSL_ELAUNCH;
+    if (want_sq && hipMemsetAsync(sumsq, 0, sizeof(double) * C * groups, s) != hipSuccess) return ASSL_ELAUNCH;
     const int slabs = C / 64;
-    long it = (M * slabs + 32L * 2048 - 1) / (32L * 2048);          // aim for ~2048 blocks in total, 1..128 iterations each
+    long it = (M * slabs * groups + 32L * 2048 - 1) / (32L * 2048);  // aim for ~2048 blocks in total, 1..128 iterations each
     it = it < 1 ? 1 : (it > 128 ? 128 : it);
     const int rpb = 32 * (int)it;
-    const dim3 grid(ceil_div(M, rpb), slabs);
+    const dim3 grid(ceil_div(M, rpb), slabs, groups);
 #define CS(TT, SQ) hipLaunchKernelGGL((colstats_kernel<TT, SQ>), grid, dim3(256), 0, s, static_cast<const TT*>(x), M, C, ld, rpb, sum, sumsq)
     if (dtype == 0) { if (want_sq) CS(float, true); else CS(float, false); }
     else            { if (want_sq) CS(bf16, true);  else CS(bf16, false); }
@@ -285,12 +293,13 @@ extern "C" int audiossl_colstats(int dtype, const void* x, long M, int C, long l
     ASSL_LAUNCH_CHECK();
 }
 
-extern "C" int audiossl_bn_finalize(const double* sum, const double* sumsq, double count, int C, const float* gamma,
-                                    const float* beta, float* running_mean, float* running_var, float momentum, float eps,
-                                    float* scale, float* shift, float* save_mean, float* save_rstd, void* stream) {
-    ASSL_REQUIRE(sum && sumsq && scale && shift && save_mean && save_rstd && C > 0 && count > 0);
+extern "C" int audiossl_bn_finalize(const double* sum, const double* sumsq, int groups, double count, int C,
+                                    const float* gamma, const float* beta, float* running_mean, float* running_var,
+                                    float momentum, float eps, float* scale, float* shift, float* save_mean, float* save_rstd,
+                                    void* stream) {
+    ASSL_REQUIRE(sum && sumsq && scale && shift && save_mean && save_rstd && C > 0 && count > 0 && groups > 0);
     hipLaunchKernelGGL(bn_finalize_kernel, dim3(ceil_div(C, 256)), dim3(256), 0, static_cast<hipStream_t>(stream), sum, sumsq,
-                       count, C, gamma, beta, running_mean, running_var, momentum, eps, scale, shift, save_mean, save_rstd);
+                       groups, count, C, gamma, beta, running_mean, running_var, momentum, eps, scale, shift, save_mean, save_rstd);
     ASSL_LAUNCH_CHECK();
 }
 

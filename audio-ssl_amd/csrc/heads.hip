@@ -61,14 +61,18 @@ __global__ __launch_bounds__(256) void maxmean_bwd_kernel(const T_* __restrict__
 }
 
 // --------------------------------------------------------------------------------------------- BatchNorm1d pieces
-// h = act(scale*a + shift), elementwise over [M][C]
+// h = act(scale_g*a + shift_g), elementwise over [G][M][C] with per-group [G][C] scale / shift
 template <typename T_>
 __global__ __launch_bounds__(256) void colbn_fwd_kernel(const T_* __restrict__ a, const float* __restrict__ scale,
-                                                        const float* __restrict__ shift, int relu, T_* __restrict__ h, long M, int C) {
+                                                        const float* __restrict__ shift, int relu, T_* __restrict__ h, long M, int C,
+                                                        int groups) {
     const long idx = (long)blockIdx.x * 256 + threadIdx.x;
     const int C8 = C / 8;
-    if (idx >= M * C8) return;
+    if (idx >= (long)groups * M * C8) return;
     const int c8 = (int)(idx % C8);
+    const int grp = (int)(idx / (M * C8));
+    scale += (long)grp * C;
+    shift += (long)grp * C;
     const Vec8<T_> v = Vec8<T_>::load(a + idx * 8);
     Vec8<T_> o;
 #pragma unroll
@@ -91,6 +95,10 @@ __global__ __launch_bounds__(256) void colbn_bwd_stats_kernel(const T_* __restri
     const int cg = threadIdx.x & 7, r0 = threadIdx.x >> 3;
     const int col0 = blockIdx.y * 64 + cg * 8;
     const long rb = (long)blockIdx.x * rows_per_block, re = min(M, rb + rows_per_block);
+    {   // group offsets: activations [G][M][C], statistics [G][C]
+        const long go = (long)blockIdx.z * C, ro = (long)blockIdx.z * M * C;
+        a += ro; dh += ro; scale += go; shift += go; mean += go; rstd += go; sg += go; sgx += go;
+    }
     float s[8], q[8], sc[8], sh[8], mu[8], rs[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
@@ -126,14 +134,20 @@ template <typename T_>
 __global__ __launch_bounds__(256) void colbn_bwd_apply_kernel(const T_* __restrict__ a, const T_* __restrict__ dh,
                                                               const float* __restrict__ scale, const float* __restrict__ shift,
                                                               const float* __restrict__ mean, const float* __restrict__ rstd,
-                                                              int relu, long M, int C, const double* __restrict__ sg,
+                                                              int relu, long M, int C, int groups, const double* __restrict__ sg,
                                                               const double* __restrict__ sgx, T_* __restrict__ da,
                                                               float* dgamma, float* dbeta) {
     const long idx = (long)blockIdx.x * 256 + threadIdx.x;
     const int C8 = C / 8;
-    if (idx >= M * C8) return;
+    if (idx >= (long)groups * M * C8) return;
     const int c8 = (int)(idx % C8);
-    const long row = idx / C8;
+    const long grow = idx / C8;
+    const int grp = (int)(grow / M);
+    const long row = grow - (long)grp * M;
+    {
+        const long go = (long)grp * C;
+        scale += go; shift += go; mean += go; rstd += go; sg += go; sgx += go;
+    }
     const Vec8<T_> va = Vec8<T_>::load(a + idx * 8);
     const Vec8<T_> vg = Vec8<T_>::load(dh + idx * 8);
     Vec8<T_> o;
@@ -147,7 +161,7 @@ __global__ __launch_bounds__(256) void colbn_bwd_apply_kernel(const T_* __restri
         const float xhat = (x - mean[c]) * rstd[c];
         const float mg = (float)sg[c] * invM, mgx = (float)sgx[c] * invM;
         o.set(i, scale[c] * (g - mg - xhat * mgx));
-        if (row == 0 && dgamma) { dgamma[c] += (float)sgx[c]; dbeta[c] += (float)sg[c]; }
+        if (row == 0 && dgamma) { atomicAdd(&dgamma[c], (float)sgx[c]); atomicAdd(&dbeta[c], (float)sg[c]); }
     }
     o.store(da + idx * 8);
 }
@@ -348,31 +362,32 @@ extern "C" int audiossl_maxmean_bwd(int dtype, const void* dy, const uint8_t* ar
     ASSL_LAUNCH_CHECK();
 }
 
-extern "C" int audiossl_colbn_fwd(int dtype, const void* a, const float* scale, const float* shift, int relu, void* h, long M,
-                                  int C, void* stream) {
-    ASSL_REQUIRE(a && scale && shift && h && M > 0 && C > 0 && (C % 8) == 0 && (dtype == 0 || dtype == 1));
-    const long total = M * C / 8;
-    if (dtype == 0) hipLaunchKernelGGL(colbn_fwd_kernel<float>, GRID1(total), dim3(256), 0, S_(stream), (const float*)a, scale, shift, relu, (float*)h, M, C);
-    else            hipLaunchKernelGGL(colbn_fwd_kernel<bf16>, GRID1(total), dim3(256), 0, S_(stream), (const bf16*)a, scale, shift, relu, (bf16*)h, M, C);
+extern "C" int audiossl_colbn_fwd(int dtype, const void* a, const float* scale, const float* shift, int relu, void* h, int groups,
+                                  long M, int C, void* stream) {
+    ASSL_REQUIRE(a && scale && shift && h && groups > 0 && M > 0 && C > 0 && (C % 8) == 0 && (dtype == 0 || dtype == 1));
+    const long total = groups * M * C / 8;
+    if (dtype == 0) hipLaunchKernelGGL(colbn_fwd_kernel<float>, GRID1(total), dim3(256), 0, S_(stream), (const float*)a, scale, shift, relu, (float*)h, M, C, groups);
+    else            hipLaunchKernelGGL(colbn_fwd_kernel<bf16>, GRID1(total), dim3(256), 0, S_(stream), (const bf16*)a, scale, shift, relu, (bf16*)h, M, C, groups);
     ASSL_LAUNCH_CHECK();
 }
 
 // tmp: 2*C doubles of scratch.  dgamma/dbeta may be null (affine=False); otherwise accumulated (+=).
 extern "C" int audiossl_colbn_bwd(int dtype, const void* a, const void* dh, const float* scale, const float* shift,
-                                  const float* mean, const float* rstd, int relu, long M, int C, double* tmp, void* da,
-                                  float* dgamma, float* dbeta, void* stream) {
-    ASSL_REQUIRE(a && dh && scale && shift && mean && rstd && tmp && da && M > 0 && C > 0 && (C % 8) == 0);
+                                  const float* mean, const float* rstd, int relu, int groups, long M, int C, double* tmp,
+                                  void* da, float* dgamma, float* dbeta, void* stream) {
+    ASSL_REQUIRE(a && dh && scale && shift && mean && rstd && tmp && da && groups > 0 && M > 0 && C > 0 && (C % 8) == 0);
     ASSL_REQUIRE((dtype == 0 || dtype == 1) && (C % 64) == 0);
     hipStream_t s = S_(stream);
-    if (hipMemsetAsync(tmp, 0, sizeof(double) * 2 * C, s) != hipSuccess) return ASSL_ELAUNCH;
+    if (hipMemsetAsync(tmp, 0, sizeof(double) * 2 * C * groups, s) != hipSuccess) return ASSL_ELAUNCH;
     const int rpb = M >= 4096 ? 256 : 64;
-    dim3 grid(ceil_div(M, rpb), C / 64);
-    const long total = M * C / 8;
+    dim3 grid(ceil_div(M, rpb), C / 64, groups);
+    const long total = groups * M * C / 8;
+    const long GC = (long)groups * C;
 #define CB(TT) do {                                                                                                                  \
     hipLaunchKernelGGL(colbn_bwd_stats_kernel<TT>, grid, dim3(256), 0, s, (const TT*)a, (const TT*)dh, scale, shift, mean, rstd, relu, \
-                       M, C, rpb, tmp, tmp + C);                                                                                      \
+                       M, C, rpb, tmp, tmp + GC);                                                                                     \
     hipLaunchKernelGGL(colbn_bwd_apply_kernel<TT>, GRID1(total), dim3(256), 0, s, (const TT*)a, (const TT*)dh, scale, shift, mean,     \
-                       rstd, relu, M, C, tmp, tmp + C, (TT*)da, dgamma, dbeta); } while (0)
+                       rstd, relu, M, C, groups, tmp, tmp + GC, (TT*)da, dgamma, dbeta); } while (0)
     if (dtype == 0) CB(float); else CB(bf16);
 #undef CB
     ASSL_LAUNCH_CHECK();

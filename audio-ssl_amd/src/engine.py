@@ -60,7 +60,7 @@ def linear_bwd_x(dtype, dY, W, M, Nout, K, alpha=1.0, gate=None, out=None):
 def colsum_add(dtype, X, M, C, dst, tmp=None):
     """dst[C] += column sums of X [M,C]"""
     tmp = tmp if tmp is not None else _empty((C,), torch.float64, like=X)
-    N.call("colstats", dtype, X, M, C, C, 0, tmp, None)
+    N.call("colstats", dtype, X, 1, M, C, C, 0, tmp, None)
     N.call("add_d2f", tmp, dst, C)
 
 
@@ -79,14 +79,14 @@ class EncoderCtx:
     pass
 
 
-def _bn_train(dtype, Y, M, C, gamma, beta, rm, rv, update_running):
-    s = _empty((C,), torch.float64, like=Y)
-    q = _empty((C,), torch.float64, like=Y)
-    N.call("colstats", dtype, Y, M, C, C, 1, s, q)
-    scale, shift, mean, rstd = (_empty((C,), torch.float32, like=Y) for _ in range(4))
-    N.call("bn_finalize", s, q, float(M), C, gamma, beta, rm if update_running else None, rv if update_running else None,
-           BN_MOMENTUM, BN_EPS, scale, shift, mean, rstd)
-    return scale, shift, mean, rstd
+def _bn_train(dtype, Y, M, C, gamma, beta, rm, rv, update_running, groups=1):
+    """Batch statistics of Y [groups][M][C] -> per-group (scale, shift, mean, rstd), each [groups*C]."""
+    sq = _empty((2, groups * C), torch.float64, like=Y)
+    N.call("colstats", dtype, Y, groups, M, C, C, 1, sq[0], sq[1])
+    st = _empty((4, groups * C), torch.float32, like=Y)
+    N.call("bn_finalize", sq[0], sq[1], groups, float(M), C, gamma, beta, rm if update_running else None,
+           rv if update_running else None, BN_MOMENTUM, BN_EPS, st[0], st[1], st[2], st[3])
+    return st[0], st[1], st[2], st[3]
 
 
 def _bn_eval(like, C, gamma, beta, rm, rv):
@@ -119,9 +119,12 @@ def _col_buffer(dtype, Nimg, T1, F1, like):
     return _empty((Nimg * T1 * F1, 576), N.torch_dtype(dtype), like=like)
 
 
-def encoder_forward(P, x, dtype, keep=None, p_drop=0.3, train=True, update_running=True, want_layers=True):
+def encoder_forward(P, x, dtype, keep=None, p_drop=0.3, train=True, update_running=True, want_layers=True, Wc=None,
+                    layer_out=None):
     """P: dict of fp32 device tensors with the reference's state_dict keys (features_1.0.weight, ...).
     x [N,1,F,T] fp32.  keep: uint8 [N*T3, d] dropout keep-mask or None (no dropout).
+    Wc: optional {"fc.0.weight", "fc.3.weight"} already in the activation dtype (flat shadow); layer_out: optional
+    (x1, x2, x3) output buffers [N, F*64] (e.g. halves of the stacked projector inputs).
     Returns (x1, x2, x3, H2 [N,T3,d]) in the activation dtype and the ctx for the backward."""
     Nimg, _, F, T = x.shape
     assert F == 64, "the HIP encoder is built for n_mels = 64 (the reference's only setting)"
@@ -158,7 +161,7 @@ def encoder_forward(P, x, dtype, keep=None, p_drop=0.3, train=True, update_runni
     c.dims = (T1, F1, T2, F2, T3, F3)
     x1 = x2 = x3 = None
     if want_layers:
-        x1, x2, x3 = (_empty((Nimg, f * 64), td, like=x) for f in (F1, F2, F3))
+        x1, x2, x3 = layer_out if layer_out is not None else (_empty((Nimg, f * 64), td, like=x) for f in (F1, F2, F3))
         N.call("tmean_fwd", dtype, c.P1, x1, Nimg, T1, F1)
         N.call("tmean_fwd", dtype, c.P2, x2, Nimg, T2, F2)
         N.call("tmean_fwd", dtype, c.P3, x3, Nimg, T3, F3)
@@ -166,7 +169,10 @@ def encoder_forward(P, x, dtype, keep=None, p_drop=0.3, train=True, update_runni
     kin = F3 * 64
     M = Nimg * T3
     c.d, c.kin, c.M = d, kin, M
-    c.fw1, c.fw2 = cast(dtype, P["fc.0.weight"]), cast(dtype, P["fc.3.weight"])
+    if Wc is not None:
+        c.fw1, c.fw2 = Wc["fc.0.weight"], Wc["fc.3.weight"]
+    else:
+        c.fw1, c.fw2 = cast(dtype, P["fc.0.weight"]), cast(dtype, P["fc.3.weight"])
     c.keep = keep if train else None
     scale = 1.0 / (1.0 - p_drop) if c.keep is not None else 1.0
     c.H1 = linear_fwd(dtype, c.P3, c.fw1, M, d, kin, bias=P["fc.0.bias"], relu=1, keep=c.keep, keep_scale=scale)
@@ -231,10 +237,10 @@ def encoder_backward(c, G, dA2=None, dH2=None, dx1=None, dx2=None, dx3=None):
 
 
 # =============================================================================================== max + mean pooling
-def maxmean_forward(dtype, H2):
+def maxmean_forward(dtype, H2, out=None):
     """H2 [N,T3,d] -> y [N,d] = max_T + mean_T, plus the argmax needed by the backward."""
     Nimg, T3, d = H2.shape
-    y = _empty((Nimg, d), N.torch_dtype(dtype), like=H2)
+    y = out if out is not None else _empty((Nimg, d), N.torch_dtype(dtype), like=H2)
     arg = _empty((Nimg, d), torch.uint8, like=H2)
     N.call("maxmean_fwd", dtype, H2, y, arg, Nimg, T3, d)
     return y, arg
@@ -253,87 +259,89 @@ class ProjCtx:
     pass
 
 
-def projector_forward(PP, y, dtype, update_running=True, Wc=None):
-    """Lin-BN-ReLU-Lin-BN-ReLU-Lin then affine-free BN.  PP keys: projector.{0,3,6}.weight, projector.{1,4}.{weight,bias,
-    running_mean,running_var}, bn.{running_mean,running_var}.  y [B,in] activation dtype.  Returns zn [B,D], ctx."""
-    B, kin = y.shape
+def projector_forward(PP, Y, dtype, groups, B, update_running=True, Wc=None):
+    """Lin-BN-ReLU-Lin-BN-ReLU-Lin then affine-free BN on `groups` stacked batches Y [groups*B, in] (the two views share
+    the weights, so they go through each GEMM together; BatchNorm statistics stay per view).
+    PP keys: projector.{0,3,6}.weight, projector.{1,4}.{weight,bias,running_mean,running_var}, bn.{running_*}."""
+    kin = Y.shape[1]
     c = ProjCtx()
-    c.dtype, c.B, c.kin, c.y = dtype, B, kin, y
+    c.dtype, c.B, c.groups, c.kin, c.y = dtype, B, groups, kin, Y
     W = Wc if Wc is not None else tuple(cast(dtype, PP[f"projector.{i}.weight"]) for i in (0, 3, 6))
     c.W = W
     D = W[0].shape[0]
     c.D = D
+    M = groups * B
 
     def bn(a, prefix, affine):
         g = PP[prefix + ".weight"] if affine else None
         b = PP[prefix + ".bias"] if affine else None
-        return _bn_train(dtype, a, B, D, g, b, PP[prefix + ".running_mean"], PP[prefix + ".running_var"], update_running)
+        return _bn_train(dtype, a, B, D, g, b, PP[prefix + ".running_mean"], PP[prefix + ".running_var"], update_running,
+                         groups)
     td = N.torch_dtype(dtype)
-    c.a1 = linear_fwd(dtype, y, W[0], B, D, kin)
+    c.a1 = linear_fwd(dtype, Y, W[0], M, D, kin)
     c.st1 = bn(c.a1, "projector.1", True)
-    c.h1 = _empty((B, D), td, like=y)
-    N.call("colbn_fwd", dtype, c.a1, c.st1[0], c.st1[1], 1, c.h1, B, D)
-    c.a2 = linear_fwd(dtype, c.h1, W[1], B, D, D)
+    c.h1 = _empty((M, D), td, like=Y)
+    N.call("colbn_fwd", dtype, c.a1, c.st1[0], c.st1[1], 1, c.h1, groups, B, D)
+    c.a2 = linear_fwd(dtype, c.h1, W[1], M, D, D)
     c.st2 = bn(c.a2, "projector.4", True)
-    c.h2 = _empty((B, D), td, like=y)
-    N.call("colbn_fwd", dtype, c.a2, c.st2[0], c.st2[1], 1, c.h2, B, D)
-    c.z = linear_fwd(dtype, c.h2, W[2], B, D, D)
+    c.h2 = _empty((M, D), td, like=Y)
+    N.call("colbn_fwd", dtype, c.a2, c.st2[0], c.st2[1], 1, c.h2, groups, B, D)
+    c.z = linear_fwd(dtype, c.h2, W[2], M, D, D)
     c.st0 = bn(c.z, "bn", False)
-    c.zn = _empty((B, D), td, like=y)
-    N.call("colbn_fwd", dtype, c.z, c.st0[0], c.st0[1], 0, c.zn, B, D)
+    c.zn = _empty((M, D), td, like=Y)
+    N.call("colbn_fwd", dtype, c.z, c.st0[0], c.st0[1], 0, c.zn, groups, B, D)
     return c.zn, c
 
 
-def projector_backward(c, PP, G, dzn, need_dy=True):
-    """dzn [B,D] (activation dtype) -> accumulates projector grads into G, returns dy [B,in] (or None)."""
-    dtype, B, D, kin = c.dtype, c.B, c.D, c.kin
+def projector_backward(c, PP, G, dzn, dy_rows=None):
+    """dzn [groups*B, D] (activation dtype) -> accumulates projector grads into G; returns dY for the first `dy_rows`
+    rows of the stacked input (None: all rows, 0: skip)."""
+    dtype, B, D, kin, groups = c.dtype, c.B, c.D, c.kin, c.groups
+    M = groups * B
     td = N.torch_dtype(dtype)
-    tmp = _empty((2 * D,), torch.float64, like=dzn)
-    dz = _empty((B, D), td, like=dzn)
-    N.call("colbn_bwd", dtype, c.z, dzn, *c.st0, 0, B, D, tmp, dz, None, None)
-    linear_bwd_w(dtype, dz, c.h2, G["projector.6.weight"], B, D, D)
-    dh2 = linear_bwd_x(dtype, dz, c.W[2], B, D, D)
-    da2 = _empty((B, D), td, like=dzn)
-    N.call("colbn_bwd", dtype, c.a2, dh2, *c.st2, 1, B, D, tmp, da2, G["projector.4.weight"], G["projector.4.bias"])
-    linear_bwd_w(dtype, da2, c.h1, G["projector.3.weight"], B, D, D)
-    dh1 = linear_bwd_x(dtype, da2, c.W[1], B, D, D)
-    da1 = _empty((B, D), td, like=dzn)
-    N.call("colbn_bwd", dtype, c.a1, dh1, *c.st1, 1, B, D, tmp, da1, G["projector.1.weight"], G["projector.1.bias"])
-    linear_bwd_w(dtype, da1, c.y, G["projector.0.weight"], B, D, kin)
-    if not need_dy:
+    tmp = _empty((2 * groups * D,), torch.float64, like=dzn)
+    dz = _empty((M, D), td, like=dzn)
+    N.call("colbn_bwd", dtype, c.z, dzn, *c.st0, 0, groups, B, D, tmp, dz, None, None)
+    linear_bwd_w(dtype, dz, c.h2, G["projector.6.weight"], M, D, D)
+    dh2 = linear_bwd_x(dtype, dz, c.W[2], M, D, D)
+    da2 = _empty((M, D), td, like=dzn)
+    N.call("colbn_bwd", dtype, c.a2, dh2, *c.st2, 1, groups, B, D, tmp, da2, G["projector.4.weight"], G["projector.4.bias"])
+    linear_bwd_w(dtype, da2, c.h1, G["projector.3.weight"], M, D, D)
+    dh1 = linear_bwd_x(dtype, da2, c.W[1], M, D, D)
+    da1 = _empty((M, D), td, like=dzn)
+    N.call("colbn_bwd", dtype, c.a1, dh1, *c.st1, 1, groups, B, D, tmp, da1, G["projector.1.weight"], G["projector.1.bias"])
+    linear_bwd_w(dtype, da1, c.y, G["projector.0.weight"], M, D, kin)
+    rows = M if dy_rows is None else dy_rows
+    if rows == 0:
         return None
-    return linear_bwd_x(dtype, da1, c.W[0], B, D, kin)
+    return linear_bwd_x(dtype, da1, c.W[0], rows, D, kin)
 
 
-def barlow_forward_backward(PP, G, y1, y2, dtype, lambd, scale_loss, loss_out, need_dy1=True, need_dy2=True,
-                            update_running=True, all_reduce=None, global_batch=None, backward=True):
-    """Projection.forward + its whole backward.  loss_out: fp32 device scalar, accumulated (+=).
-    all_reduce: optional callable summing the [D,D] fp32 correlation over ranks in place (cross-GPU Barlow,
-    `extras/delores-s/models_byol.py:108-112`); the divisor is then `global_batch`.
-    Returns (dy1, dy2) in the activation dtype (None where not requested)."""
-    B = y1.shape[0]
-    W = tuple(cast(dtype, PP[f"projector.{i}.weight"]) for i in (0, 3, 6))
-    zn1, c1 = projector_forward(PP, y1, dtype, update_running, W)
-    zn2, c2 = projector_forward(PP, y2, dtype, update_running, W)
-    D = c1.D
+def barlow_forward_backward(PP, G, Y, dtype, lambd, scale_loss, loss_out, need_dy1=True, need_dy2=True,
+                            update_running=True, all_reduce=None, global_batch=None, backward=True, Wc=None):
+    """Projection.forward + its whole backward on the stacked views Y [2B, in] (rows [0,B) = view 1, [B,2B) = view 2).
+    loss_out: fp32 device scalar, accumulated (+=).  all_reduce: optional callable summing the [D,D] fp32 correlation
+    over ranks in place (cross-GPU Barlow, `extras/delores-s/models_byol.py:108-112`); the divisor is then
+    `global_batch`.  Returns dY [rows, in] in the activation dtype: rows = 2B, B (only view 1) or None."""
+    B = Y.shape[0] // 2
+    zn, c = projector_forward(PP, Y, dtype, 2, B, update_running, Wc)
+    D = c.D
+    zn1, zn2 = zn[:B], zn[B:]
     denom = float(global_batch if global_batch else B)
-    cmat = _empty((D, D), torch.float32, like=y1)
+    cmat = _empty((D, D), torch.float32, like=Y)
     gemm(dtype, 1, 1, D, D, B, zn1, D, zn2, D, cmat, D, alpha=1.0 / denom, out_f32=1)         # c = zn1^T zn2 / B
     if all_reduce is not None:
         all_reduce(cmat)
     coef = (lambd if lambd else 1.0) * scale_loss
-    dc = _empty((D, D), N.torch_dtype(dtype), like=y1)
+    dc = _empty((D, D), N.torch_dtype(dtype), like=Y)
     N.call("barlow_loss", dtype, cmat, D, coef, 2.0 * coef / denom, dc, loss_out)
     if not backward:
-        return None, None
-    td = N.torch_dtype(dtype)
-    dzn1 = _empty((B, D), td, like=y1)
-    dzn2 = _empty((B, D), td, like=y1)
-    gemm(dtype, 0, 0, B, D, D, zn2, D, dc, D, dzn1, D)      # dzn1[b,i] = sum_j zn2[b,j] dc[i,j]
-    gemm(dtype, 0, 1, B, D, D, zn1, D, dc, D, dzn2, D)      # dzn2[b,j] = sum_i zn1[b,i] dc[i,j]
-    dy1 = projector_backward(c1, PP, G, dzn1, need_dy1)
-    dy2 = projector_backward(c2, PP, G, dzn2, need_dy2)
-    return dy1, dy2
+        return None
+    dzn = _empty((2 * B, D), N.torch_dtype(dtype), like=Y)
+    gemm(dtype, 0, 0, B, D, D, zn2, D, dc, D, dzn[:B], D)      # dzn1[b,i] = sum_j zn2[b,j] dc[i,j]
+    gemm(dtype, 0, 1, B, D, D, zn1, D, dc, D, dzn[B:], D)      # dzn2[b,j] = sum_i zn1[b,i] dc[i,j]
+    rows = 2 * B if need_dy2 else (B if need_dy1 else 0)
+    return projector_backward(c, PP, G, dzn, rows)
 
 
 # =============================================================================================== MoCo head

@@ -25,10 +25,30 @@ class FlatGroup:
         self.data = torch.zeros(off, dtype=torch.float32, device=device)
         self.grad = torch.zeros(off, dtype=torch.float32, device=device)
         self.momentum = None
+        self._shadow = None
         for p, o in zip(self.params, self.offsets):
             v = self.data[o:o + p.numel()].view(p.shape)
             v.copy_(p.data)
             p.data = v
+
+    def refresh_shadow(self, dtype):
+        """One cast launch over the whole buffer: bf16 copies of every weight for the MFMA GEMMs of this step."""
+        from src import _native as N
+        if dtype == N.F32:
+            self._shadow = None
+            return
+        if self._shadow is None or self._shadow.device != self.data.device:
+            self._shadow = torch.empty(self.numel, dtype=torch.bfloat16, device=self.data.device)
+        N.call("cast", dtype, self.data, self._shadow, self.numel)
+
+    def shadow_dict(self, prefix=""):
+        """name (prefix stripped) -> weight in the activation dtype (the fp32 parameter itself on the fp32 path)."""
+        src = self.data if self._shadow is None else self._shadow
+        out = {}
+        for n, p, o in zip(self.names, self.params, self.offsets):
+            if n.startswith(prefix):
+                out[n[len(prefix):]] = src[o:o + p.numel()].view(p.shape)
+        return out
 
     def grad_view(self, i):
         p, o = self.params[i], self.offsets[i]

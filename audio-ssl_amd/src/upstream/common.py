@@ -40,10 +40,13 @@ class _ProjectionFn(torch.autograd.Function):
         loss = torch.zeros(1, dtype=torch.float32, device=y1.device)
         G = {n: torch.zeros_like(p, dtype=torch.float32) for n, p in mod.named_parameters()}
         need1, need2 = ctx.needs_input_grad[1], ctx.needs_input_grad[2]
-        dy1, dy2 = E.barlow_forward_backward(mod.param_dict(), G, y1.contiguous(), y2.contiguous(), dt, mod.lambd,
-                                             mod.scale_loss, loss, need_dy1=need1, need_dy2=need2,
-                                             update_running=mod.training, all_reduce=getattr(mod, "all_reduce", None),
-                                             global_batch=getattr(mod, "global_batch", None))
+        B = y1.shape[0]
+        dY = E.barlow_forward_backward(mod.param_dict(), G, torch.cat([y1, y2]).contiguous(), dt, mod.lambd,
+                                       mod.scale_loss, loss, need_dy1=need1 or need2, need_dy2=need2,
+                                       update_running=mod.training, all_reduce=getattr(mod, "all_reduce", None),
+                                       global_batch=getattr(mod, "global_batch", None))
+        dy1 = dY[:B] if (dY is not None and need1) else None
+        dy2 = dY[B:] if (dY is not None and need2) else None
         ctx.saved = (dy1, dy2, [G[n] for n, _ in mod.named_parameters()])
         return loss[0].clone()
 

@@ -16,7 +16,7 @@ from src import engine as E
 from src.encoder.audiontt import default_precision
 from src.flat import FlatGroup
 from src.module_base import UpstreamModule
-from src.upstream.common import FusedExpertMixin, FusedStepFn, Projection
+from src.upstream.common import FusedExpertMixin, FusedStepFn, Projection, strip
 from src.upstream.delores_m.upstream_encoder import DELORES_M as DELORES_M_ENCODER
 from src.utils import concat_all_gather
 
@@ -111,55 +111,79 @@ class Upstream_Expert(FusedExpertMixin, UpstreamModule):
     # ------------------------------------------------------------------ fused step
     def fused_loss(self, img_q, img_k, need_grad=True, parts=None):
         dt = self.precision
+        td = N.torch_dtype(dt)
         flat = self.ensure_flat()
         if need_grad:
             flat.zero_grad()
+        flat.refresh_shadow(dt)
         dev = img_q.device
         B = img_q.shape[0]
         loss = torch.zeros(4, dtype=torch.float32, device=dev)          # [ce, barlow1, barlow2, barlow3]
         eq, ek = self.encoder_q, self.encoder_k
+        Wq = flat.shadow_dict("encoder_q.")
+        # stacked projector inputs: rows [0,B) from the query encoder, [B,2B) from the key encoder
+        Ys = [torch.empty(2 * B, f, dtype=td, device=dev) for f in (2048, 1024, 512)]
         # ---- query encoder
         img_q = img_q.float().contiguous()
         keep = eq.encoder.next_keep_mask(B, img_q.shape[-1])
-        q1, q2, q3, Hq, cq = E.encoder_forward(eq.encoder.param_dict(), img_q, dt, keep=keep, p_drop=0.3, train=self.training)
+        _, _, _, Hq, cq = E.encoder_forward(eq.encoder.param_dict(), img_q, dt, keep=keep, p_drop=0.3, train=self.training,
+                                            Wc=strip(Wq, "encoder."), layer_out=tuple(y[:B] for y in Ys))
         yq, argq = E.maxmean_forward(dt, Hq)
-        Wq = E.cast(dt, eq.fc.weight.data)
-        q = E.linear_fwd(dt, yq, Wq, B, Wq.shape[0], Wq.shape[1], bias=eq.fc.bias.data, out_f32=1)
+        wq = Wq["fc.weight"]
+        q = E.linear_fwd(dt, yq, wq, B, wq.shape[0], wq.shape[1], bias=eq.fc.bias.data, out_f32=1)
         # ---- key encoder (no gradient): EMA first, then forward on (shuffled) keys
         self._momentum_update_key_encoder()
+        self.flat_k.refresh_shadow(dt)
+        Wk = self.flat_k.shadow_dict()
         img_k = img_k.float().contiguous()
         ddp = _world() > 1
         if ddp:
             img_k, idx_unshuffle = self._batch_shuffle_ddp(img_k)
         keepk = ek.encoder.next_keep_mask(B, img_k.shape[-1])
-        k1, k2, k3, Hk, _ = E.encoder_forward(ek.encoder.param_dict(), img_k, dt, keep=keepk, p_drop=0.3, train=self.training)
+        _, _, _, Hk, _ = E.encoder_forward(ek.encoder.param_dict(), img_k, dt, keep=keepk, p_drop=0.3, train=self.training,
+                                           Wc=strip(Wk, "encoder."), layer_out=tuple(y[B:] for y in Ys))
         yk, _ = E.maxmean_forward(dt, Hk)
-        k = E.linear_fwd(dt, yk, E.cast(dt, ek.fc.weight.data), B, Wq.shape[0], Wq.shape[1], bias=ek.fc.bias.data, out_f32=1)
+        k = E.linear_fwd(dt, yk, Wk["fc.weight"], B, wq.shape[0], wq.shape[1], bias=ek.fc.bias.data, out_f32=1)
         if ddp:
             k = self._batch_unshuffle_ddp(k, idx_unshuffle)
-        # ---- InfoNCE against the queue, then enqueue the keys
+        # ---- the three Barlow heads are independent of each other and of the MoCo head: one side stream each
+        G = flat.grad_dict
+        main = torch.cuda.current_stream()
+        dys = [None, None, None]
+        for i, p in enumerate((self.p1, self.p2, self.p3)):
+            st = self._streams(dev)[i]
+            st.wait_stream(main)
+            with torch.cuda.stream(st):
+                Wp = flat.shadow_dict(f"p{i + 1}.")
+                dys[i] = E.barlow_forward_backward(p.param_dict(), G(f"p{i + 1}."), Ys[i], dt, p.lambd, p.scale_loss,
+                                                   loss[i + 1:i + 2], need_dy1=True, need_dy2=False,
+                                                   update_running=self.training, backward=need_grad,
+                                                   Wc=tuple(Wp[f"projector.{j}.weight"] for j in (0, 3, 6)))
+        # ---- InfoNCE against the queue, then enqueue the keys (main stream, concurrent with the heads)
         shadow = E.cast(dt, self.queue) if dt != N.F32 else self.queue
         dq, kn32 = E.moco_forward_backward(dt, q, k, self.queue, shadow, float(self.hparams.softmax_temperature),
                                            loss[0:1], backward=need_grad)
         self._dequeue_and_enqueue(kn32, None)
-        # ---- Barlow heads on the layer means
-        G = flat.grad_dict
-        dys = []
-        for i, (p, xq, xk) in enumerate(((self.p1, q1, k1), (self.p2, q2, k2), (self.p3, q3, k3))):
-            dy, _ = E.barlow_forward_backward(p.param_dict(), G(f"p{i + 1}."), xq, xk, dt, p.lambd, p.scale_loss,
-                                              loss[i + 1:i + 2], need_dy1=True, need_dy2=False,
-                                              update_running=self.training, backward=need_grad)
-            dys.append(dy)
         if need_grad:
             Gq = G("encoder_q.")
-            E.linear_bwd_w(dt, dq, yq, Gq["fc.weight"], B, Wq.shape[0], Wq.shape[1])
-            E.colsum_add(dt, dq, B, Wq.shape[0], Gq["fc.bias"])
-            dyq = E.linear_bwd_x(dt, dq, Wq, B, Wq.shape[0], Wq.shape[1])
-            E.encoder_backward(cq, G("encoder_q.encoder."), dA2=E.maxmean_backward(dt, dyq, argq, Hq), dx1=dys[0],
-                               dx2=dys[1], dx3=dys[2])
+            E.linear_bwd_w(dt, dq, yq, Gq["fc.weight"], B, wq.shape[0], wq.shape[1])
+            E.colsum_add(dt, dq, B, wq.shape[0], Gq["fc.bias"])
+            dyq = E.linear_bwd_x(dt, dq, wq, B, wq.shape[0], wq.shape[1])
+            dA2 = E.maxmean_backward(dt, dyq, argq, Hq)
+        for st in self._streams(dev):
+            main.wait_stream(st)
+        for y in Ys + [d for d in dys if d is not None]:
+            y.record_stream(main)
+        if need_grad:
+            E.encoder_backward(cq, G("encoder_q.encoder."), dA2=dA2, dx1=dys[0], dx2=dys[1], dx3=dys[2])
         if parts is not None:
             parts["losses"] = loss
         return loss.sum()
+
+    def _streams(self, dev):
+        if getattr(self, "_side_streams", None) is None or self._side_streams[0].device != dev:
+            self._side_streams = [torch.cuda.Stream(device=dev) for _ in range(3)]
+        return self._side_streams
 
     def forward(self, img_q=None, img_k=None):
         raise NotImplementedError("the HIP expert fuses forward and loss; call training_step((img_1, img_2), i)")

@@ -49,24 +49,29 @@ class Upstream_Expert(FusedExpertMixin, UpstreamModule):
         flat = self.ensure_flat()
         if need_grad:
             flat.zero_grad()
+        flat.refresh_shadow(dt)
+        B = img_1.shape[0]
         loss = torch.zeros(1, dtype=torch.float32, device=img_1.device)
         P = enc.param_dict()
         G = flat.grad_dict("encoder.encoder.")
+        Wenc = flat.shadow_dict("encoder.encoder.")
+        Wp = flat.shadow_dict("p.")
+        Y = torch.empty(2 * B, enc.d, dtype=N.torch_dtype(dt), device=img_1.device)      # both views, stacked
         views = []
-        for img in (img_1, img_2):
+        for v, img in enumerate((img_1, img_2)):
             img = img.float().contiguous()
-            keep = enc.next_keep_mask(img.shape[0], img.shape[-1])
+            keep = enc.next_keep_mask(B, img.shape[-1])
             _, _, _, H, c = E.encoder_forward(P, img, dt, keep=keep, p_drop=enc.fc[2].p, train=self.training,
-                                              want_layers=False)
-            y, arg = E.maxmean_forward(dt, H)
-            views.append((c, H, y, arg))
+                                              want_layers=False, Wc=Wenc)
+            _, arg = E.maxmean_forward(dt, H, out=Y[v * B:(v + 1) * B])
+            views.append((c, H, arg))
         ar, gb = self._barlow_reduce()
-        dy1, dy2 = E.barlow_forward_backward(self.p.param_dict(), flat.grad_dict("p."), views[0][2], views[1][2], dt,
-                                             self.p.lambd, self.p.scale_loss, loss, update_running=self.training,
-                                             all_reduce=ar, global_batch=gb(img_1.shape[0]), backward=need_grad)
+        dY = E.barlow_forward_backward(self.p.param_dict(), flat.grad_dict("p."), Y, dt, self.p.lambd, self.p.scale_loss,
+                                       loss, update_running=self.training, all_reduce=ar, global_batch=gb(B),
+                                       backward=need_grad, Wc=tuple(Wp[f"projector.{i}.weight"] for i in (0, 3, 6)))
         if need_grad:
-            for (c, H, y, arg), dy in zip(views, (dy1, dy2)):
-                E.encoder_backward(c, G, dA2=E.maxmean_backward(dt, dy, arg, H))
+            for v, (c, H, arg) in enumerate(views):
+                E.encoder_backward(c, G, dA2=E.maxmean_backward(dt, dY[v * B:(v + 1) * B], arg, H))
         return loss[0]
 
     def _barlow_reduce(self):

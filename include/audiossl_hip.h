@@ -85,14 +85,16 @@ int audiossl_conv1_bwd(int dtype, const float* img, int N, int F, int T, const f
                        float* dgamma, float* dbeta, void* stream);
 
 /* ---- K7/K8 conv blocks 2,3: audiontt.py:52-60, 76-93 ----------------------------------------------------
- * colstats : per-column sum / sum of squares of x [M][C] (ld) in fp64.
- * bn_finalize: train-mode BatchNorm statistics -> scale/shift/mean/rstd (+ running stats, momentum 0.1).
+ * colstats : per-column sum / sum of squares of x [G][M][C] (ld) in fp64 -> [G][C].  `groups` = independent batches that
+ *            go through the same layer (the two views of the projector); C % 64 == 0.
+ * bn_finalize: train-mode BatchNorm statistics -> per-group scale/shift/mean/rstd [G][C]; running stats (momentum 0.1)
+ *            are updated group after group, as the reference's successive module calls do.
  * bn_relu_pool_fwd: Y [N][Ti][Fi][64] -> P [N][Ti/2][Fi/2][64].   tmean_fwd: P -> xl [N][Fo*64] (x_1/x_2/x_3).
  * bn_relu_pool_bwd: dP (+dxl/To) -> dY at every position, dgamma, dbeta (stat = 128 floats scratch).
  * im2col3x3 / pack_conv_w / unpack_conv_dw: implicit-GEMM plumbing, tap = kh*3+kw, kh on mel, kw on time. */
-int audiossl_colstats(int dtype, const void* x, long M, int C, long ld, int want_sq, double* sum, double* sumsq,
-                      void* stream);
-int audiossl_bn_finalize(const double* sum, const double* sumsq, double count, int C, const float* gamma,
+int audiossl_colstats(int dtype, const void* x, int groups, long M, int C, long ld, int want_sq, double* sum,
+                      double* sumsq, void* stream);
+int audiossl_bn_finalize(const double* sum, const double* sumsq, int groups, double count, int C, const float* gamma,
                          const float* beta, float* running_mean, float* running_var, float momentum, float eps,
                          float* scale, float* shift, float* save_mean, float* save_rstd, void* stream);
 int audiossl_bn_relu_pool_fwd(int dtype, const void* Y, const float* scale, const float* shift, void* P, int N, int Ti,
@@ -122,13 +124,14 @@ int audiossl_maxmean_bwd(int dtype, const void* dy, const uint8_t* arg, const vo
                          void* stream);
 
 /* ---- K10/K11 Barlow head: delores_s/upstream_expert.py:11-46, src/utils/utils.py:185-189 ------------------
- * colbn_fwd: h = act(scale*a+shift).  colbn_bwd: BatchNorm1d(train) backward (tmp = 2*C doubles scratch).
+ * colbn_fwd: h = act(scale_g*a+shift_g) on [G][M][C].  colbn_bwd: BatchNorm1d(train) backward per group (tmp = 2*G*C
+ * doubles scratch), parameter grads summed over groups.
  * barlow_loss: loss += coef * sum (c - I)^2 ; dc = dscale * (c - I). */
-int audiossl_colbn_fwd(int dtype, const void* a, const float* scale, const float* shift, int relu, void* h, long M, int C,
-                       void* stream);
+int audiossl_colbn_fwd(int dtype, const void* a, const float* scale, const float* shift, int relu, void* h, int groups,
+                       long M, int C, void* stream);
 int audiossl_colbn_bwd(int dtype, const void* a, const void* dh, const float* scale, const float* shift, const float* mean,
-                       const float* rstd, int relu, long M, int C, double* tmp, void* da, float* dgamma, float* dbeta,
-                       void* stream);
+                       const float* rstd, int relu, int groups, long M, int C, double* tmp, void* da, float* dgamma,
+                       float* dbeta, void* stream);
 int audiossl_add_d2f(const double* src, float* dst, int n, void* stream);
 int audiossl_barlow_loss(int dtype, const float* c, int D, float coef, float dscale, void* dc, float* loss_out,
                          void* stream);
