@@ -18,7 +18,7 @@ namespace {
 
 constexpr int BM = 128, BN = 128, BK = 32;
 constexpr int NT_PITCH = BK + 8;      // elements; [row][k] image, conflict-free 16-byte row reads
-constexpr int TR_PITCH = 128 + 8;     // elements; [k][row] image
+constexpr int TR_PITCH = 128 + 32;    // elements; [k][row] image: 80-dword rows keep ds_read_b64_tr_b16 conflict-free
 
 struct GemmArgs {
     const void* A; const void* B; void* C;
@@ -84,9 +84,25 @@ struct Stage {
     __device__ __forceinline__ static Vec8<T> frag(const T* lds, int row, int kk, int lane) {
         const int r_ = row + (lane & 31), kb = kk + 8 * (lane >> 5);
         if (!TRANS) return Vec8<T>::load(lds + r_ * NT_PITCH + kb);
-        Vec8<T> f;
+        return frag_trans(lds, row, kb, r_, lane);
+    }
+    // [k][row] image -> 8 consecutive k of one row.  bf16: two ds_read_b64_tr_b16 (each 16-lane group transposes a
+    // 4 (k) x 16 (row) block: lane 4q+p supplies the address of k-row q, columns 4p..4p+3, and receives column i);
+    // fp32: 8 scalar reads (validation path).
+    __device__ __forceinline__ static Vec8<float> frag_trans(const float* lds, int, int kb, int r_, int) {
+        Vec8<float> f;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) f.setraw(j, lds[(kb + j) * TR_PITCH + r_]);
+        for (int j = 0; j < 8; ++j) f.set(j, lds[(kb + j) * TR_PITCH + r_]);
+        return f;
+    }
+    __device__ __forceinline__ static Vec8<bf16> frag_trans(const bf16* lds, int row, int kb, int, int lane) {
+        typedef __attribute__((address_space(3))) bf16x4* lds4_t;
+        const int i = lane & 15, q = i >> 2, p = i & 3;
+        const bf16* a = lds + (kb + q) * TR_PITCH + row + 16 * ((lane >> 4) & 1) + 4 * p;
+        const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds4_t)a);
+        const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds4_t)(a + 4 * TR_PITCH));
+        Vec8<bf16> f;
+        f.v = bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
         return f;
     }
     static constexpr int LDS_ELEMS = TRANS ? BK * TR_PITCH : BM * NT_PITCH;

@@ -96,16 +96,27 @@ def _bn_eval(like, C, gamma, beta, rm, rv):
 
 
 def _conv_block_fwd(dtype, Pin, Nimg, Ti, Fi, W, bias, bn, train, update_running, col):
-    """3x3 conv (im2col + MFMA GEMM) -> BN -> ReLU -> pool.  Returns (Y, Pout, stats, Wf, Wd)."""
+    """3x3 conv -> BN -> ReLU -> pool.  bf16: implicit-GEMM kernel with the batch statistics fused into its epilogue;
+    fp32 (validation path): im2col + exact-f32 MFMA GEMM + colstats.  Returns (Y, Pout, stats, Wf, Wd)."""
     td = N.torch_dtype(dtype)
     Wf, Wd = _empty((64, 576), td, like=Pin), _empty((64, 576), td, like=Pin)
     N.call("pack_conv_w", dtype, W, Wf, Wd)
     M = Nimg * Ti * Fi
-    N.call("im2col3x3", dtype, Pin, col, Nimg, Ti, Fi)
     Y = _empty((M, 64), td, like=Pin)
-    gemm(dtype, 0, 0, M, 64, 576, col, 576, Wf, 576, Y, 64, bias=bias)
     gamma, beta, rm, rv = bn
-    if train:
+    fused = dtype == N.BF16 and Fi in (16, 32)
+    sq = _empty((2, 64), torch.float64, like=Pin) if (fused and train) else None
+    if fused:
+        N.call("conv3x3_fwd", Pin, Wf, bias, Y, None if sq is None else sq[0], None if sq is None else sq[1], Nimg, Ti, Fi)
+    else:
+        N.call("im2col3x3", dtype, Pin, col, Nimg, Ti, Fi)
+        gemm(dtype, 0, 0, M, 64, 576, col, 576, Wf, 576, Y, 64, bias=bias)
+    if train and fused:
+        st = _empty((4, 64), torch.float32, like=Pin)
+        N.call("bn_finalize", sq[0], sq[1], 1, float(M), 64, gamma, beta, rm if update_running else None,
+               rv if update_running else None, BN_MOMENTUM, BN_EPS, st[0], st[1], st[2], st[3])
+        scale, shift, mean, rstd = st[0], st[1], st[2], st[3]
+    elif train:
         scale, shift, mean, rstd = _bn_train(dtype, Y, M, 64, gamma, beta, rm, rv, update_running)
     else:
         scale, shift = _bn_eval(Y, 64, gamma, beta, rm, rv)
@@ -116,6 +127,9 @@ def _conv_block_fwd(dtype, Pin, Nimg, Ti, Fi, W, bias, bn, train, update_running
 
 
 def _col_buffer(dtype, Nimg, T1, F1, like):
+    """im2col scratch of the fp32 path (the bf16 path convolves implicitly)."""
+    if dtype == N.BF16 and F1 in (16, 32):
+        return None
     return _empty((Nimg * T1 * F1, 576), N.torch_dtype(dtype), like=like)
 
 
@@ -188,17 +202,24 @@ def _conv_block_bwd(dtype, Y, dP, dxl, st, Nimg, Ti, Fi, Pin, Wd, G_w, G_gamma, 
     dY = _empty((M, 64), td, like=Y)
     stat = _empty((128,), torch.float32, like=Y)
     N.call("bn_relu_pool_bwd", dtype, Y, dP, dxl, scale, shift, mean, rstd, stat, dY, G_gamma, G_beta, Nimg, Ti, Fi)
-    # wgrad: dWp[co][tap*64+ci] = sum_pix dY[pix][co] * col(Pin)[pix][tap*64+ci]
-    N.call("im2col3x3", dtype, Pin, col, Nimg, Ti, Fi)
+    # wgrad: dWp[co][tap*64+ci] = sum_pix dY[pix][co] * Pin[pix + off(tap)][ci]
+    fused = dtype == N.BF16 and Fi in (16, 32)
     dWp = torch.zeros(64, 576, dtype=torch.float32, device=Y.device)
-    gemm(dtype, 1, 1, 64, 576, M, dY, 64, col, 576, dWp, 576, out_f32=1, atomic=1, ksplit=_ksplit(64, 576, M, 1024))
+    if fused:
+        N.call("conv3x3_wgrad", dY, Pin, dWp, Nimg, Ti, Fi)
+    else:
+        N.call("im2col3x3", dtype, Pin, col, Nimg, Ti, Fi)
+        gemm(dtype, 1, 1, 64, 576, M, dY, 64, col, 576, dWp, 576, out_f32=1, atomic=1, ksplit=_ksplit(64, 576, M, 1024))
     N.call("unpack_conv_dw", dWp, G_w)
     if not need_dx:
         return None
     # dgrad: dPin[pix][ci] = sum_{tap,co} dY[pix + off(tap)][co] * W[co][ci][8 - tap]
-    N.call("im2col3x3", dtype, dY, col, Nimg, Ti, Fi)
     dPin = _empty((Nimg, Ti, Fi, 64), td, like=Y)
-    gemm(dtype, 0, 0, M, 64, 576, col, 576, Wd, 576, dPin, 64)
+    if fused:
+        N.call("conv3x3_fwd", dY, Wd, None, dPin, None, None, Nimg, Ti, Fi)
+    else:
+        N.call("im2col3x3", dtype, dY, col, Nimg, Ti, Fi)
+        gemm(dtype, 0, 0, M, 64, 576, col, 576, Wd, 576, dPin, 64)
     return dPin
 
 

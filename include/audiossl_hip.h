@@ -107,6 +107,14 @@ int audiossl_im2col3x3(int dtype, const void* X, void* col, int N, int Ti, int F
 int audiossl_pack_conv_w(int dtype, const float* W, void* Wf, void* Wd, void* stream);
 int audiossl_unpack_conv_dw(const float* dWp, float* dW, void* stream);
 
+/* Implicit-GEMM 3x3 / 64->64 convolution on the bf16 MFMA pipe (no im2col buffer); bf16 only, Fi in {32, 16}.
+ * conv3x3_fwd : Y = conv(X, W) (+bias); W = packed [64][576] (pack_conv_w: Wf = forward, Wd = data gradient);
+ *               optional BatchNorm batch statistics of the fp32 accumulators: sum / sumsq fp64 [64] (zeroed inside).
+ * conv3x3_wgrad: dWp fp32 [64][576] += dY^T * patches(X) (caller zeroes; unpack_conv_dw maps back to [co][ci][3][3]). */
+int audiossl_conv3x3_fwd(const void* X, const void* W, const float* bias, void* Y, double* sum, double* sumsq, int N,
+                         int Ti, int Fi, void* stream);
+int audiossl_conv3x3_wgrad(const void* dY, const void* X, float* dWp, int N, int Ti, int Fi, void* stream);
+
 /* ---- K9-K12 GEMM: every nn.Linear / matmul / einsum of the path ------------------------------------------
  * (audiontt.py:62-68; delores_s/upstream_expert.py:15-22, 36; delores_m/upstream_expert.py:250-252)
  * C[M,N] (+)= alpha * op(A) * op(B), operands of `dtype`, fp32 accumulate.

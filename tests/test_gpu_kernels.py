@@ -237,3 +237,44 @@ def test_conv1_block_fwd_bwd(N, dtype, T):
     assert rel_l2(dg.cpu(), bn.weight.grad) < tol
     assert rel_l2(dbt.cpu(), bn.bias.grad) < tol
     assert float(conv.bias.grad.abs().max()) < 1e-3 and float(db.abs().max()) == 0.0
+
+
+# ------------------------------------------------------------------------------------------------ implicit-GEMM conv
+@pytest.mark.parametrize("shape", [(3, 50, 32), (2, 48, 32), (3, 25, 16), (5, 24, 16), (1, 3, 32)])
+def test_conv3x3_implicit_gemm_fwd_dgrad_wgrad(N, shape):
+    """bf16 implicit-GEMM conv vs torch conv2d on the same (bf16-exact) operands: forward + fused BN statistics,
+    data gradient, weight gradient.  Tiles end inside images and images end inside tiles for these shapes."""
+    import torch.nn.functional as Fnn
+    Nimg, Ti, Fi = shape
+    x = torch.from_numpy(fill.normalish((Nimg, Ti, Fi, 64), 61 + Ti)).cuda().bfloat16()          # [N][T][F][C]
+    w = torch.from_numpy(fill.uniform((64, 64, 3, 3), 62, -0.05, 0.05)).cuda()
+    b = torch.from_numpy(fill.uniform((64,), 63)).cuda()
+    Wf = torch.empty(64, 576, device="cuda", dtype=torch.bfloat16)
+    Wd = torch.empty_like(Wf)
+    N.call("pack_conv_w", 1, w, Wf, Wd)
+    wq = Wf.float().view(64, 9, 64).permute(0, 2, 1).reshape(64, 64, 3, 3)                        # bf16-rounded [co][ci][kh][kw]
+    x_nchw = x.float().permute(0, 3, 2, 1).contiguous()                                           # [N][C][F][T]
+    ref = Fnn.conv2d(x_nchw.double(), wq.double(), b.double(), padding=1)                         # [N][co][F][T]
+    Y = torch.full((Nimg, Ti, Fi, 64), float("nan"), device="cuda", dtype=torch.bfloat16)
+    sq = torch.empty(2, 64, dtype=torch.float64, device="cuda")
+    N.call("conv3x3_fwd", x, Wf, b, Y, sq[0], sq[1], Nimg, Ti, Fi)
+    torch.cuda.synchronize()
+    ref_cl = ref.permute(0, 3, 2, 1)
+    assert rel_l2(Y.float().cpu(), ref_cl.cpu()) < 4e-3                                           # bf16 output rounding only
+    np.testing.assert_allclose(sq[0].cpu().numpy(), ref_cl.sum((0, 1, 2)).cpu().numpy(), rtol=1e-4, atol=1e-2)
+    np.testing.assert_allclose(sq[1].cpu().numpy(), (ref_cl ** 2).sum((0, 1, 2)).cpu().numpy(), rtol=1e-4)
+    # data gradient = the same kernel on dY with the flipped / transposed weights
+    dy = torch.from_numpy(fill.normalish((Nimg, Ti, Fi, 64), 64 + Ti)).cuda().bfloat16()
+    dx = torch.empty_like(Y)
+    N.call("conv3x3_fwd", dy, Wd, None, dx, None, None, Nimg, Ti, Fi)
+    dy_nchw = dy.float().permute(0, 3, 2, 1).contiguous().double()
+    ref_dx = torch.nn.grad.conv2d_input(x_nchw.shape, wq.double(), dy_nchw, padding=1).permute(0, 3, 2, 1)
+    assert rel_l2(dx.float().cpu(), ref_dx.cpu()) < 4e-3
+    # weight gradient
+    dWp = torch.zeros(64, 576, device="cuda")
+    N.call("conv3x3_wgrad", dy, x, dWp, Nimg, Ti, Fi)
+    dW = torch.zeros(64, 64, 3, 3, device="cuda")
+    N.call("unpack_conv_dw", dWp, dW)
+    torch.cuda.synchronize()
+    ref_dw = torch.nn.grad.conv2d_weight(x_nchw.double(), wq.shape, dy_nchw, padding=1)
+    assert rel_l2(dW.cpu(), ref_dw.cpu()) < 1e-5
