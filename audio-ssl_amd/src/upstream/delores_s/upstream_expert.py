@@ -70,8 +70,10 @@ class Upstream_Expert(FusedExpertMixin, UpstreamModule):
                                        loss, update_running=self.training, all_reduce=ar, global_batch=gb(B),
                                        backward=need_grad, Wc=tuple(Wp[f"projector.{i}.weight"] for i in (0, 3, 6)))
         if need_grad:
+            self.reduce_begin("heads")                      # projector gradients are complete: start their all-reduce
             for v, (c, H, arg) in enumerate(views):
                 E.encoder_backward(c, G, dA2=E.maxmean_backward(dt, dY[v * B:(v + 1) * B], arg, H))
+            self.reduce_begin("enc")
         return loss[0]
 
     def _barlow_reduce(self):

@@ -42,6 +42,47 @@ def test_concat_all_gather_orders_ranks():
     assert np.array_equal(a, want) and np.array_equal(b, want)
 
 
+def _segmented_reduce_fn(rank, world):
+    """The overlapped two-segment gradient all-reduce of FusedExpertMixin (heads first, encoder second)."""
+    from src.upstream.common import FusedExpertMixin
+
+    class Tiny(FusedExpertMixin, torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.encoder = torch.nn.Linear(8, 4)
+            self.p = torch.nn.Linear(4, 4, bias=False)
+    t = Tiny()
+    t.ensure_flat()
+    ho = t.head_offset()
+    assert 0 < ho < t.flat.numel and t.flat.names[-1] == "p.weight"
+    t.flat.grad.fill_(float(rank + 1))
+    t.reduce_begin("heads")                 # async, before the "encoder backward"
+    t.flat.grad[:ho].add_(10.0)             # encoder gradients arrive later
+    t.all_reduce_grads()                    # launches the encoder segment, joins both
+    return t.flat.grad.clone().numpy(), ho
+
+
+def test_segmented_overlapped_gradient_allreduce():
+    (ga, ho), (gb, _) = _run(_segmented_reduce_fn)
+    assert np.array_equal(ga, gb)
+    assert np.all(ga[ho:] == 1.5) and np.all(ga[:ho] == 11.5)      # summed over 2 ranks, then averaged (no HipSGD attached)
+
+
+def _async_shuffle_fn(rank, world):
+    from src.encoder import AudioNTT2020Task6
+    from src.upstream.delores_m.upstream_expert import Upstream_Expert
+    ex = Upstream_Expert(copy.deepcopy(CFG_M), base_encoder=AudioNTT2020Task6, num_negatives=64)
+    x = torch.arange(4, dtype=torch.float32).view(4, 1) + 10 * rank
+    pend = ex._shuffle_begin(x)
+    xs, idx_un = ex._shuffle_end(pend, 4)
+    return x.numpy(), ex._batch_unshuffle_ddp(xs * 2.0, idx_un).numpy()
+
+
+def test_async_key_gather_roundtrip():
+    for x, back in _run(_async_shuffle_fn):
+        assert np.array_equal(back, 2.0 * x)
+
+
 def _shuffle_fn(rank, world):
     import sys
     from src.encoder import AudioNTT2020Task6
