@@ -16,10 +16,8 @@
 
 namespace {
 
-constexpr int BM = 128, BN = 128;
-template <typename T> struct Cfg;
-template <> struct Cfg<bf16>  { static constexpr int BK = 64; };   // 18 KB per operand stage
-template <> struct Cfg<float> { static constexpr int BK = 32; };   // fp32 validation path: keep LDS at 80 KB
+constexpr int BM = 128, BN = 128, BK = 32;
+constexpr int NT_PITCH = BK + 8;      // elements; [row][k] image, conflict-free 16-byte row reads
 constexpr int TR_PITCH = 128 + 32;    // elements; [k][row] image: 80-dword rows keep ds_read_b64_tr_b16 conflict-free
 
 struct GemmArgs {
@@ -54,22 +52,18 @@ template <> struct Mma<float> {
     }
 };
 
-// One operand's staging: 128 rows x BK k per step, NV 8-element vectors per thread.
+// One operand's staging: 128 rows x 32 k per step, two Vec8 per thread.
 template <typename T, bool TRANS>
 struct Stage {
-    static constexpr int BK = Cfg<T>::BK;
-    static constexpr int NT_PITCH = BK + 8;          // elements; [row][k] image, conflict-free 16-byte row reads
-    static constexpr int NV = BM * BK / 8 / 256;
-    static constexpr int VPR = BK / 8;               // vectors per row of the [row][k] image
-    Vec8<T> r[NV];
+    Vec8<T> r[2];
     // rows = extent of the row dimension (M or N); kend = exclusive K bound of this split
     __device__ __forceinline__ void load(const T* __restrict__ base, long ld, int row0, int rows, int k0, int kend) {
         const int t = threadIdx.x;
 #pragma unroll
-        for (int i = 0; i < NV; ++i) {
+        for (int i = 0; i < 2; ++i) {
             const int v = t + i * 256;
             if (!TRANS) {
-                const int row = row0 + v / VPR, k = k0 + (v % VPR) * 8;
+                const int row = row0 + (v >> 2), k = k0 + (v & 3) * 8;
                 r[i] = (row < rows && k < kend) ? Vec8<T>::load(base + (long)row * ld + k) : Vec8<T>::zero();
             } else {
                 const int k = k0 + (v >> 4), row = row0 + (v & 15) * 8;
@@ -80,13 +74,13 @@ struct Stage {
     __device__ __forceinline__ void put(T* lds) const {
         const int t = threadIdx.x;
 #pragma unroll
-        for (int i = 0; i < NV; ++i) {
+        for (int i = 0; i < 2; ++i) {
             const int v = t + i * 256;
-            if (!TRANS) r[i].store(lds + (v / VPR) * NT_PITCH + (v % VPR) * 8);
+            if (!TRANS) r[i].store(lds + (v >> 2) * NT_PITCH + (v & 3) * 8);
             else        r[i].store(lds + (v >> 4) * TR_PITCH + (v & 15) * 8);
         }
     }
-    // fragment of 32 rows starting at `row`, 16-wide k-step at `kk` for this lane
+    // fragment of 32 rows starting at `row`, k-step `kk` (0 or 16) for this lane
     __device__ __forceinline__ static Vec8<T> frag(const T* lds, int row, int kk, int lane) {
         const int r_ = row + (lane & 31), kb = kk + 8 * (lane >> 5);
         if (!TRANS) return Vec8<T>::load(lds + r_ * NT_PITCH + kb);
@@ -122,7 +116,6 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
     T* const ldsA0 = reinterpret_cast<T*>(smem);                 // two A buffers, then two B buffers
     T* const ldsB0 = ldsA0 + 2 * SA::LDS_ELEMS;
 
-    constexpr int BK = Cfg<T>::BK;
     const int tiles_n = (g.N + BN - 1) / BN;
     const int bm = (blockIdx.x / tiles_n) * BM, bn = (blockIdx.x % tiles_n) * BN;
     // split-K range, in whole BK steps
@@ -145,19 +138,21 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    // Software pipeline, prefetch distance 2: while the MFMAs consume step k from LDS[k&1], the registers of set (k+1)&1
-    // already hold (or are receiving) step k+1 and the loads of step k+2 are issued into set k&1.  One barrier per step.
-    SA sa0, sa1; SB sb0, sb1;
-    sa0.load(A, g.lda, bm, g.M, ks0 * BK, kend);
-    sb0.load(B, g.ldb, bn, g.N, ks0 * BK, kend);
-    if (ks0 + 1 < ks1) {
-        sa1.load(A, g.lda, bm, g.M, (ks0 + 1) * BK, kend);
-        sb1.load(B, g.ldb, bn, g.N, (ks0 + 1) * BK, kend);
-    }
-    sa0.put(ldsA0); sb0.put(ldsB0);
+    SA sa; SB sb;
+    sa.load(A, g.lda, bm, g.M, ks0 * BK, kend);
+    sb.load(B, g.ldb, bn, g.N, ks0 * BK, kend);
+    sa.put(ldsA0); sb.put(ldsB0);
     __syncthreads();
 
-    auto compute = [&](const T* la, const T* lb) {
+    int cur = 0;
+    for (int ks = ks0; ks < ks1; ++ks) {
+        const bool more = ks + 1 < ks1;
+        if (more) {
+            sa.load(A, g.lda, bm, g.M, (ks + 1) * BK, kend);
+            sb.load(B, g.ldb, bn, g.N, (ks + 1) * BK, kend);
+        }
+        const T* la = ldsA0 + cur * SA::LDS_ELEMS;
+        const T* lb = ldsB0 + cur * SB::LDS_ELEMS;
 #pragma unroll
         for (int kk = 0; kk < BK; kk += 16) {
             Vec8<T> fa[2], fb[2];
@@ -170,25 +165,9 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
 #pragma unroll
                 for (int j = 0; j < 2; ++j) Mma<T>::run(acc[i][j], fa[i], fb[j]);
         }
-    };
-    for (int ks = ks0; ks < ks1; ks += 2) {
-        // even step: LDS buffer 0 <- registers set 0 (done); set 1 holds step ks+1
-        if (ks + 2 < ks1) {
-            sa0.load(A, g.lda, bm, g.M, (ks + 2) * BK, kend);
-            sb0.load(B, g.ldb, bn, g.N, (ks + 2) * BK, kend);
-        }
-        compute(ldsA0, ldsB0);
-        if (ks + 1 < ks1) { sa1.put(ldsA0 + SA::LDS_ELEMS); sb1.put(ldsB0 + SB::LDS_ELEMS); }
+        if (more) { sa.put(ldsA0 + (cur ^ 1) * SA::LDS_ELEMS); sb.put(ldsB0 + (cur ^ 1) * SB::LDS_ELEMS); }
         __syncthreads();
-        if (ks + 1 >= ks1) break;
-        // odd step
-        if (ks + 3 < ks1) {
-            sa1.load(A, g.lda, bm, g.M, (ks + 3) * BK, kend);
-            sb1.load(B, g.ldb, bn, g.N, (ks + 3) * BK, kend);
-        }
-        compute(ldsA0 + SA::LDS_ELEMS, ldsB0 + SB::LDS_ELEMS);
-        if (ks + 2 < ks1) { sa0.put(ldsA0); sb0.put(ldsB0); }
-        __syncthreads();
+        cur ^= 1;
     }
 
     // ---- epilogue: C/D map of 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
