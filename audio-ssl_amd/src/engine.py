@@ -19,6 +19,33 @@ BN_MOMENTUM = 0.1
 BN_EPS = 1e-5
 
 
+class SideStream:
+    """A second HIP stream for work that is off the critical dependency chain (weight-gradient GEMMs, the key
+    encoder): `run(fn)` orders the side stream after everything enqueued so far on the current stream, `join()`
+    orders the current stream after the side stream."""
+
+    def __init__(self):
+        self._streams = {}
+
+    def stream(self, device):
+        key = str(device)
+        if key not in self._streams:
+            self._streams[key] = torch.cuda.Stream(device=device)
+        return self._streams[key]
+
+    def run(self, device, fn):
+        s = self.stream(device)
+        s.wait_stream(torch.cuda.current_stream(device))
+        with torch.cuda.stream(s):
+            return fn()
+
+    def join(self, device):
+        torch.cuda.current_stream(device).wait_stream(self.stream(device))
+
+
+WGRAD = SideStream()
+
+
 def _empty(shape, dtype, like=None, device=None):
     return torch.empty(shape, dtype=dtype, device=device if device is not None else like.device)
 
@@ -194,8 +221,9 @@ def encoder_forward(P, x, dtype, keep=None, p_drop=0.3, train=True, update_runni
     return x1, x2, x3, c.H2.view(Nimg, T3, d), c
 
 
-def _conv_block_bwd(dtype, Y, dP, dxl, st, Nimg, Ti, Fi, Pin, Wd, G_w, G_gamma, G_beta, need_dx, col):
-    """BN/ReLU/pool backward + conv wgrad (+ dgrad).  Returns dPin or None."""
+def _conv_block_bwd(dtype, Y, dP, dxl, st, Nimg, Ti, Fi, Pin, Wd, G_w, G_gamma, G_beta, need_dx, col, keep):
+    """BN/ReLU/pool backward + conv wgrad (+ dgrad).  Returns dPin or None.  `keep`: list that holds the tensors the
+    side-stream weight gradient still reads until the caller joins the streams."""
     td = N.torch_dtype(dtype)
     scale, shift, mean, rstd = st
     M = Nimg * Ti * Fi
@@ -204,13 +232,18 @@ def _conv_block_bwd(dtype, Y, dP, dxl, st, Nimg, Ti, Fi, Pin, Wd, G_w, G_gamma, 
     N.call("bn_relu_pool_bwd", dtype, Y, dP, dxl, scale, shift, mean, rstd, stat, dY, G_gamma, G_beta, Nimg, Ti, Fi)
     # wgrad: dWp[co][tap*64+ci] = sum_pix dY[pix][co] * Pin[pix + off(tap)][ci]
     fused = dtype == N.BF16 and Fi in (16, 32)
-    dWp = torch.zeros(64, 576, dtype=torch.float32, device=Y.device)
     if fused:
-        N.call("conv3x3_wgrad", dY, Pin, dWp, Nimg, Ti, Fi)
+        def wg():
+            dWp = torch.zeros(64, 576, dtype=torch.float32, device=Y.device)
+            N.call("conv3x3_wgrad", dY, Pin, dWp, Nimg, Ti, Fi)
+            N.call("unpack_conv_dw", dWp, G_w)
+            return dWp
+        keep.append((dY, WGRAD.run(Y.device, wg)))             # off the critical path
     else:
+        dWp = torch.zeros(64, 576, dtype=torch.float32, device=Y.device)
         N.call("im2col3x3", dtype, Pin, col, Nimg, Ti, Fi)
         gemm(dtype, 1, 1, 64, 576, M, dY, 64, col, 576, dWp, 576, out_f32=1, atomic=1, ksplit=_ksplit(64, 576, M, 1024))
-    N.call("unpack_conv_dw", dWp, G_w)
+        N.call("unpack_conv_dw", dWp, G_w)
     if not need_dx:
         return None
     # dgrad: dPin[pix][ci] = sum_{tap,co} dY[pix + off(tap)][co] * W[co][ci][8 - tap]
@@ -234,27 +267,34 @@ def encoder_backward(c, G, dA2=None, dH2=None, dx1=None, dx2=None, dx3=None):
     if dA2 is None:
         dA2 = _empty((M, d), td, like=c.H2)
         N.call("relu_bwd", dtype, dH2.contiguous(), c.H2, dA2, M * d)
+    dev = c.H2.device
+    # The data-gradient chain (dA2 -> dA1 -> dP3 -> dY3 -> ...) is the critical path; every weight / bias gradient
+    # only hangs off it, so those launches go to a second stream and overlap the chain.
     # fc.3
-    linear_bwd_w(dtype, dA2, c.H1, G["fc.3.weight"], M, d, d)
-    colsum_add(dtype, dA2, M, d, G["fc.3.bias"])
+    def w2():
+        linear_bwd_w(dtype, dA2, c.H1, G["fc.3.weight"], M, d, d)
+        colsum_add(dtype, dA2, M, d, G["fc.3.bias"])
+    WGRAD.run(dev, w2)
     scale = 1.0 / (1.0 - c.p_drop) if c.keep is not None else 1.0
     dA1 = linear_bwd_x(dtype, dA2, c.fw2, M, d, d, alpha=scale, gate=c.H1)
     # fc.0
-    linear_bwd_w(dtype, dA1, c.P3, G["fc.0.weight"], M, d, kin)
-    colsum_add(dtype, dA1, M, d, G["fc.0.bias"])
+    def w1():
+        linear_bwd_w(dtype, dA1, c.P3, G["fc.0.weight"], M, d, kin)
+        colsum_add(dtype, dA1, M, d, G["fc.0.bias"])
+    WGRAD.run(dev, w1)
     dP3 = linear_bwd_x(dtype, dA1, c.fw1, M, d, kin)
-    del dA1, dA2
     col = _col_buffer(dtype, Nimg, T1, F1, c.H2)
+    keep = []
     dP2 = _conv_block_bwd(dtype, c.Y3, dP3, dx3, c.st3, Nimg, T2, F2, c.P2, c.W3d, G["features_3.0.weight"],
-                          G["features_3.1.weight"], G["features_3.1.bias"], True, col)
+                          G["features_3.1.weight"], G["features_3.1.bias"], True, col, keep)
     dP1 = _conv_block_bwd(dtype, c.Y2, dP2, dx2, c.st2, Nimg, T1, F1, c.P1, c.W2d, G["features_2.0.weight"],
-                          G["features_2.1.weight"], G["features_2.1.bias"], True, col)
-    del col
+                          G["features_2.1.weight"], G["features_2.1.bias"], True, col, keep)
     acc = _empty((64 * 11,), torch.float32, like=c.H2)
     P = c.P
     N.call("conv1_bwd", dtype, c.img, Nimg, c.F, c.T, P["features_1.0.weight"].reshape(64, 9), P["features_1.0.bias"],
            P["features_1.1.weight"], c.sc1, c.sh1, c.mean1, c.rstd1, c.mom1, dP1, dx1, acc,
            G["features_1.0.weight"].view(64, 9), G["features_1.0.bias"], G["features_1.1.weight"], G["features_1.1.bias"])
+    WGRAD.join(dev)            # dA2 / dA1 / dY* stay referenced until the side stream is ordered before us
 
 
 # =============================================================================================== max + mean pooling

@@ -51,6 +51,7 @@ class Upstream_Expert(FusedExpertMixin, UpstreamModule):
         self.precision = {"fp32": N.F32, "bf16": N.BF16}.get(config.get("run", {}).get("precision"), default_precision())
         self.encoder_q.encoder.precision = self.encoder_k.encoder.precision = self.precision
         self.flat_k = None
+        self._key_stream = E.SideStream()
         self._ptr = 0                      # host mirror of queue_ptr (no device sync in the step)
 
     def init_encoders(self, base_encoder):
@@ -146,30 +147,38 @@ class Upstream_Expert(FusedExpertMixin, UpstreamModule):
         ddp = _world() > 1
         img_k = img_k.float().contiguous()
         pending_k = self._shuffle_begin(img_k) if ddp else None
-        # ---- query encoder
+        main = torch.cuda.current_stream()
+        wq = Wq["fc.weight"]
+
+        # ---- key encoder (no gradient) on its own stream, concurrent with the query encoder: EMA first, then forward
+        def key_branch():
+            x = img_k
+            idx_unshuffle = None
+            self._momentum_update_key_encoder()
+            self.flat_k.refresh_shadow(dt)
+            Wk = self.flat_k.shadow_dict()
+            if ddp:
+                x, idx_unshuffle = self._shuffle_end(pending_k, B)
+            keepk = ek.encoder.next_keep_mask(B, x.shape[-1])
+            _, _, _, Hk, _ = E.encoder_forward(ek.encoder.param_dict(), x, dt, keep=keepk, p_drop=0.3, train=self.training,
+                                               Wc=strip(Wk, "encoder."), layer_out=tuple(y[B:] for y in Ys))
+            yk, _ = E.maxmean_forward(dt, Hk)
+            kk = E.linear_fwd(dt, yk, Wk["fc.weight"], B, wq.shape[0], wq.shape[1], bias=ek.fc.bias.data, out_f32=1)
+            if ddp:
+                kk = self._batch_unshuffle_ddp(kk, idx_unshuffle)
+            return kk
+        k = self._key_stream.run(dev, key_branch)
+        # ---- query encoder (main stream)
         img_q = img_q.float().contiguous()
         keep = eq.encoder.next_keep_mask(B, img_q.shape[-1])
         _, _, _, Hq, cq = E.encoder_forward(eq.encoder.param_dict(), img_q, dt, keep=keep, p_drop=0.3, train=self.training,
                                             Wc=strip(Wq, "encoder."), layer_out=tuple(y[:B] for y in Ys))
         yq, argq = E.maxmean_forward(dt, Hq)
-        wq = Wq["fc.weight"]
         q = E.linear_fwd(dt, yq, wq, B, wq.shape[0], wq.shape[1], bias=eq.fc.bias.data, out_f32=1)
-        # ---- key encoder (no gradient): EMA first, then forward on (shuffled) keys
-        self._momentum_update_key_encoder()
-        self.flat_k.refresh_shadow(dt)
-        Wk = self.flat_k.shadow_dict()
-        if ddp:
-            img_k, idx_unshuffle = self._shuffle_end(pending_k, B)
-        keepk = ek.encoder.next_keep_mask(B, img_k.shape[-1])
-        _, _, _, Hk, _ = E.encoder_forward(ek.encoder.param_dict(), img_k, dt, keep=keepk, p_drop=0.3, train=self.training,
-                                           Wc=strip(Wk, "encoder."), layer_out=tuple(y[B:] for y in Ys))
-        yk, _ = E.maxmean_forward(dt, Hk)
-        k = E.linear_fwd(dt, yk, Wk["fc.weight"], B, wq.shape[0], wq.shape[1], bias=ek.fc.bias.data, out_f32=1)
-        if ddp:
-            k = self._batch_unshuffle_ddp(k, idx_unshuffle)
+        self._key_stream.join(dev)
+        k.record_stream(main)
         # ---- the three Barlow heads are independent of each other and of the MoCo head: one side stream each
         G = flat.grad_dict
-        main = torch.cuda.current_stream()
         dys = [None, None, None]
         for i, p in enumerate((self.p1, self.p2, self.p3)):
             st = self._streams(dev)[i]
