@@ -35,6 +35,7 @@ struct GemmArgs {
     int out_f32;              // C is float even when T is bf16
     int atomic;               // C (float) += via atomicAdd (split-K / multi-source accumulation)
     int ksplit;               // gridDim.z
+    unsigned a_bytes, b_bytes; // extents of A and B for the buffer descriptors (hardware bounds check)
 };
 
 template <typename T> struct Mma;
@@ -56,21 +57,35 @@ template <> struct Mma<float> {
 template <typename T, bool TRANS>
 struct Stage {
     Vec8<T> r[2];
+    // Branch-free staging loads: a raw buffer load per 16 bytes, out-of-range vectors get an offset past the
+    // descriptor's extent and come back as zeros (no exec-masked branches -> the compiler keeps counted vmcnt waits).
     // rows = extent of the row dimension (M or N); kend = exclusive K bound of this split
-    __device__ __forceinline__ void load(const T* __restrict__ base, long ld, int row0, int rows, int k0, int kend) {
+    __device__ __forceinline__ static Vec8<bf16> bload16(__amdgpu_buffer_rsrc_t rs, unsigned off) {
+        Vec8<bf16> r;
+        r.v = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 0));
+        return r;
+    }
+    __device__ __forceinline__ static Vec8<float> bload32(__amdgpu_buffer_rsrc_t rs, unsigned off) {
+        Vec8<float> r;
+        r.lo = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 0));
+        r.hi = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, off + 16u, 0, 0));
+        return r;
+    }
+    __device__ __forceinline__ void load(__amdgpu_buffer_rsrc_t rs, long ld, int row0, int rows, int k0, int kend) {
         const int t = threadIdx.x;
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int v = t + i * 256;
-            if (!TRANS) {
-                const int row = row0 + (v >> 2), k = k0 + (v & 3) * 8;
-                r[i] = (row < rows && k < kend) ? Vec8<T>::load(base + (long)row * ld + k) : Vec8<T>::zero();
-            } else {
-                const int k = k0 + (v >> 4), row = row0 + (v & 15) * 8;
-                r[i] = (row < rows && k < kend) ? Vec8<T>::load(base + (long)k * ld + row) : Vec8<T>::zero();
-            }
+            int row, k;
+            long idx;
+            if (!TRANS) { row = row0 + (v >> 2); k = k0 + (v & 3) * 8; idx = (long)row * ld + k; }
+            else        { k = k0 + (v >> 4); row = row0 + (v & 15) * 8; idx = (long)k * ld + row; }
+            const unsigned off = (row < rows && k < kend) ? (unsigned)(idx * (long)sizeof(T)) : 0xFFFFFFE0u;
+            r[i] = select_load(rs, off, (T*)nullptr);
         }
     }
+    __device__ __forceinline__ static Vec8<bf16> select_load(__amdgpu_buffer_rsrc_t rs, unsigned off, bf16*) { return bload16(rs, off); }
+    __device__ __forceinline__ static Vec8<float> select_load(__amdgpu_buffer_rsrc_t rs, unsigned off, float*) { return bload32(rs, off); }
     __device__ __forceinline__ void put(T* lds) const {
         const int t = threadIdx.x;
 #pragma unroll
@@ -125,8 +140,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
     if (ks0 >= ks1) return;
     const int kend = min(g.K, ks1 * BK);
 
-    const T* A = static_cast<const T*>(g.A);
-    const T* B = static_cast<const T*>(g.B);
+    const __amdgpu_buffer_rsrc_t A = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(g.A), 0, g.a_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t B = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(g.B), 0, g.b_bytes, 0x00020000);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
 
@@ -138,6 +153,9 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
+    // Double-buffered LDS + one register stage: the loads of step k+1 are issued before the MFMAs of step k and land in
+    // LDS after them (counted vmcnt, no branches).  A second register stage (prefetch distance 2) was measured slower:
+    // hipcc aliases the staging and fragment registers and drains vmcnt at the loop back-edge (gpurun_out/gemm_d2.log).
     SA sa; SB sb;
     sa.load(A, g.lda, bm, g.M, ks0 * BK, kend);
     sb.load(B, g.ldb, bn, g.N, ks0 * BK, kend);
@@ -231,8 +249,12 @@ extern "C" int audiossl_gemm(int dtype, int trans_a, int trans_b, int M, int N, 
     // vector (8-element) dimension of each operand must be a multiple of 8 and its rows 16-byte aligned
     ASSL_REQUIRE((trans_a ? M : K) % 8 == 0 && (trans_b ? N : K) % 8 == 0);
     if (!ASSL_ALIGNED16(A) || !ASSL_ALIGNED16(B) || lda % 8 || ldb % 8) return ASSL_EALIGN;
+    const long esz = dtype == 0 ? 4 : 2;
+    const long a_ext = (trans_a ? ((long)(K - 1) * lda + M) : ((long)(M - 1) * lda + K)) * esz;
+    const long b_ext = (trans_b ? ((long)(K - 1) * ldb + N) : ((long)(N - 1) * ldb + K)) * esz;
+    ASSL_REQUIRE(a_ext < 0xFFFFFF00L && b_ext < 0xFFFFFF00L);            // 32-bit buffer offsets
     GemmArgs g{A, B, C, M, N, K, lda, ldb, ldc, alpha, bias, relu, keep, ldk, keep_scale, gate, ldg,
-               (dtype == 0) ? 1 : out_f32, atomic, ksplit};
+               (dtype == 0) ? 1 : out_f32, atomic, ksplit, (unsigned)a_ext, (unsigned)b_ext};
     hipStream_t s = static_cast<hipStream_t>(stream);
     return dtype == 0 ? dispatch<float>(g, trans_a, trans_b, s) : dispatch<bf16>(g, trans_a, trans_b, s);
 }
