@@ -37,3 +37,51 @@ class HipSGD(torch.optim.Optimizer):
         self.steps = sd["steps"]
         for fg, m in zip(self.flat_groups, sd["momentum"]):
             fg.momentum = None if m is None else m.to(fg.data.device).clone()
+
+
+class HipLARS(torch.optim.Optimizer):
+    """LARS of `extras/delores-s/multi_proc.py:4-43` on flat parameter groups: two launches per group (per-tensor
+    norms, then the fused trust-ratio / momentum / update).  `lr_weights` applies to tensors with ndim > 1, `lr_biases`
+    to 1-D tensors (the reference's two param groups, `adjust_learning_rate` :45-57)."""
+
+    def __init__(self, flat_groups, params, lr_weights, lr_biases=None, weight_decay=0.0, momentum=0.9, eta=0.001,
+                 weight_decay_filter=False, lars_adaptation_filter=False):
+        super().__init__(params, dict(lr=lr_weights, weight_decay=weight_decay, momentum=momentum, eta=eta))
+        self.flat_groups = list(flat_groups)
+        self.lr_weights, self.lr_biases = lr_weights, lr_weights if lr_biases is None else lr_biases
+        self.wd_filter, self.adapt_filter = weight_decay_filter, lars_adaptation_filter
+        self.grad_scale = 1.0
+        self._tables = {}
+
+    def _table(self, fg):
+        import numpy as np
+        key = id(fg)
+        if key not in self._tables:
+            seg = np.zeros(len(fg.params), dtype=[("off", "<i8"), ("n", "<i8"), ("flags", "<i4"), ("pad", "<i4")])
+            for i, (p, o) in enumerate(zip(fg.params, fg.offsets)):
+                is1d = p.ndim == 1
+                seg[i] = (o, p.numel(), (1 if (not self.wd_filter or not is1d) else 0) |
+                          (2 if (not self.adapt_filter or not is1d) else 0), 0)
+            dev = fg.data.device
+            self._tables[key] = (torch.from_numpy(seg.view(np.uint8)).to(dev), [p.ndim == 1 for p in fg.params],
+                                 torch.empty(2 * len(fg.params), dtype=torch.float64, device=dev))
+        return self._tables[key]
+
+    def set_lr(self, lr_weights, lr_biases):
+        self.lr_weights, self.lr_biases = lr_weights, lr_biases
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        g0 = self.param_groups[0]
+        for fg in self.flat_groups:
+            if fg.momentum is None:
+                fg.momentum = torch.zeros_like(fg.data)
+            seg, is1d, norms = self._table(fg)
+            lr = torch.tensor([self.lr_biases if b else self.lr_weights for b in is1d], dtype=torch.float32, device=fg.data.device)
+            N.call("lars_step", fg.data, fg.grad, fg.momentum, seg, len(is1d), lr, float(g0["weight_decay"]),
+                   float(g0["momentum"]), float(g0["eta"]), float(self.grad_scale), norms)
+
+    def zero_grad(self, set_to_none=True):
+        for fg in self.flat_groups:
+            for p in fg.params:
+                p.grad = None

@@ -168,6 +168,29 @@ int audiossl_bn_eval_affine(const float* gamma, const float* beta, const float* 
                             float eps, int C, float* scale, float* shift, void* stream);
 int audiossl_axpy(float* y, const float* x, float a, long n, void* stream);
 
+/* ---- K14 NT-Xent / ClusterLoss: extras/slicer/contrastive_loss.py:6-92 -----------------------------------------
+ * sim [N][N] fp32 = z z^T / tau from audiossl_gemm (N = 2B; positives at (r + B) mod N; the diagonal is excluded).
+ * fwd: lse[r] and loss += mean_r(lse_r - sim[r][pos]).  bwd: dsim = (softmax - onehot_pos) * gscale, 0 on the diagonal. */
+int audiossl_ntxent_fwd(const float* sim, int N, int B, float* lse, float* loss_out, void* stream);
+int audiossl_ntxent_bwd(int dtype, const float* sim, const float* lse, int N, int B, float gscale, void* dsim, void* stream);
+
+/* ---- K15/K16 DeepCluster-v2: extras/decar-v2/utils.py:291-318 (k-means E/M steps), main.py:228-233 (prototype CE) ----
+ * row_argmax: assign[r] = first argmax of dot[r][:] (dot = mem * centroids^T from audiossl_gemm).
+ * kmeans_accumulate: sums[a] += x[r], counts[a] += 1 (zeroed inside).  kmeans_update: mean + L2-normalise, empty
+ * clusters keep their previous centroid.  ce_rows: CrossEntropyLoss(ignore_index) forward + dlogits. */
+int audiossl_row_argmax(const float* dot, long N, int K, long long* assign, void* stream);
+int audiossl_kmeans_accumulate(const float* x, const long long* assign, long N, int K, int D, float* sums, int* counts,
+                               void* stream);
+int audiossl_kmeans_update(const float* sums, const int* counts, int K, int D, float* centroids, void* stream);
+int audiossl_ce_rows(int dtype, const float* logits, const long long* target, int B, int K, int ignore_index, int* cnt,
+                     float* loss_out, void* dlogits, void* stream);
+
+/* ---- LARS: extras/delores-s/multi_proc.py:4-43, on the flat parameter buffer ---------------------------------------
+ * seg: n_seg x {int64 offset, int64 numel, int32 flags (bit0 weight decay, bit1 trust ratio), int32 pad} (device);
+ * lr: per-segment learning rate (device); norms: 2*n_seg doubles of scratch. */
+int audiossl_lars_step(float* p, const float* g, float* mu, const void* seg, int n_seg, const float* lr, float weight_decay,
+                       float momentum, float eta, float grad_scale, double* norms, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
