@@ -149,3 +149,23 @@ def _flat_allreduce_fn(rank, world):
 def test_flat_gradient_allreduce_is_one_collective():
     (ga, n), (gb, _) = _run(_flat_allreduce_fn)
     assert np.all(ga == 3.0) and np.all(gb == 3.0) and n % 64 == 0
+
+
+def _kmeans_fn(rank, world):
+    """DeepCluster-v2 M step sharded over ranks == single-process k-means on the concatenated memory (C7-C8)."""
+    from oracle import fill, kmeans as OK
+    mem = torch.nn.functional.normalize(torch.from_numpy(fill.normalish((256, 32), 5)).abs(), dim=1)
+    init = mem[:8].clone()
+    dist.broadcast(init, 0)
+
+    def ar(t):
+        t = t.clone()
+        dist.all_reduce(t)
+        return t
+    c, a = OK.cluster_memory(mem[rank * 128:(rank + 1) * 128], init, n_iters=4, all_reduce=ar)
+    c_full, a_full = OK.cluster_memory(mem, init, n_iters=4)
+    return bool(torch.allclose(c, c_full, atol=1e-6)), bool(torch.equal(a, a_full[rank * 128:(rank + 1) * 128]))
+
+
+def test_distributed_kmeans_equals_single_process():
+    assert _run(_kmeans_fn) == [(True, True), (True, True)]

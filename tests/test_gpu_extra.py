@@ -74,9 +74,10 @@ def test_lars_vs_reference_golden(golden):
 def test_spherical_kmeans_vs_oracle():
     from src.upstream.decar_v2.kmeans import cluster_memory, spherical_kmeans
     Nn, D, K = 4096, 512, 64
-    mem = torch.nn.functional.normalize(torch.from_numpy(fill.normalish((Nn, D), 11)), dim=1)
+    mem = torch.nn.functional.normalize(torch.from_numpy(fill.normalish((Nn, D), 11)).abs() + 0.05 *
+                                        torch.from_numpy(fill.normalish((Nn, D), 12)), dim=1)
     init = mem[torch.arange(K) * 7].clone()
-    init[5] = -mem.mean(0) / mem.mean(0).norm()              # a centroid nobody is closest to: stays empty
+    init[5] = -torch.ones(D) / D ** 0.5                       # negative dot with every (mostly positive) point: stays empty
     c_ref, a_ref = OK.cluster_memory(mem, init, n_iters=10)
     c, a = spherical_kmeans(mem.cuda(), K, 10, centroids=init.cuda())
     agree = float((a.cpu() == a_ref).float().mean())

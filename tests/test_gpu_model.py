@@ -218,3 +218,77 @@ def test_delores_m_b32_vs_oracle(cfg_m, prec):
         gp = dict(em.named_parameters())[n].grad.float().cpu()
         gr = dict(ref.named_parameters())[n].grad
         assert rel_l2(gp, gr) < (2e-3 if prec == "fp32" else 0.25), n
+
+
+# ------------------------------------------------------------------------------------------------ harness / checkpoints
+def _synth_csv(tmp_path, n=40):
+    import pandas as pd
+    from scipy.io import wavfile
+    files = []
+    for i in range(n):
+        L = 16000 + (i % 5) * 3000 - (4000 if i % 7 == 0 else 0)            # some shorter, some longer than 1 s
+        w = fill.uniform((L,), 300 + i, -0.3, 0.3) + 0.2 * np.sin(2 * np.pi * (200 + 30 * i) * np.arange(L) / 16000).astype(np.float32)
+        p = str(tmp_path / f"clip{i}.wav")
+        wavfile.write(p, 16000, (w * 32767).astype(np.int16))
+        files.append(p)
+    csv = str(tmp_path / "train.csv")
+    pd.DataFrame({"files": files}).to_csv(csv, index=False)
+    return csv
+
+
+def test_train_upstream_end_to_end_and_downstream_probe(tmp_path, cfg_m):
+    """train_upstream.py's own entry points on a synthetic CSV (BASELINE config 1 plumbing, on the GPU), then the
+    checkpoint -> load_pretrained_encoder -> frozen linear probe path (config 5)."""
+    import importlib.util, os, types, yaml
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("train_upstream_hip", os.path.join(root, "audio-ssl_amd", "train_upstream.py"))
+    tu = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(tu)
+    cfg = _cfg(cfg_m, "bf16")
+    cfg["run"].update(batch_size=16, save_path=str(tmp_path / "run") + "/", max_epochs=1)
+    cfg_path = str(tmp_path / "cfg.yaml")
+    yaml.safe_dump(cfg, open(cfg_path, "w"))
+    final = str(tmp_path / "final.ckpt")
+    args = tu.get_args(["--input", _synth_csv(tmp_path), "--upstream", "delores_m", "-c", cfg_path, "--max_steps", "2",
+                        "--final_checkpoint", final])
+    import src.upstream.delores_m.upstream_expert as M
+    orig = M.Upstream_Expert.__init__
+
+    def small_queue(self, *a, **k):                      # 65536 % 16 == 0 already; keep the test light
+        k.setdefault("num_negatives", 1024)
+        orig(self, *a, **k)
+    M.Upstream_Expert.__init__ = small_queue
+    try:
+        trainer = tu.main(args)
+    finally:
+        M.Upstream_Expert.__init__ = orig
+    assert trainer.global_step == 2 and os.path.exists(final)
+    ck = torch.load(final, map_location="cpu", weights_only=True)
+    assert "encoder_q.encoder.features_1.0.weight" in ck["state_dict"] and "queue_ptr" in ck["state_dict"]
+    assert int(ck["state_dict"]["queue_ptr"]) == 32
+    # ---- downstream: frozen encoder + linear head from the checkpoint
+    from src.downstream import DownstreamEncoder
+    from src.encoder import AudioNTT2020Task6
+    from src.utils import load_pretrained_encoder, freeze_encoder
+    dcfg = {"downstream": {"finetune_layer": -1, "base_encoder": {"return_all_layers": False, "output_dim": 2048},
+                           "input": {"n_mels": 64}}}
+    model = DownstreamEncoder(dcfg, None, AudioNTT2020Task6, 35).cuda()
+    freeze_encoder(model)
+    load_pretrained_encoder(model, types.SimpleNamespace(upstream="delores_m", checkpoint=final))
+    got = model.encoder.state_dict()["fc.3.weight"].cpu()
+    assert torch.equal(got, ck["state_dict"]["encoder_q.encoder.fc.3.weight"])
+    model.eval()
+    x = views(4, 96, 77).cuda()
+    logits = model(x)
+    assert logits.shape == (4, 35) and torch.isfinite(logits).all()
+    # oracle: same weights, eval mode
+    ref = OM.AudioNTT2020Task6(64, 2048, False)
+    ref.load_state_dict({k: v.cpu() for k, v in model.encoder.state_dict().items()})
+    ref.eval()
+    with torch.no_grad():
+        want = torch.nn.functional.linear(ref(x.cpu()).mean(1), model.final.weight.cpu(), model.final.bias.cpu())
+    assert rel_l2(logits.float().cpu(), want) < 3e-2
+    # the head trains (encoder frozen): gradients reach `final` only
+    model.train()
+    model(x).float().sum().backward()
+    assert model.final.weight.grad is not None and all(p.grad is None for p in model.encoder.parameters())
