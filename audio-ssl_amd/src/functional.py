@@ -54,11 +54,16 @@ class LinearFn(torch.autograd.Function):
         M, K = x.shape
         Nout = Wc.shape[0]
         g = gy.to(x.dtype).contiguous()
-        dW = torch.zeros(Nout, K, dtype=torch.float32, device=x.device)
-        E.linear_bwd_w(dt, g, x, dW, M, Nout, K)
+        Np = (Nout + 63) // 64 * 64                 # the kernels vectorise by 8 (GEMM) / 64 (column sums): pad the class axis
+        if Np != Nout:
+            g = torch.nn.functional.pad(g, (0, Np - Nout))
+            Wc = torch.nn.functional.pad(Wc, (0, 0, 0, Np - Nout))
+        dW = torch.zeros(Np, K, dtype=torch.float32, device=x.device)
+        E.linear_bwd_w(dt, g, x, dW, M, Np, K)
         db = None
         if ctx.has_bias:
-            db = torch.zeros(Nout, dtype=torch.float32, device=x.device)
-            E.colsum_add(dt, g, M, Nout, db)
-        dx = E.linear_bwd_x(dt, g, Wc, M, Nout, K)
-        return dx, dW, db
+            db = torch.zeros(Np, dtype=torch.float32, device=x.device)
+            E.colsum_add(dt, g, M, Np, db)
+            db = db[:Nout]
+        dx = E.linear_bwd_x(dt, g, Wc, M, Np, K)
+        return dx, dW[:Nout], db

@@ -30,11 +30,12 @@ class UpstreamModule(nn.Module):
         self.logged = {}
 
     def save_hyperparameters(self):
-        frame = inspect.currentframe().f_back
-        sig = inspect.signature(type(self).__init__)
+        frame = inspect.currentframe().f_back                       # the __init__ that called us
+        code = frame.f_code
+        names = code.co_varnames[:code.co_argcount + code.co_kwonlyargcount]
         loc = frame.f_locals
         simple = (int, float, str, bool, type(None), dict, list, tuple)
-        for k in sig.parameters:
+        for k in names:
             if k in loc and k not in ("self", "args", "kwargs") and isinstance(loc[k], simple):
                 self.hparams[k] = loc[k]
 
