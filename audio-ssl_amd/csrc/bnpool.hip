@@ -131,9 +131,9 @@ __global__ __launch_bounds__(256) void tmean_fwd_kernel(const T_* __restrict__ P
 // Backward, pass 1: dbeta_c = sum routed grad, dgamma_c = sum routed grad * xhat   (fp32 atomics into stat[2][64])
 // Backward, pass 2: dY = gamma*rstd * (dyhat_routed - dbeta/n - xhat*dgamma/n) at EVERY position (incl. the
 // unpooled last time row when Ti is odd).
-template <typename T_, bool APPLY>
-__global__ __launch_bounds__(256) void bn_relu_pool_bwd_kernel(const T_* __restrict__ Y, const T_* __restrict__ dP,
-                                                               const T_* __restrict__ dxl, float inv_To,
+template <typename T_, bool APPLY, typename TG>
+__global__ __launch_bounds__(256) void bn_relu_pool_bwd_kernel(const T_* __restrict__ Y, const TG* __restrict__ dP,
+                                                               const TG* __restrict__ dxl, float inv_To,
                                                                const float* __restrict__ scale, const float* __restrict__ shift,
                                                                const float* __restrict__ mean, const float* __restrict__ rstd,
                                                                float* __restrict__ stat, float inv_count,
@@ -162,11 +162,11 @@ __global__ __launch_bounds__(256) void bn_relu_pool_bwd_kernel(const T_* __restr
             if (APPLY) { cb[i] = stat[c] * inv_count; cg[i] = stat[64 + c] * inv_count; }
         }
         if (pooled) {
-            const Vec8<T_> gp = Vec8<T_>::load(dP + ((((long)n * To + tq) * Fo + fo) * 64 + c8 * 8));
+            const Vec8<TG> gp = Vec8<TG>::load(dP + ((((long)n * To + tq) * Fo + fo) * 64 + c8 * 8));
 #pragma unroll
             for (int i = 0; i < 8; ++i) g[i] = gp.get(i);
             if (dxl) {
-                const Vec8<T_> gx = Vec8<T_>::load(dxl + ((long)n * Fo * 64 + fo * 64 + c8 * 8));
+                const Vec8<TG> gx = Vec8<TG>::load(dxl + ((long)n * Fo * 64 + fo * 64 + c8 * 8));
 #pragma unroll
                 for (int i = 0; i < 8; ++i) g[i] += gx.get(i) * inv_To;
             }
@@ -336,21 +336,23 @@ __global__ void add_stat_kernel(const float* __restrict__ stat, float* dgamma, f
 }
 }  // namespace
 
-extern "C" int audiossl_bn_relu_pool_bwd(int dtype, const void* Y, const void* dP, const void* dxl, const float* scale,
+extern "C" int audiossl_bn_relu_pool_bwd(int dtype, int gdtype, const void* Y, const void* dP, const void* dxl, const float* scale,
                                          const float* shift, const float* mean, const float* rstd, float* stat, void* dY,
                                          float* dgamma, float* dbeta, int N, int Ti, int Fi, void* stream) {
     ASSL_REQUIRE(Y && dP && scale && shift && mean && rstd && stat && dY && dgamma && dbeta);
-    ASSL_REQUIRE(N > 0 && Ti >= 2 && Fi >= 2 && (Fi % 2) == 0 && (dtype == 0 || dtype == 1));
+    ASSL_REQUIRE(N > 0 && Ti >= 2 && Fi >= 2 && (Fi % 2) == 0 && (dtype == 0 || dtype == 1) && (gdtype == 0 || gdtype == dtype));
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (hipMemsetAsync(stat, 0, sizeof(float) * 128, s) != hipSuccess) return ASSL_ELAUNCH;
     const long total = (long)N * ((Ti + 1) / 2) * (Fi / 2) * 8;
     const int grid = ceil_div(total, 256);
     const float inv_To = 1.f / (float)(Ti / 2);
     const float inv_count = (float)(1.0 / ((double)N * Ti * Fi));
-#define BW(TT, AP) hipLaunchKernelGGL((bn_relu_pool_bwd_kernel<TT, AP>), dim3(grid), dim3(256), 0, s, static_cast<const TT*>(Y), \
-        static_cast<const TT*>(dP), static_cast<const TT*>(dxl), inv_To, scale, shift, mean, rstd, stat, inv_count,             \
+#define BW(TT, AP, TG) hipLaunchKernelGGL((bn_relu_pool_bwd_kernel<TT, AP, TG>), dim3(grid), dim3(256), 0, s, static_cast<const TT*>(Y), \
+        static_cast<const TG*>(dP), static_cast<const TG*>(dxl), inv_To, scale, shift, mean, rstd, stat, inv_count,                  \
         static_cast<TT*>(dY), N, Ti, Fi)
-    if (dtype == 0) { BW(float, false); BW(float, true); } else { BW(bf16, false); BW(bf16, true); }
+    if (dtype == 0) { BW(float, false, float); BW(float, true, float); }
+    else if (gdtype == 0) { BW(bf16, false, float); BW(bf16, true, float); }
+    else { BW(bf16, false, bf16); BW(bf16, true, bf16); }
 #undef BW
     hipLaunchKernelGGL(add_stat_kernel, dim3(1), dim3(64), 0, s, stat, dgamma, dbeta);
     ASSL_LAUNCH_CHECK();

@@ -30,7 +30,7 @@ typedef __attribute__((address_space(3))) bf16x4* lds4_t;
 
 struct ConvArgs {
     const bf16* X; const bf16* W; const float* bias; bf16* Y; double* sum; double* sumsq;
-    int Ti, rows_total, tiles;
+    int Ti, rows_total, tiles, out_f32;
 };
 
 template <int FI, int PITCH>
@@ -152,7 +152,8 @@ __global__ __launch_bounds__(256, 1) void conv3x3_kernel(ConvArgs a) {
                         const float v = acc[i][j][r] + bias;
                         ssum[j] += v;
                         ssq[j] += v * v;
-                        a.Y[((long)g * FI + f) * CH + co] = (bf16)v;
+                        if (a.out_f32) reinterpret_cast<float*>(a.Y)[((long)g * FI + f) * CH + co] = v;
+                        else a.Y[((long)g * FI + f) * CH + co] = (bf16)v;
                     }
                 }
             }
@@ -279,8 +280,9 @@ int set_lds(K kernel, size_t bytes) {
 
 // X, W, Y bf16.  W = packed [64][576] (audiossl_pack_conv_w: Wf for the forward, Wd for the data gradient).
 // bias / sum / sumsq may be NULL; sum and sumsq (fp64 [64]) are zeroed here.  Fi must be 32 or 16.
-extern "C" int audiossl_conv3x3_fwd(const void* X, const void* W, const float* bias, void* Y, double* sum, double* sumsq,
-                                    int N, int Ti, int Fi, void* stream) {
+// out_f32: Y is float (used for the data gradient that feeds a BatchNorm backward).
+extern "C" int audiossl_conv3x3_fwd(const void* X, const void* W, const float* bias, void* Y, int out_f32, double* sum,
+                                    double* sumsq, int N, int Ti, int Fi, void* stream) {
     ASSL_REQUIRE(X && W && Y && N > 0 && Ti > 0 && (Fi == 32 || Fi == 16) && (!sum == !sumsq));
     if (!ASSL_ALIGNED16(X) || !ASSL_ALIGNED16(W) || !ASSL_ALIGNED16(Y)) return ASSL_EALIGN;
     hipStream_t s = static_cast<hipStream_t>(stream);
@@ -289,7 +291,7 @@ extern "C" int audiossl_conv3x3_fwd(const void* X, const void* W, const float* b
         if (hipMemsetAsync(sumsq, 0, sizeof(double) * 64, s) != hipSuccess) return ASSL_ELAUNCH;
     }
     const int rows = N * Ti, TT = 256 / Fi, tiles = (rows + TT - 1) / TT;
-    ConvArgs a{static_cast<const bf16*>(X), static_cast<const bf16*>(W), bias, static_cast<bf16*>(Y), sum, sumsq, Ti, rows, tiles};
+    ConvArgs a{static_cast<const bf16*>(X), static_cast<const bf16*>(W), bias, static_cast<bf16*>(Y), sum, sumsq, Ti, rows, tiles, out_f32};
     const int grid = tiles < 256 ? tiles : 256;
     static bool attr32 = false, attr16 = false;
     if (Fi == 32) {

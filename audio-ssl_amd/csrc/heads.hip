@@ -36,9 +36,9 @@ __global__ __launch_bounds__(256) void maxmean_fwd_kernel(const T_* __restrict__
     o.store(y + n * D + d8 * 8);
 }
 
-// dA[n][t][d] = (dy[n][d]/Tt + dy[n][d]*[t==arg]) * (H[n][t][d] > 0)
-template <typename T_>
-__global__ __launch_bounds__(256) void maxmean_bwd_kernel(const T_* __restrict__ dy, const uint8_t* __restrict__ arg,
+// dA[n][t][d] = (dy[n][d]/Tt + dy[n][d]*[t==arg]) * (H[n][t][d] > 0)      (TG = type of the incoming gradient dy)
+template <typename T_, typename TG>
+__global__ __launch_bounds__(256) void maxmean_bwd_kernel(const TG* __restrict__ dy, const uint8_t* __restrict__ arg,
                                                           const T_* __restrict__ H, T_* __restrict__ dA, int N, int Tt, int D) {
     const long idx = (long)blockIdx.x * 256 + threadIdx.x;          // over N * Tt * D/8
     const int D8 = D / 8;
@@ -47,7 +47,7 @@ __global__ __launch_bounds__(256) void maxmean_bwd_kernel(const T_* __restrict__
     const long r = idx / D8;
     const int t = (int)(r % Tt);
     const long n = r / Tt;
-    const Vec8<T_> g = Vec8<T_>::load(dy + n * D + d8 * 8);
+    const Vec8<TG> g = Vec8<TG>::load(dy + n * D + d8 * 8);
     const Vec8<T_> h = Vec8<T_>::load(H + idx * 8);
     Vec8<T_> o;
     const float inv = 1.f / (float)Tt;
@@ -85,8 +85,8 @@ __global__ __launch_bounds__(256) void colbn_fwd_kernel(const T_* __restrict__ a
 
 // stats: sg[c] = sum_b g, sgx[c] = sum_b g*xhat with g = dh * (act > 0 if relu), xhat = (a-mean)*rstd   (fp64 atomics)
 // Same slab mapping as colstats: a block = 64 columns x 32 rows per iteration, blockIdx.y = slab.
-template <typename T_>
-__global__ __launch_bounds__(256) void colbn_bwd_stats_kernel(const T_* __restrict__ a, const T_* __restrict__ dh,
+template <typename T_, typename TG>
+__global__ __launch_bounds__(256) void colbn_bwd_stats_kernel(const T_* __restrict__ a, const TG* __restrict__ dh,
                                                               const float* __restrict__ scale, const float* __restrict__ shift,
                                                               const float* __restrict__ mean, const float* __restrict__ rstd,
                                                               int relu, long M, int C, int rows_per_block,
@@ -107,7 +107,7 @@ __global__ __launch_bounds__(256) void colbn_bwd_stats_kernel(const T_* __restri
     }
     for (long r = rb + r0; r < re; r += 32) {
         const Vec8<T_> va = Vec8<T_>::load(a + r * C + col0);
-        const Vec8<T_> vg = Vec8<T_>::load(dh + r * C + col0);
+        const Vec8<TG> vg = Vec8<TG>::load(dh + r * C + col0);
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             const float x = va.get(i);
@@ -130,8 +130,8 @@ __global__ __launch_bounds__(256) void colbn_bwd_stats_kernel(const T_* __restri
 }
 
 // da = scale * (g - sg/M - xhat*sgx/M); rows handled by block 0 also accumulate the parameter grads.
-template <typename T_>
-__global__ __launch_bounds__(256) void colbn_bwd_apply_kernel(const T_* __restrict__ a, const T_* __restrict__ dh,
+template <typename T_, typename TG>
+__global__ __launch_bounds__(256) void colbn_bwd_apply_kernel(const T_* __restrict__ a, const TG* __restrict__ dh,
                                                               const float* __restrict__ scale, const float* __restrict__ shift,
                                                               const float* __restrict__ mean, const float* __restrict__ rstd,
                                                               int relu, long M, int C, int groups, const double* __restrict__ sg,
@@ -149,7 +149,7 @@ __global__ __launch_bounds__(256) void colbn_bwd_apply_kernel(const T_* __restri
         scale += go; shift += go; mean += go; rstd += go; sg += go; sgx += go;
     }
     const Vec8<T_> va = Vec8<T_>::load(a + idx * 8);
-    const Vec8<T_> vg = Vec8<T_>::load(dh + idx * 8);
+    const Vec8<TG> vg = Vec8<TG>::load(dh + idx * 8);
     Vec8<T_> o;
     const float invM = 1.f / (float)M;
 #pragma unroll
@@ -353,12 +353,14 @@ extern "C" int audiossl_maxmean_fwd(int dtype, const void* H, void* y, uint8_t* 
     ASSL_LAUNCH_CHECK();
 }
 
-extern "C" int audiossl_maxmean_bwd(int dtype, const void* dy, const uint8_t* arg, const void* H, void* dA, int N, int Tt, int D,
-                                    void* stream) {
+extern "C" int audiossl_maxmean_bwd(int dtype, int gdtype, const void* dy, const uint8_t* arg, const void* H, void* dA, int N, int Tt,
+                                    int D, void* stream) {
     ASSL_REQUIRE(dy && arg && H && dA && N > 0 && Tt > 0 && D > 0 && (D % 8) == 0 && (dtype == 0 || dtype == 1));
+    ASSL_REQUIRE(gdtype == 0 || gdtype == dtype);
     const long total = (long)N * Tt * D / 8;
-    if (dtype == 0) hipLaunchKernelGGL(maxmean_bwd_kernel<float>, GRID1(total), dim3(256), 0, S_(stream), (const float*)dy, arg, (const float*)H, (float*)dA, N, Tt, D);
-    else            hipLaunchKernelGGL(maxmean_bwd_kernel<bf16>, GRID1(total), dim3(256), 0, S_(stream), (const bf16*)dy, arg, (const bf16*)H, (bf16*)dA, N, Tt, D);
+    if (dtype == 0) hipLaunchKernelGGL((maxmean_bwd_kernel<float, float>), GRID1(total), dim3(256), 0, S_(stream), (const float*)dy, arg, (const float*)H, (float*)dA, N, Tt, D);
+    else if (gdtype == 0) hipLaunchKernelGGL((maxmean_bwd_kernel<bf16, float>), GRID1(total), dim3(256), 0, S_(stream), (const float*)dy, arg, (const bf16*)H, (bf16*)dA, N, Tt, D);
+    else            hipLaunchKernelGGL((maxmean_bwd_kernel<bf16, bf16>), GRID1(total), dim3(256), 0, S_(stream), (const bf16*)dy, arg, (const bf16*)H, (bf16*)dA, N, Tt, D);
     ASSL_LAUNCH_CHECK();
 }
 
@@ -372,23 +374,23 @@ extern "C" int audiossl_colbn_fwd(int dtype, const void* a, const float* scale, 
 }
 
 // tmp: 2*C doubles of scratch.  dgamma/dbeta may be null (affine=False); otherwise accumulated (+=).
-extern "C" int audiossl_colbn_bwd(int dtype, const void* a, const void* dh, const float* scale, const float* shift,
+extern "C" int audiossl_colbn_bwd(int dtype, int gdtype, const void* a, const void* dh, const float* scale, const float* shift,
                                   const float* mean, const float* rstd, int relu, int groups, long M, int C, double* tmp,
                                   void* da, float* dgamma, float* dbeta, void* stream) {
     ASSL_REQUIRE(a && dh && scale && shift && mean && rstd && tmp && da && groups > 0 && M > 0 && C > 0 && (C % 8) == 0);
-    ASSL_REQUIRE((dtype == 0 || dtype == 1) && (C % 64) == 0);
+    ASSL_REQUIRE((dtype == 0 || dtype == 1) && (C % 64) == 0 && (gdtype == 0 || gdtype == dtype));
     hipStream_t s = S_(stream);
     if (hipMemsetAsync(tmp, 0, sizeof(double) * 2 * C * groups, s) != hipSuccess) return ASSL_ELAUNCH;
     const int rpb = M >= 4096 ? 256 : 64;
     dim3 grid(ceil_div(M, rpb), C / 64, groups);
     const long total = groups * M * C / 8;
     const long GC = (long)groups * C;
-#define CB(TT) do {                                                                                                                  \
-    hipLaunchKernelGGL(colbn_bwd_stats_kernel<TT>, grid, dim3(256), 0, s, (const TT*)a, (const TT*)dh, scale, shift, mean, rstd, relu, \
-                       M, C, rpb, tmp, tmp + GC);                                                                                     \
-    hipLaunchKernelGGL(colbn_bwd_apply_kernel<TT>, GRID1(total), dim3(256), 0, s, (const TT*)a, (const TT*)dh, scale, shift, mean,     \
-                       rstd, relu, M, C, groups, tmp, tmp + GC, (TT*)da, dgamma, dbeta); } while (0)
-    if (dtype == 0) CB(float); else CB(bf16);
+#define CB(TT, TG) do {                                                                                                              \
+    hipLaunchKernelGGL((colbn_bwd_stats_kernel<TT, TG>), grid, dim3(256), 0, s, (const TT*)a, (const TG*)dh, scale, shift, mean, rstd,  \
+                       relu, M, C, rpb, tmp, tmp + GC);                                                                               \
+    hipLaunchKernelGGL((colbn_bwd_apply_kernel<TT, TG>), GRID1(total), dim3(256), 0, s, (const TT*)a, (const TG*)dh, scale, shift,      \
+                       mean, rstd, relu, M, C, groups, tmp, tmp + GC, (TT*)da, dgamma, dbeta); } while (0)
+    if (dtype == 0) CB(float, float); else if (gdtype == 0) CB(bf16, float); else CB(bf16, bf16);
 #undef CB
     ASSL_LAUNCH_CHECK();
 }

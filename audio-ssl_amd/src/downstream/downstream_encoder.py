@@ -29,7 +29,7 @@ class MeanTFn(torch.autograd.Function):
         g = torch.empty(n * T, D, dtype=td, device=gy.device)
         never = torch.full((n, D), 255, dtype=torch.uint8, device=gy.device)       # no arg-max term: pure g / T
         ones = torch.ones(n, T, D, dtype=td, device=gy.device)
-        N.call("maxmean_bwd", dt, gy.to(td).contiguous(), never, ones, g, n, T, D)
+        N.call("maxmean_bwd", dt, N.F32, gy.float().contiguous(), never, ones, g, n, T, D)
         return g.view(n, T, D)
 
 

@@ -77,7 +77,7 @@ class _EncoderFn(torch.autograd.Function):
         G = {n: torch.zeros_like(p, dtype=torch.float32) for n, p in mod.named_parameters()}
 
         def prep(g, like):
-            return None if g is None else g.to(td).contiguous()
+            return None if g is None else g.float().contiguous()         # layer-mean gradients enter pool backwards: fp32
         gh = torch.zeros_like(c.H2.view(c.N, -1, c.d)) if gh is None else gh.to(td).contiguous()
         E.encoder_backward(c, G, dH2=gh.view(c.M, c.d), dx1=prep(g1, None), dx2=prep(g2, None), dx3=prep(g3, None))
         return (None, None, None) + tuple(G[n] for n, _ in mod.named_parameters())

@@ -76,12 +76,17 @@ def linear_bwd_w(dtype, dY, X, dW, M, Nout, K):
     gemm(dtype, 1, 1, Nout, K, M, dY, Nout, X, K, dW, K, out_f32=1, atomic=1, ksplit=_ksplit(Nout, K, M))
 
 
-def linear_bwd_x(dtype, dY, W, M, Nout, K, alpha=1.0, gate=None, out=None):
-    """dX[M,K] = alpha * dY[M,Nout] @ W[Nout,K]   (optionally zeroed where gate <= 0)"""
+def linear_bwd_x(dtype, dY, W, M, Nout, K, alpha=1.0, gate=None, out=None, out_f32=0):
+    """dX[M,K] = alpha * dY[M,Nout] @ W[Nout,K]   (optionally zeroed where gate <= 0).
+    out_f32: store the result in fp32 - used whenever dX feeds a BatchNorm / pooling backward (precision contract in
+    DESIGN.md section 6: such gradients are GEMM outputs, so fp32 is free; pure MFMA operands stay in `dtype`)."""
     if out is None:
-        out = _empty((M, K), N.torch_dtype(dtype), like=dY)
-    gemm(dtype, 0, 1, M, K, Nout, dY, Nout, W, K, out, K, alpha=alpha, gate=gate, ldg=K)
+        out = _empty((M, K), torch.float32 if (out_f32 or dtype == N.F32) else torch.bfloat16, like=dY)
+    gemm(dtype, 0, 1, M, K, Nout, dY, Nout, W, K, out, K, alpha=alpha, gate=gate, ldg=K, out_f32=out_f32)
     return out
+
+
+GD = N.F32     # storage type of gradients that enter a BatchNorm / pooling backward
 
 
 def colsum_add(dtype, X, M, C, dst, tmp=None):
@@ -134,7 +139,7 @@ def _conv_block_fwd(dtype, Pin, Nimg, Ti, Fi, W, bias, bn, train, update_running
     fused = dtype == N.BF16 and Fi in (16, 32)
     sq = _empty((2, 64), torch.float64, like=Pin) if (fused and train) else None
     if fused:
-        N.call("conv3x3_fwd", Pin, Wf, bias, Y, None if sq is None else sq[0], None if sq is None else sq[1], Nimg, Ti, Fi)
+        N.call("conv3x3_fwd", Pin, Wf, bias, Y, 0, None if sq is None else sq[0], None if sq is None else sq[1], Nimg, Ti, Fi)
     else:
         N.call("im2col3x3", dtype, Pin, col, Nimg, Ti, Fi)
         gemm(dtype, 0, 0, M, 64, 576, col, 576, Wf, 576, Y, 64, bias=bias)
@@ -229,7 +234,7 @@ def _conv_block_bwd(dtype, Y, dP, dxl, st, Nimg, Ti, Fi, Pin, Wd, G_w, G_gamma, 
     M = Nimg * Ti * Fi
     dY = _empty((M, 64), td, like=Y)
     stat = _empty((128,), torch.float32, like=Y)
-    N.call("bn_relu_pool_bwd", dtype, Y, dP, dxl, scale, shift, mean, rstd, stat, dY, G_gamma, G_beta, Nimg, Ti, Fi)
+    N.call("bn_relu_pool_bwd", dtype, GD, Y, dP, dxl, scale, shift, mean, rstd, stat, dY, G_gamma, G_beta, Nimg, Ti, Fi)
     # wgrad: dWp[co][tap*64+ci] = sum_pix dY[pix][co] * Pin[pix + off(tap)][ci]
     fused = dtype == N.BF16 and Fi in (16, 32)
     if fused:
@@ -247,9 +252,9 @@ def _conv_block_bwd(dtype, Y, dP, dxl, st, Nimg, Ti, Fi, Pin, Wd, G_w, G_gamma, 
     if not need_dx:
         return None
     # dgrad: dPin[pix][ci] = sum_{tap,co} dY[pix + off(tap)][co] * W[co][ci][8 - tap]
-    dPin = _empty((Nimg, Ti, Fi, 64), td, like=Y)
+    dPin = _empty((Nimg, Ti, Fi, 64), torch.float32, like=Y)            # feeds the previous block's BN backward: fp32
     if fused:
-        N.call("conv3x3_fwd", dY, Wd, None, dPin, None, None, Nimg, Ti, Fi)
+        N.call("conv3x3_fwd", dY, Wd, None, dPin, 1, None, None, Nimg, Ti, Fi)
     else:
         N.call("im2col3x3", dtype, dY, col, Nimg, Ti, Fi)
         gemm(dtype, 0, 0, M, 64, 576, col, 576, Wd, 576, dPin, 64)
@@ -259,7 +264,7 @@ def _conv_block_bwd(dtype, Y, dP, dxl, st, Nimg, Ti, Fi, Pin, Wd, G_w, G_gamma, 
 def encoder_backward(c, G, dA2=None, dH2=None, dx1=None, dx2=None, dx3=None):
     """Accumulate parameter gradients of one encoder_forward call into G (dict keyed like P, fp32).
     dA2: grad w.r.t. the pre-ReLU output of fc.3 (already ReLU-gated), or dH2: grad w.r.t. H2.
-    dx1..dx3: grads w.r.t. the temporal layer means (activation dtype) or None."""
+    dx1..dx3: grads w.r.t. the temporal layer means (fp32) or None."""
     dtype, Nimg, M, d, kin = c.dtype, c.N, c.M, c.d, c.kin
     T1, F1, T2, F2, T3, F3 = c.dims
     td = N.torch_dtype(dtype)
@@ -282,7 +287,7 @@ def encoder_backward(c, G, dA2=None, dH2=None, dx1=None, dx2=None, dx3=None):
         linear_bwd_w(dtype, dA1, c.P3, G["fc.0.weight"], M, d, kin)
         colsum_add(dtype, dA1, M, d, G["fc.0.bias"])
     WGRAD.run(dev, w1)
-    dP3 = linear_bwd_x(dtype, dA1, c.fw1, M, d, kin)
+    dP3 = linear_bwd_x(dtype, dA1, c.fw1, M, d, kin, out_f32=1)
     col = _col_buffer(dtype, Nimg, T1, F1, c.H2)
     keep = []
     dP2 = _conv_block_bwd(dtype, c.Y3, dP3, dx3, c.st3, Nimg, T2, F2, c.P2, c.W3d, G["features_3.0.weight"],
@@ -291,7 +296,7 @@ def encoder_backward(c, G, dA2=None, dH2=None, dx1=None, dx2=None, dx3=None):
                           G["features_2.1.weight"], G["features_2.1.bias"], True, col, keep)
     acc = _empty((64 * 11,), torch.float32, like=c.H2)
     P = c.P
-    N.call("conv1_bwd", dtype, c.img, Nimg, c.F, c.T, P["features_1.0.weight"].reshape(64, 9), P["features_1.0.bias"],
+    N.call("conv1_bwd", GD, c.img, Nimg, c.F, c.T, P["features_1.0.weight"].reshape(64, 9), P["features_1.0.bias"],
            P["features_1.1.weight"], c.sc1, c.sh1, c.mean1, c.rstd1, c.mom1, dP1, dx1, acc,
            G["features_1.0.weight"].view(64, 9), G["features_1.0.bias"], G["features_1.1.weight"], G["features_1.1.bias"])
     WGRAD.join(dev)            # dA2 / dA1 / dY* stay referenced until the side stream is ordered before us
@@ -308,10 +313,11 @@ def maxmean_forward(dtype, H2, out=None):
 
 
 def maxmean_backward(dtype, dy, arg, H2):
-    """-> dA2 [N*T3, d]: gradient w.r.t. the pre-ReLU fc.3 output (ReLU gate fused)."""
+    """dy [N, d] fp32 -> dA2 [N*T3, d] (activation dtype: it is only an MFMA operand afterwards): gradient w.r.t. the
+    pre-ReLU fc.3 output, ReLU gate fused."""
     Nimg, T3, d = H2.shape
     dA2 = _empty((Nimg * T3, d), N.torch_dtype(dtype), like=H2)
-    N.call("maxmean_bwd", dtype, dy, arg, H2, dA2, Nimg, T3, d)
+    N.call("maxmean_bwd", dtype, GD, dy, arg, H2, dA2, Nimg, T3, d)
     return dA2
 
 
@@ -361,21 +367,23 @@ def projector_backward(c, PP, G, dzn, dy_rows=None):
     M = groups * B
     td = N.torch_dtype(dtype)
     tmp = _empty((2 * groups * D,), torch.float64, like=dzn)
-    dz = _empty((M, D), td, like=dzn)
-    N.call("colbn_bwd", dtype, c.z, dzn, *c.st0, 0, groups, B, D, tmp, dz, None, None)
+    dz = _empty((M, D), td, like=c.z)
+    # gradients entering a BatchNorm backward (dzn, dh2, dh1) are fp32 GEMM outputs; its outputs (dz, da2, da1) are
+    # MFMA operands only and are stored in the activation dtype
+    N.call("colbn_bwd", dtype, GD, c.z, dzn, *c.st0, 0, groups, B, D, tmp, dz, None, None)
     linear_bwd_w(dtype, dz, c.h2, G["projector.6.weight"], M, D, D)
-    dh2 = linear_bwd_x(dtype, dz, c.W[2], M, D, D)
-    da2 = _empty((M, D), td, like=dzn)
-    N.call("colbn_bwd", dtype, c.a2, dh2, *c.st2, 1, groups, B, D, tmp, da2, G["projector.4.weight"], G["projector.4.bias"])
+    dh2 = linear_bwd_x(dtype, dz, c.W[2], M, D, D, out_f32=1)
+    da2 = _empty((M, D), td, like=c.z)
+    N.call("colbn_bwd", dtype, GD, c.a2, dh2, *c.st2, 1, groups, B, D, tmp, da2, G["projector.4.weight"], G["projector.4.bias"])
     linear_bwd_w(dtype, da2, c.h1, G["projector.3.weight"], M, D, D)
-    dh1 = linear_bwd_x(dtype, da2, c.W[1], M, D, D)
-    da1 = _empty((M, D), td, like=dzn)
-    N.call("colbn_bwd", dtype, c.a1, dh1, *c.st1, 1, groups, B, D, tmp, da1, G["projector.1.weight"], G["projector.1.bias"])
+    dh1 = linear_bwd_x(dtype, da2, c.W[1], M, D, D, out_f32=1)
+    da1 = _empty((M, D), td, like=c.z)
+    N.call("colbn_bwd", dtype, GD, c.a1, dh1, *c.st1, 1, groups, B, D, tmp, da1, G["projector.1.weight"], G["projector.1.bias"])
     linear_bwd_w(dtype, da1, c.y, G["projector.0.weight"], M, D, kin)
     rows = M if dy_rows is None else dy_rows
     if rows == 0:
         return None
-    return linear_bwd_x(dtype, da1, c.W[0], rows, D, kin)
+    return linear_bwd_x(dtype, da1, c.W[0], rows, D, kin, out_f32=1)
 
 
 def barlow_forward_backward(PP, G, Y, dtype, lambd, scale_loss, loss_out, need_dy1=True, need_dy2=True,
@@ -398,9 +406,9 @@ def barlow_forward_backward(PP, G, Y, dtype, lambd, scale_loss, loss_out, need_d
     N.call("barlow_loss", dtype, cmat, D, coef, 2.0 * coef / denom, dc, loss_out)
     if not backward:
         return None
-    dzn = _empty((2 * B, D), N.torch_dtype(dtype), like=Y)
-    gemm(dtype, 0, 0, B, D, D, zn2, D, dc, D, dzn[:B], D)      # dzn1[b,i] = sum_j zn2[b,j] dc[i,j]
-    gemm(dtype, 0, 1, B, D, D, zn1, D, dc, D, dzn[B:], D)      # dzn2[b,j] = sum_i zn1[b,i] dc[i,j]
+    dzn = _empty((2 * B, D), torch.float32, like=Y)            # enters the affine-free BatchNorm backward: fp32
+    gemm(dtype, 0, 0, B, D, D, zn2, D, dc, D, dzn[:B], D, out_f32=1)      # dzn1[b,i] = sum_j zn2[b,j] dc[i,j]
+    gemm(dtype, 0, 1, B, D, D, zn1, D, dc, D, dzn[B:], D, out_f32=1)      # dzn2[b,j] = sum_i zn1[b,i] dc[i,j]
     rows = 2 * B if need_dy2 else (B if need_dy1 else 0)
     return projector_backward(c, PP, G, dzn, rows)
 

@@ -29,7 +29,7 @@ class MaxMeanFn(torch.autograd.Function):
         gh = torch.empty_like(h)
         # gate-free variant: the ReLU gate belongs to the encoder's own backward, so route through an all-ones gate
         ones = torch.ones_like(h)
-        N.call("maxmean_bwd", dt, gy.to(h.dtype).contiguous(), arg, ones, gh.view(Nimg * T, d), Nimg, T, d)
+        N.call("maxmean_bwd", dt, N.F32, gy.float().contiguous(), arg, ones, gh.view(Nimg * T, d), Nimg, T, d)
         return gh
 
 

@@ -48,12 +48,13 @@ class _ProjectionFn(torch.autograd.Function):
         dy1 = dY[:B] if (dY is not None and need1) else None
         dy2 = dY[B:] if (dY is not None and need2) else None
         ctx.saved = (dy1, dy2, [G[n] for n, _ in mod.named_parameters()])
+        ctx.in_dtype = y1.dtype
         return loss[0].clone()
 
     @staticmethod
     def backward(ctx, g):
         dy1, dy2, grads = ctx.saved
-        return (None, None if dy1 is None else dy1 * g.to(dy1.dtype), None if dy2 is None else dy2 * g.to(dy2.dtype)) + \
+        return (None, None if dy1 is None else (dy1 * g).to(ctx.in_dtype), None if dy2 is None else (dy2 * g).to(ctx.in_dtype)) + \
             tuple(gr * g for gr in grads)
 
 

@@ -198,7 +198,7 @@ class Upstream_Expert(FusedExpertMixin, UpstreamModule):
             Gq = G("encoder_q.")
             E.linear_bwd_w(dt, dq, yq, Gq["fc.weight"], B, wq.shape[0], wq.shape[1])
             E.colsum_add(dt, dq, B, wq.shape[0], Gq["fc.bias"])
-            dyq = E.linear_bwd_x(dt, dq, wq, B, wq.shape[0], wq.shape[1])
+            dyq = E.linear_bwd_x(dt, dq, wq, B, wq.shape[0], wq.shape[1], out_f32=1)
             dA2 = E.maxmean_backward(dt, dyq, argq, Hq)
         for st in self._streams(dev):
             main.wait_stream(st)

@@ -15,7 +15,10 @@
  *   - activations of the conv encoder are channels-last [N][T][F][64] (time, mel, channel), i.e. the
  *     reference's x.permute(0,3,2,1) (src/encoder/audiontt.py:76,83,90,95), so its feature index d*64+c
  *     is contiguous;
- *   - gradient outputs named d* are ACCUMULATED (+=) into caller-zeroed buffers.
+ *   - gradient outputs named d* are ACCUMULATED (+=) into caller-zeroed buffers;
+ *   - `gdtype` (backward kernels of BatchNorm / pooling): storage type of the INCOMING gradient tensor - 0 = fp32 even
+ *     when `dtype` is bf16 (it is a GEMM output, so fp32 is free, and BatchNorm's backward cancels most of it); the
+ *     outgoing gradient is stored in `dtype` because it is only ever an MFMA operand.
  */
 #ifndef AUDIOSSL_HIP_H
 #define AUDIOSSL_HIP_H
@@ -100,7 +103,7 @@ int audiossl_bn_finalize(const double* sum, const double* sumsq, int groups, dou
 int audiossl_bn_relu_pool_fwd(int dtype, const void* Y, const float* scale, const float* shift, void* P, int N, int Ti,
                               int Fi, void* stream);
 int audiossl_tmean_fwd(int dtype, const void* P, void* xl, int N, int To, int Fo, void* stream);
-int audiossl_bn_relu_pool_bwd(int dtype, const void* Y, const void* dP, const void* dxl, const float* scale,
+int audiossl_bn_relu_pool_bwd(int dtype, int gdtype, const void* Y, const void* dP, const void* dxl, const float* scale,
                               const float* shift, const float* mean, const float* rstd, float* stat, void* dY,
                               float* dgamma, float* dbeta, int N, int Ti, int Fi, void* stream);
 int audiossl_im2col3x3(int dtype, const void* X, void* col, int N, int Ti, int Fi, void* stream);
@@ -111,8 +114,8 @@ int audiossl_unpack_conv_dw(const float* dWp, float* dW, void* stream);
  * conv3x3_fwd : Y = conv(X, W) (+bias); W = packed [64][576] (pack_conv_w: Wf = forward, Wd = data gradient);
  *               optional BatchNorm batch statistics of the fp32 accumulators: sum / sumsq fp64 [64] (zeroed inside).
  * conv3x3_wgrad: dWp fp32 [64][576] += dY^T * patches(X) (caller zeroes; unpack_conv_dw maps back to [co][ci][3][3]). */
-int audiossl_conv3x3_fwd(const void* X, const void* W, const float* bias, void* Y, double* sum, double* sumsq, int N,
-                         int Ti, int Fi, void* stream);
+int audiossl_conv3x3_fwd(const void* X, const void* W, const float* bias, void* Y, int out_f32, double* sum,
+                         double* sumsq, int N, int Ti, int Fi, void* stream);
 int audiossl_conv3x3_wgrad(const void* dY, const void* X, float* dWp, int N, int Ti, int Fi, void* stream);
 
 /* ---- K9-K12 GEMM: every nn.Linear / matmul / einsum of the path ------------------------------------------
@@ -128,8 +131,8 @@ int audiossl_gemm(int dtype, int trans_a, int trans_b, int M, int N, int K, floa
 
 /* ---- encoder tail: delores_s/upstream_encoder.py:26-28 ---------------------------------------------------- */
 int audiossl_maxmean_fwd(int dtype, const void* H, void* y, uint8_t* arg, int N, int Tt, int D, void* stream);
-int audiossl_maxmean_bwd(int dtype, const void* dy, const uint8_t* arg, const void* H, void* dA, int N, int Tt, int D,
-                         void* stream);
+int audiossl_maxmean_bwd(int dtype, int gdtype, const void* dy, const uint8_t* arg, const void* H, void* dA, int N, int Tt,
+                         int D, void* stream);
 
 /* ---- K10/K11 Barlow head: delores_s/upstream_expert.py:11-46, src/utils/utils.py:185-189 ------------------
  * colbn_fwd: h = act(scale_g*a+shift_g) on [G][M][C].  colbn_bwd: BatchNorm1d(train) backward per group (tmp = 2*G*C
@@ -137,7 +140,7 @@ int audiossl_maxmean_bwd(int dtype, const void* dy, const uint8_t* arg, const vo
  * barlow_loss: loss += coef * sum (c - I)^2 ; dc = dscale * (c - I). */
 int audiossl_colbn_fwd(int dtype, const void* a, const float* scale, const float* shift, int relu, void* h, int groups,
                        long M, int C, void* stream);
-int audiossl_colbn_bwd(int dtype, const void* a, const void* dh, const float* scale, const float* shift, const float* mean,
+int audiossl_colbn_bwd(int dtype, int gdtype, const void* a, const void* dh, const float* scale, const float* shift, const float* mean,
                        const float* rstd, int relu, int groups, long M, int C, double* tmp, void* da, float* dgamma,
                        float* dbeta, void* stream);
 int audiossl_add_d2f(const double* src, float* dst, int n, void* stream);
