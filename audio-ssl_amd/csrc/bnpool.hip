@@ -75,8 +75,8 @@ __global__ void bn_finalize_kernel(const double* __restrict__ sum, const double*
 
 // ------------------------------------------------------------------------------- BN + ReLU + MaxPool2
 // Y [N][Ti][Fi][64] -> P [N][To][Fo][64]; one thread per (n,to,fo,8-channel group)
-template <typename T_>
-__global__ __launch_bounds__(256) void bn_relu_pool_fwd_kernel(const T_* __restrict__ Y, const float* __restrict__ scale,
+template <typename TY, typename T_>
+__global__ __launch_bounds__(256) void bn_relu_pool_fwd_kernel(const TY* __restrict__ Y, const float* __restrict__ scale,
                                                                const float* __restrict__ shift, T_* __restrict__ P,
                                                                int N, int Ti, int Fi) {
     const int To = Ti / 2, Fo = Fi / 2;
@@ -95,7 +95,7 @@ __global__ __launch_bounds__(256) void bn_relu_pool_fwd_kernel(const T_* __restr
     for (int df = 0; df < 2; ++df)
 #pragma unroll
         for (int dt = 0; dt < 2; ++dt) {
-            const Vec8<T_> v = Vec8<T_>::load(Y + ((((long)n * Ti + 2 * to + dt) * Fi + 2 * fo + df) * 64 + c8 * 8));
+            const Vec8<TY> v = Vec8<TY>::load(Y + ((((long)n * Ti + 2 * to + dt) * Fi + 2 * fo + df) * 64 + c8 * 8));
 #pragma unroll
             for (int i = 0; i < 8; ++i) m[i] = fmaxf(m[i], sc[i] * v.get(i) + sh[i]);      // m starts at 0 = ReLU
         }
@@ -131,8 +131,8 @@ __global__ __launch_bounds__(256) void tmean_fwd_kernel(const T_* __restrict__ P
 // Backward, pass 1: dbeta_c = sum routed grad, dgamma_c = sum routed grad * xhat   (fp32 atomics into stat[2][64])
 // Backward, pass 2: dY = gamma*rstd * (dyhat_routed - dbeta/n - xhat*dgamma/n) at EVERY position (incl. the
 // unpooled last time row when Ti is odd).
-template <typename T_, bool APPLY, typename TG>
-__global__ __launch_bounds__(256) void bn_relu_pool_bwd_kernel(const T_* __restrict__ Y, const TG* __restrict__ dP,
+template <typename TY, bool APPLY, typename TG, typename T_>
+__global__ __launch_bounds__(256) void bn_relu_pool_bwd_kernel(const TY* __restrict__ Y, const TG* __restrict__ dP,
                                                                const TG* __restrict__ dxl, float inv_To,
                                                                const float* __restrict__ scale, const float* __restrict__ shift,
                                                                const float* __restrict__ mean, const float* __restrict__ rstd,
@@ -171,7 +171,7 @@ __global__ __launch_bounds__(256) void bn_relu_pool_bwd_kernel(const T_* __restr
                 for (int i = 0; i < 8; ++i) g[i] += gx.get(i) * inv_To;
             }
         }
-        Vec8<T_> y[4];
+        Vec8<TY> y[4];
         int best[8];
         float bm[8];
 #pragma unroll
@@ -180,8 +180,8 @@ __global__ __launch_bounds__(256) void bn_relu_pool_bwd_kernel(const T_* __restr
         for (int p = 0; p < 4; ++p) {
             const int df = p >> 1, dt = p & 1;
             const int t = 2 * tq + dt;
-            if (t < Ti) y[p] = Vec8<T_>::load(Y + ((((long)n * Ti + t) * Fi + 2 * fo + df) * 64 + c8 * 8));
-            else y[p] = Vec8<T_>::zero();
+            if (t < Ti) y[p] = Vec8<TY>::load(Y + ((((long)n * Ti + t) * Fi + 2 * fo + df) * 64 + c8 * 8));
+            else y[p] = Vec8<TY>::zero();
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
                 const float a = sc[i] * y[p].get(i) + sh[i];
@@ -303,16 +303,17 @@ extern "C" int audiossl_bn_finalize(const double* sum, const double* sumsq, int 
     ASSL_LAUNCH_CHECK();
 }
 
-extern "C" int audiossl_bn_relu_pool_fwd(int dtype, const void* Y, const float* scale, const float* shift, void* P, int N,
-                                         int Ti, int Fi, void* stream) {
+// ydtype: storage type of the pre-BatchNorm conv output Y (0 = fp32 also on the bf16 path, see colbn_fwd)
+extern "C" int audiossl_bn_relu_pool_fwd(int dtype, int ydtype, const void* Y, const float* scale, const float* shift, void* P,
+                                         int N, int Ti, int Fi, void* stream) {
     ASSL_REQUIRE(Y && scale && shift && P && N > 0 && Ti >= 2 && Fi >= 2 && (Fi % 2) == 0 && (dtype == 0 || dtype == 1));
+    ASSL_REQUIRE(ydtype == 0 || ydtype == dtype);
     const long total = (long)N * (Ti / 2) * (Fi / 2) * 8;
     hipStream_t s = static_cast<hipStream_t>(stream);
-    DISPATCH_T(dtype,
-        hipLaunchKernelGGL(bn_relu_pool_fwd_kernel<float>, dim3(ceil_div(total, 256)), dim3(256), 0, s,
-                           static_cast<const float*>(Y), scale, shift, static_cast<float*>(P), N, Ti, Fi),
-        hipLaunchKernelGGL(bn_relu_pool_fwd_kernel<bf16>, dim3(ceil_div(total, 256)), dim3(256), 0, s,
-                           static_cast<const bf16*>(Y), scale, shift, static_cast<bf16*>(P), N, Ti, Fi));
+#define PF(TY, TO) hipLaunchKernelGGL((bn_relu_pool_fwd_kernel<TY, TO>), dim3(ceil_div(total, 256)), dim3(256), 0, s, \
+        static_cast<const TY*>(Y), scale, shift, static_cast<TO*>(P), N, Ti, Fi)
+    if (dtype == 0) PF(float, float); else if (ydtype == 0) PF(float, bf16); else PF(bf16, bf16);
+#undef PF
     ASSL_LAUNCH_CHECK();
 }
 
@@ -336,23 +337,28 @@ __global__ void add_stat_kernel(const float* __restrict__ stat, float* dgamma, f
 }
 }  // namespace
 
-extern "C" int audiossl_bn_relu_pool_bwd(int dtype, int gdtype, const void* Y, const void* dP, const void* dxl, const float* scale,
+extern "C" int audiossl_bn_relu_pool_bwd(int dtype, int ydtype, int gdtype, const void* Y, const void* dP, const void* dxl, const float* scale,
                                          const float* shift, const float* mean, const float* rstd, float* stat, void* dY,
                                          float* dgamma, float* dbeta, int N, int Ti, int Fi, void* stream) {
     ASSL_REQUIRE(Y && dP && scale && shift && mean && rstd && stat && dY && dgamma && dbeta);
     ASSL_REQUIRE(N > 0 && Ti >= 2 && Fi >= 2 && (Fi % 2) == 0 && (dtype == 0 || dtype == 1) && (gdtype == 0 || gdtype == dtype));
+    ASSL_REQUIRE(ydtype == 0 || ydtype == dtype);
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (hipMemsetAsync(stat, 0, sizeof(float) * 128, s) != hipSuccess) return ASSL_ELAUNCH;
     const long total = (long)N * ((Ti + 1) / 2) * (Fi / 2) * 8;
     const int grid = ceil_div(total, 256);
     const float inv_To = 1.f / (float)(Ti / 2);
     const float inv_count = (float)(1.0 / ((double)N * Ti * Fi));
-#define BW(TT, AP, TG) hipLaunchKernelGGL((bn_relu_pool_bwd_kernel<TT, AP, TG>), dim3(grid), dim3(256), 0, s, static_cast<const TT*>(Y), \
-        static_cast<const TG*>(dP), static_cast<const TG*>(dxl), inv_To, scale, shift, mean, rstd, stat, inv_count,                  \
-        static_cast<TT*>(dY), N, Ti, Fi)
-    if (dtype == 0) { BW(float, false, float); BW(float, true, float); }
-    else if (gdtype == 0) { BW(bf16, false, float); BW(bf16, true, float); }
-    else { BW(bf16, false, bf16); BW(bf16, true, bf16); }
+#define BW(TY, AP, TG, TO) hipLaunchKernelGGL((bn_relu_pool_bwd_kernel<TY, AP, TG, TO>), dim3(grid), dim3(256), 0, s,              \
+        static_cast<const TY*>(Y), static_cast<const TG*>(dP), static_cast<const TG*>(dxl), inv_To, scale, shift, mean, rstd, stat, \
+        inv_count, static_cast<TO*>(dY), N, Ti, Fi)
+#define BW2(TY, TG, TO) do { BW(TY, false, TG, TO); BW(TY, true, TG, TO); } while (0)
+    if (dtype == 0) BW2(float, float, float);
+    else if (ydtype == 0 && gdtype == 0) BW2(float, float, bf16);
+    else if (ydtype == 0) BW2(float, bf16, bf16);
+    else if (gdtype == 0) BW2(bf16, float, bf16);
+    else BW2(bf16, bf16, bf16);
+#undef BW2
 #undef BW
     hipLaunchKernelGGL(add_stat_kernel, dim3(1), dim3(64), 0, s, stat, dgamma, dbeta);
     ASSL_LAUNCH_CHECK();

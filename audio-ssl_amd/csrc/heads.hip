@@ -62,8 +62,8 @@ __global__ __launch_bounds__(256) void maxmean_bwd_kernel(const TG* __restrict__
 
 // --------------------------------------------------------------------------------------------- BatchNorm1d pieces
 // h = act(scale_g*a + shift_g), elementwise over [G][M][C] with per-group [G][C] scale / shift
-template <typename T_>
-__global__ __launch_bounds__(256) void colbn_fwd_kernel(const T_* __restrict__ a, const float* __restrict__ scale,
+template <typename TA, typename T_>
+__global__ __launch_bounds__(256) void colbn_fwd_kernel(const TA* __restrict__ a, const float* __restrict__ scale,
                                                         const float* __restrict__ shift, int relu, T_* __restrict__ h, long M, int C,
                                                         int groups) {
     const long idx = (long)blockIdx.x * 256 + threadIdx.x;
@@ -73,7 +73,7 @@ __global__ __launch_bounds__(256) void colbn_fwd_kernel(const T_* __restrict__ a
     const int grp = (int)(idx / (M * C8));
     scale += (long)grp * C;
     shift += (long)grp * C;
-    const Vec8<T_> v = Vec8<T_>::load(a + idx * 8);
+    const Vec8<TA> v = Vec8<TA>::load(a + idx * 8);
     Vec8<T_> o;
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
@@ -85,8 +85,8 @@ __global__ __launch_bounds__(256) void colbn_fwd_kernel(const T_* __restrict__ a
 
 // stats: sg[c] = sum_b g, sgx[c] = sum_b g*xhat with g = dh * (act > 0 if relu), xhat = (a-mean)*rstd   (fp64 atomics)
 // Same slab mapping as colstats: a block = 64 columns x 32 rows per iteration, blockIdx.y = slab.
-template <typename T_, typename TG>
-__global__ __launch_bounds__(256) void colbn_bwd_stats_kernel(const T_* __restrict__ a, const TG* __restrict__ dh,
+template <typename TA, typename TG>
+__global__ __launch_bounds__(256) void colbn_bwd_stats_kernel(const TA* __restrict__ a, const TG* __restrict__ dh,
                                                               const float* __restrict__ scale, const float* __restrict__ shift,
                                                               const float* __restrict__ mean, const float* __restrict__ rstd,
                                                               int relu, long M, int C, int rows_per_block,
@@ -106,7 +106,7 @@ __global__ __launch_bounds__(256) void colbn_bwd_stats_kernel(const T_* __restri
         sc[i] = scale[col0 + i]; sh[i] = shift[col0 + i]; mu[i] = mean[col0 + i]; rs[i] = rstd[col0 + i];
     }
     for (long r = rb + r0; r < re; r += 32) {
-        const Vec8<T_> va = Vec8<T_>::load(a + r * C + col0);
+        const Vec8<TA> va = Vec8<TA>::load(a + r * C + col0);
         const Vec8<TG> vg = Vec8<TG>::load(dh + r * C + col0);
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
@@ -130,8 +130,8 @@ __global__ __launch_bounds__(256) void colbn_bwd_stats_kernel(const T_* __restri
 }
 
 // da = scale * (g - sg/M - xhat*sgx/M); rows handled by block 0 also accumulate the parameter grads.
-template <typename T_, typename TG>
-__global__ __launch_bounds__(256) void colbn_bwd_apply_kernel(const T_* __restrict__ a, const TG* __restrict__ dh,
+template <typename TA, typename TG, typename T_>
+__global__ __launch_bounds__(256) void colbn_bwd_apply_kernel(const TA* __restrict__ a, const TG* __restrict__ dh,
                                                               const float* __restrict__ scale, const float* __restrict__ shift,
                                                               const float* __restrict__ mean, const float* __restrict__ rstd,
                                                               int relu, long M, int C, int groups, const double* __restrict__ sg,
@@ -148,7 +148,7 @@ __global__ __launch_bounds__(256) void colbn_bwd_apply_kernel(const T_* __restri
         const long go = (long)grp * C;
         scale += go; shift += go; mean += go; rstd += go; sg += go; sgx += go;
     }
-    const Vec8<T_> va = Vec8<T_>::load(a + idx * 8);
+    const Vec8<TA> va = Vec8<TA>::load(a + idx * 8);
     const Vec8<TG> vg = Vec8<TG>::load(dh + idx * 8);
     Vec8<T_> o;
     const float invM = 1.f / (float)M;
@@ -364,33 +364,42 @@ extern "C" int audiossl_maxmean_bwd(int dtype, int gdtype, const void* dy, const
     ASSL_LAUNCH_CHECK();
 }
 
-extern "C" int audiossl_colbn_fwd(int dtype, const void* a, const float* scale, const float* shift, int relu, void* h, int groups,
-                                  long M, int C, void* stream) {
+// adtype: storage type of the BatchNorm input `a` (0 = fp32 even when the output dtype is bf16: pre-normalisation values
+// can have |mean| >> std, which bf16's 8 significand bits cannot carry); dtype: type of the output (an MFMA operand).
+extern "C" int audiossl_colbn_fwd(int dtype, int adtype, const void* a, const float* scale, const float* shift, int relu, void* h,
+                                  int groups, long M, int C, void* stream) {
     ASSL_REQUIRE(a && scale && shift && h && groups > 0 && M > 0 && C > 0 && (C % 8) == 0 && (dtype == 0 || dtype == 1));
+    ASSL_REQUIRE(adtype == 0 || adtype == dtype);
     const long total = groups * M * C / 8;
-    if (dtype == 0) hipLaunchKernelGGL(colbn_fwd_kernel<float>, GRID1(total), dim3(256), 0, S_(stream), (const float*)a, scale, shift, relu, (float*)h, M, C, groups);
-    else            hipLaunchKernelGGL(colbn_fwd_kernel<bf16>, GRID1(total), dim3(256), 0, S_(stream), (const bf16*)a, scale, shift, relu, (bf16*)h, M, C, groups);
+    if (dtype == 0) hipLaunchKernelGGL((colbn_fwd_kernel<float, float>), GRID1(total), dim3(256), 0, S_(stream), (const float*)a, scale, shift, relu, (float*)h, M, C, groups);
+    else if (adtype == 0) hipLaunchKernelGGL((colbn_fwd_kernel<float, bf16>), GRID1(total), dim3(256), 0, S_(stream), (const float*)a, scale, shift, relu, (bf16*)h, M, C, groups);
+    else hipLaunchKernelGGL((colbn_fwd_kernel<bf16, bf16>), GRID1(total), dim3(256), 0, S_(stream), (const bf16*)a, scale, shift, relu, (bf16*)h, M, C, groups);
     ASSL_LAUNCH_CHECK();
 }
 
-// tmp: 2*C doubles of scratch.  dgamma/dbeta may be null (affine=False); otherwise accumulated (+=).
-extern "C" int audiossl_colbn_bwd(int dtype, int gdtype, const void* a, const void* dh, const float* scale, const float* shift,
-                                  const float* mean, const float* rstd, int relu, int groups, long M, int C, double* tmp,
-                                  void* da, float* dgamma, float* dbeta, void* stream) {
+// tmp: 2*G*C doubles of scratch.  dgamma/dbeta may be null (affine=False); otherwise accumulated (+=).
+// adtype / gdtype: storage types of `a` and of the incoming gradient `dh` (0 = fp32); `da` is written in `dtype`.
+extern "C" int audiossl_colbn_bwd(int dtype, int adtype, int gdtype, const void* a, const void* dh, const float* scale,
+                                  const float* shift, const float* mean, const float* rstd, int relu, int groups, long M, int C,
+                                  double* tmp, void* da, float* dgamma, float* dbeta, void* stream) {
     ASSL_REQUIRE(a && dh && scale && shift && mean && rstd && tmp && da && groups > 0 && M > 0 && C > 0 && (C % 8) == 0);
-    ASSL_REQUIRE((dtype == 0 || dtype == 1) && (C % 64) == 0 && (gdtype == 0 || gdtype == dtype));
+    ASSL_REQUIRE((dtype == 0 || dtype == 1) && (C % 64) == 0 && (gdtype == 0 || gdtype == dtype) && (adtype == 0 || adtype == dtype));
     hipStream_t s = S_(stream);
     if (hipMemsetAsync(tmp, 0, sizeof(double) * 2 * C * groups, s) != hipSuccess) return ASSL_ELAUNCH;
     const int rpb = M >= 4096 ? 256 : 64;
     dim3 grid(ceil_div(M, rpb), C / 64, groups);
     const long total = groups * M * C / 8;
     const long GC = (long)groups * C;
-#define CB(TT, TG) do {                                                                                                              \
-    hipLaunchKernelGGL((colbn_bwd_stats_kernel<TT, TG>), grid, dim3(256), 0, s, (const TT*)a, (const TG*)dh, scale, shift, mean, rstd,  \
+#define CB(TA, TG, TO) do {                                                                                                           \
+    hipLaunchKernelGGL((colbn_bwd_stats_kernel<TA, TG>), grid, dim3(256), 0, s, (const TA*)a, (const TG*)dh, scale, shift, mean, rstd,  \
                        relu, M, C, rpb, tmp, tmp + GC);                                                                               \
-    hipLaunchKernelGGL((colbn_bwd_apply_kernel<TT, TG>), GRID1(total), dim3(256), 0, s, (const TT*)a, (const TG*)dh, scale, shift,      \
-                       mean, rstd, relu, M, C, groups, tmp, tmp + GC, (TT*)da, dgamma, dbeta); } while (0)
-    if (dtype == 0) CB(float, float); else if (gdtype == 0) CB(bf16, float); else CB(bf16, bf16);
+    hipLaunchKernelGGL((colbn_bwd_apply_kernel<TA, TG, TO>), GRID1(total), dim3(256), 0, s, (const TA*)a, (const TG*)dh, scale, shift,  \
+                       mean, rstd, relu, M, C, groups, tmp, tmp + GC, (TO*)da, dgamma, dbeta); } while (0)
+    if (dtype == 0) CB(float, float, float);
+    else if (adtype == 0 && gdtype == 0) CB(float, float, bf16);
+    else if (adtype == 0) CB(float, bf16, bf16);
+    else if (gdtype == 0) CB(bf16, float, bf16);
+    else CB(bf16, bf16, bf16);
 #undef CB
     ASSL_LAUNCH_CHECK();
 }

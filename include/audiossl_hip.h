@@ -18,7 +18,9 @@
  *   - gradient outputs named d* are ACCUMULATED (+=) into caller-zeroed buffers;
  *   - `gdtype` (backward kernels of BatchNorm / pooling): storage type of the INCOMING gradient tensor - 0 = fp32 even
  *     when `dtype` is bf16 (it is a GEMM output, so fp32 is free, and BatchNorm's backward cancels most of it); the
- *     outgoing gradient is stored in `dtype` because it is only ever an MFMA operand.
+ *     outgoing gradient is stored in `dtype` because it is only ever an MFMA operand;
+ *   - `adtype` / `ydtype`: storage type of a BatchNorm INPUT (projector pre-activations, conv outputs) - 0 = fp32 also on
+ *     the bf16 path: pre-normalisation values can have |mean| >> std, which 8 significand bits cannot carry.
  */
 #ifndef AUDIOSSL_HIP_H
 #define AUDIOSSL_HIP_H
@@ -100,10 +102,10 @@ int audiossl_colstats(int dtype, const void* x, int groups, long M, int C, long 
 int audiossl_bn_finalize(const double* sum, const double* sumsq, int groups, double count, int C, const float* gamma,
                          const float* beta, float* running_mean, float* running_var, float momentum, float eps,
                          float* scale, float* shift, float* save_mean, float* save_rstd, void* stream);
-int audiossl_bn_relu_pool_fwd(int dtype, const void* Y, const float* scale, const float* shift, void* P, int N, int Ti,
-                              int Fi, void* stream);
+int audiossl_bn_relu_pool_fwd(int dtype, int ydtype, const void* Y, const float* scale, const float* shift, void* P, int N,
+                              int Ti, int Fi, void* stream);
 int audiossl_tmean_fwd(int dtype, const void* P, void* xl, int N, int To, int Fo, void* stream);
-int audiossl_bn_relu_pool_bwd(int dtype, int gdtype, const void* Y, const void* dP, const void* dxl, const float* scale,
+int audiossl_bn_relu_pool_bwd(int dtype, int ydtype, int gdtype, const void* Y, const void* dP, const void* dxl, const float* scale,
                               const float* shift, const float* mean, const float* rstd, float* stat, void* dY,
                               float* dgamma, float* dbeta, int N, int Ti, int Fi, void* stream);
 int audiossl_im2col3x3(int dtype, const void* X, void* col, int N, int Ti, int Fi, void* stream);
@@ -138,9 +140,9 @@ int audiossl_maxmean_bwd(int dtype, int gdtype, const void* dy, const uint8_t* a
  * colbn_fwd: h = act(scale_g*a+shift_g) on [G][M][C].  colbn_bwd: BatchNorm1d(train) backward per group (tmp = 2*G*C
  * doubles scratch), parameter grads summed over groups.
  * barlow_loss: loss += coef * sum (c - I)^2 ; dc = dscale * (c - I). */
-int audiossl_colbn_fwd(int dtype, const void* a, const float* scale, const float* shift, int relu, void* h, int groups,
-                       long M, int C, void* stream);
-int audiossl_colbn_bwd(int dtype, int gdtype, const void* a, const void* dh, const float* scale, const float* shift, const float* mean,
+int audiossl_colbn_fwd(int dtype, int adtype, const void* a, const float* scale, const float* shift, int relu, void* h,
+                       int groups, long M, int C, void* stream);
+int audiossl_colbn_bwd(int dtype, int adtype, int gdtype, const void* a, const void* dh, const float* scale, const float* shift, const float* mean,
                        const float* rstd, int relu, int groups, long M, int C, double* tmp, void* da, float* dgamma,
                        float* dbeta, void* stream);
 int audiossl_add_d2f(const double* src, float* dst, int n, void* stream);
