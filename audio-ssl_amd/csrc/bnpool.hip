@@ -106,8 +106,8 @@ __global__ __launch_bounds__(256) void bn_relu_pool_fwd_kernel(const TY* __restr
 }
 
 // xl[n][f*64+c] = mean_t P[n][t][f][c]
-template <typename T_>
-__global__ __launch_bounds__(256) void tmean_fwd_kernel(const T_* __restrict__ P, T_* __restrict__ xl, int N, int To, int Fo) {
+template <typename T_, typename TO>
+__global__ __launch_bounds__(256) void tmean_fwd_kernel(const T_* __restrict__ P, TO* __restrict__ xl, int N, int To, int Fo) {
     const long total = (long)N * Fo * 8;
     const long idx = (long)blockIdx.x * 256 + threadIdx.x;
     if (idx >= total) return;
@@ -121,7 +121,7 @@ __global__ __launch_bounds__(256) void tmean_fwd_kernel(const T_* __restrict__ P
 #pragma unroll
         for (int i = 0; i < 8; ++i) s[i] += v.get(i);
     }
-    Vec8<T_> o;
+    Vec8<TO> o;
     const float inv = 1.f / (float)To;
 #pragma unroll
     for (int i = 0; i < 8; ++i) o.set(i, s[i] * inv);
@@ -317,15 +317,14 @@ extern "C" int audiossl_bn_relu_pool_fwd(int dtype, int ydtype, const void* Y, c
     ASSL_LAUNCH_CHECK();
 }
 
-extern "C" int audiossl_tmean_fwd(int dtype, const void* P, void* xl, int N, int To, int Fo, void* stream) {
+extern "C" int audiossl_tmean_fwd(int dtype, int out_f32, const void* P, void* xl, int N, int To, int Fo, void* stream) {
     ASSL_REQUIRE(P && xl && N > 0 && To > 0 && Fo > 0 && (dtype == 0 || dtype == 1));
     const long total = (long)N * Fo * 8;
     hipStream_t s = static_cast<hipStream_t>(stream);
-    DISPATCH_T(dtype,
-        hipLaunchKernelGGL(tmean_fwd_kernel<float>, dim3(ceil_div(total, 256)), dim3(256), 0, s,
-                           static_cast<const float*>(P), static_cast<float*>(xl), N, To, Fo),
-        hipLaunchKernelGGL(tmean_fwd_kernel<bf16>, dim3(ceil_div(total, 256)), dim3(256), 0, s,
-                           static_cast<const bf16*>(P), static_cast<bf16*>(xl), N, To, Fo));
+#define TM(TI, TO_) hipLaunchKernelGGL((tmean_fwd_kernel<TI, TO_>), dim3(ceil_div(total, 256)), dim3(256), 0, s, \
+        static_cast<const TI*>(P), static_cast<TO_*>(xl), N, To, Fo)
+    if (dtype == 0) TM(float, float); else if (out_f32) TM(bf16, float); else TM(bf16, bf16);
+#undef TM
     ASSL_LAUNCH_CHECK();
 }
 

@@ -10,8 +10,8 @@ namespace {
 
 // --------------------------------------------------------------------------------------------- max + mean over time
 // H [N][Tt][D] -> y [N][D] = max_t + mean_t ; arg [N][D] = first argmax
-template <typename T_>
-__global__ __launch_bounds__(256) void maxmean_fwd_kernel(const T_* __restrict__ H, T_* __restrict__ y, uint8_t* __restrict__ arg,
+template <typename T_, typename TO>
+__global__ __launch_bounds__(256) void maxmean_fwd_kernel(const T_* __restrict__ H, TO* __restrict__ y, uint8_t* __restrict__ arg,
                                                           int N, int Tt, int D) {
     const long idx = (long)blockIdx.x * 256 + threadIdx.x;          // over N * D/8
     const int D8 = D / 8;
@@ -29,7 +29,7 @@ __global__ __launch_bounds__(256) void maxmean_fwd_kernel(const T_* __restrict__
             else { sm[i] += f; if (f > mx[i]) { mx[i] = f; am[i] = t; } }
         }
     }
-    Vec8<T_> o;
+    Vec8<TO> o;
     const float inv = 1.f / (float)Tt;
 #pragma unroll
     for (int i = 0; i < 8; ++i) { o.set(i, mx[i] + sm[i] * inv); arg[n * D + d8 * 8 + i] = (uint8_t)am[i]; }
@@ -345,11 +345,12 @@ __global__ __launch_bounds__(256) void dropout_mask_kernel(uint8_t* __restrict__
 #define S_(stream) static_cast<hipStream_t>(stream)
 #define GRID1(n) dim3((unsigned)(((long)(n) + 255) / 256))
 
-extern "C" int audiossl_maxmean_fwd(int dtype, const void* H, void* y, uint8_t* arg, int N, int Tt, int D, void* stream) {
+extern "C" int audiossl_maxmean_fwd(int dtype, int out_f32, const void* H, void* y, uint8_t* arg, int N, int Tt, int D, void* stream) {
     ASSL_REQUIRE(H && y && arg && N > 0 && Tt > 0 && Tt < 256 && D > 0 && (D % 8) == 0 && (dtype == 0 || dtype == 1));
     const long total = (long)N * D / 8;
-    if (dtype == 0) hipLaunchKernelGGL(maxmean_fwd_kernel<float>, GRID1(total), dim3(256), 0, S_(stream), (const float*)H, (float*)y, arg, N, Tt, D);
-    else            hipLaunchKernelGGL(maxmean_fwd_kernel<bf16>, GRID1(total), dim3(256), 0, S_(stream), (const bf16*)H, (bf16*)y, arg, N, Tt, D);
+    if (dtype == 0) hipLaunchKernelGGL((maxmean_fwd_kernel<float, float>), GRID1(total), dim3(256), 0, S_(stream), (const float*)H, (float*)y, arg, N, Tt, D);
+    else if (out_f32) hipLaunchKernelGGL((maxmean_fwd_kernel<bf16, float>), GRID1(total), dim3(256), 0, S_(stream), (const bf16*)H, (float*)y, arg, N, Tt, D);
+    else            hipLaunchKernelGGL((maxmean_fwd_kernel<bf16, bf16>), GRID1(total), dim3(256), 0, S_(stream), (const bf16*)H, (bf16*)y, arg, N, Tt, D);
     ASSL_LAUNCH_CHECK();
 }
 
@@ -524,6 +525,15 @@ __global__ void bn_eval_affine_kernel(const float* gamma, const float* beta, con
     scale[c] = s;
     shift[c] = b - rm[c] * s;
 }
+// x (fp32) = hi + lo with hi = bf16(x), lo = bf16(x - hi): two MFMA operands that together carry ~16 significand bits
+__global__ __launch_bounds__(256) void split_bf16_kernel(const float* __restrict__ x, bf16* __restrict__ hi, bf16* __restrict__ lo, long n) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        const float v = x[i];
+        const bf16 h = (bf16)v;
+        hi[i] = h;
+        lo[i] = (bf16)(v - (float)h);
+    }
+}
 __global__ void axpy_kernel(float* __restrict__ y, const float* __restrict__ x, float a, long n) {
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) y[i] += a * x[i];
 }
@@ -541,6 +551,13 @@ extern "C" int audiossl_bn_eval_affine(const float* gamma, const float* beta, co
     ASSL_REQUIRE(running_mean && running_var && scale && shift && C > 0);
     hipLaunchKernelGGL(bn_eval_affine_kernel, dim3(ceil_div(C, 256)), dim3(256), 0, S_(stream), gamma, beta, running_mean,
                        running_var, eps, C, scale, shift);
+    ASSL_LAUNCH_CHECK();
+}
+
+extern "C" int audiossl_split_bf16(const float* x, void* hi, void* lo, long n, void* stream) {
+    ASSL_REQUIRE(x && hi && lo && n > 0);
+    const int grid = (int)min((long)2048, (n + 255) / 256);
+    hipLaunchKernelGGL(split_bf16_kernel, dim3(grid), dim3(256), 0, S_(stream), x, (bf16*)hi, (bf16*)lo, n);
     ASSL_LAUNCH_CHECK();
 }
 

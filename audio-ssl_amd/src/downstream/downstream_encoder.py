@@ -18,7 +18,7 @@ class MeanTFn(torch.autograd.Function):
         dt = N.F32 if h.dtype == torch.float32 else N.BF16
         n, T, D = h.shape
         y = torch.empty(n, D, dtype=h.dtype, device=h.device)
-        N.call("tmean_fwd", dt, h, y, n, T, D // 64)
+        N.call("tmean_fwd", dt, 0, h, y, n, T, D // 64)
         ctx.shape = (n, T, D, dt)
         return y
 

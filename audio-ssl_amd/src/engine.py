@@ -209,9 +209,10 @@ def encoder_forward(P, x, dtype, keep=None, p_drop=0.3, train=True, update_runni
     x1 = x2 = x3 = None
     if want_layers:
         x1, x2, x3 = layer_out if layer_out is not None else (_empty((Nimg, f * 64), td, like=x) for f in (F1, F2, F3))
-        N.call("tmean_fwd", dtype, c.P1, x1, Nimg, T1, F1)
-        N.call("tmean_fwd", dtype, c.P2, x2, Nimg, T2, F2)
-        N.call("tmean_fwd", dtype, c.P3, x3, Nimg, T3, F3)
+        o32 = int(x1.dtype == torch.float32)
+        N.call("tmean_fwd", dtype, o32, c.P1, x1, Nimg, T1, F1)
+        N.call("tmean_fwd", dtype, o32, c.P2, x2, Nimg, T2, F2)
+        N.call("tmean_fwd", dtype, o32, c.P3, x3, Nimg, T3, F3)
     d = P["fc.0.weight"].shape[0]
     kin = F3 * 64
     M = Nimg * T3
@@ -309,7 +310,7 @@ def maxmean_forward(dtype, H2, out=None):
     Nimg, T3, d = H2.shape
     y = out if out is not None else _empty((Nimg, d), N.torch_dtype(dtype), like=H2)
     arg = _empty((Nimg, d), torch.uint8, like=H2)
-    N.call("maxmean_fwd", dtype, H2, y, arg, Nimg, T3, d)
+    N.call("maxmean_fwd", dtype, int(y.dtype == torch.float32), H2, y, arg, Nimg, T3, d)
     return y, arg
 
 
@@ -347,7 +348,17 @@ def projector_forward(PP, Y, dtype, groups, B, update_running=True, Wc=None):
                          groups)
     td = N.torch_dtype(dtype)
     # pre-BatchNorm tensors (a1, a2, z) are fp32 GEMM outputs; the normalised activations (MFMA operands) are `dtype`
-    c.a1 = linear_fwd(dtype, Y, W[0], M, D, kin, out_f32=1)
+    if dtype == N.BF16 and Y.dtype == torch.float32:
+        # time-pooled post-ReLU features: |mean| >> batch-std, so a single bf16 rounding would eat the batch variation
+        # that BatchNorm amplifies.  Run the first GEMM on hi + lo bf16 pieces (fp32 accumulate into the same output).
+        c.y_hi, c.y_lo = _empty((M, kin), td, like=Y), _empty((M, kin), td, like=Y)
+        N.call("split_bf16", Y, c.y_hi, c.y_lo, M * kin)
+        c.a1 = torch.zeros(M, D, dtype=torch.float32, device=Y.device)
+        gemm(dtype, 0, 0, M, D, kin, c.y_hi, kin, W[0], kin, c.a1, D, out_f32=1, atomic=1)
+        gemm(dtype, 0, 0, M, D, kin, c.y_lo, kin, W[0], kin, c.a1, D, out_f32=1, atomic=1)
+    else:
+        c.y_hi, c.y_lo = Y, None
+        c.a1 = linear_fwd(dtype, Y, W[0], M, D, kin, out_f32=1)
     c.st1 = bn(c.a1, "projector.1", True)
     c.h1 = _empty((M, D), td, like=Y)
     N.call("colbn_fwd", dtype, AD, c.a1, c.st1[0], c.st1[1], 1, c.h1, groups, B, D)
@@ -381,7 +392,9 @@ def projector_backward(c, PP, G, dzn, dy_rows=None):
     dh1 = linear_bwd_x(dtype, da2, c.W[1], M, D, D, out_f32=1)
     da1 = _empty((M, D), td, like=c.zn)
     N.call("colbn_bwd", dtype, AD, GD, c.a1, dh1, *c.st1, 1, groups, B, D, tmp, da1, G["projector.1.weight"], G["projector.1.bias"])
-    linear_bwd_w(dtype, da1, c.y, G["projector.0.weight"], M, D, kin)
+    linear_bwd_w(dtype, da1, c.y_hi, G["projector.0.weight"], M, D, kin)
+    if c.y_lo is not None:
+        linear_bwd_w(dtype, da1, c.y_lo, G["projector.0.weight"], M, D, kin)
     rows = M if dy_rows is None else dy_rows
     if rows == 0:
         return None

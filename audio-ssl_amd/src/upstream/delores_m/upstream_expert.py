@@ -143,7 +143,7 @@ class Upstream_Expert(FusedExpertMixin, UpstreamModule):
         eq, ek = self.encoder_q, self.encoder_k
         Wq = flat.shadow_dict("encoder_q.")
         # stacked projector inputs: rows [0,B) from the query encoder, [B,2B) from the key encoder
-        Ys = [torch.empty(2 * B, f, dtype=td, device=dev) for f in (2048, 1024, 512)]
+        Ys = [torch.empty(2 * B, f, dtype=torch.float32, device=dev) for f in (2048, 1024, 512)]     # fp32: engine.projector_forward
         ddp = _world() > 1
         img_k = img_k.float().contiguous()
         pending_k = self._shuffle_begin(img_k) if ddp else None

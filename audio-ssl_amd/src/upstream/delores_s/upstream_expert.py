@@ -56,7 +56,7 @@ class Upstream_Expert(FusedExpertMixin, UpstreamModule):
         G = flat.grad_dict("encoder.encoder.")
         Wenc = flat.shadow_dict("encoder.encoder.")
         Wp = flat.shadow_dict("p.")
-        Y = torch.empty(2 * B, enc.d, dtype=N.torch_dtype(dt), device=img_1.device)      # both views, stacked
+        Y = torch.empty(2 * B, enc.d, dtype=torch.float32, device=img_1.device)          # both views, stacked, fp32
         views = []
         for v, img in enumerate((img_1, img_2)):
             img = img.float().contiguous()

@@ -104,7 +104,7 @@ int audiossl_bn_finalize(const double* sum, const double* sumsq, int groups, dou
                          float* scale, float* shift, float* save_mean, float* save_rstd, void* stream);
 int audiossl_bn_relu_pool_fwd(int dtype, int ydtype, const void* Y, const float* scale, const float* shift, void* P, int N,
                               int Ti, int Fi, void* stream);
-int audiossl_tmean_fwd(int dtype, const void* P, void* xl, int N, int To, int Fo, void* stream);
+int audiossl_tmean_fwd(int dtype, int out_f32, const void* P, void* xl, int N, int To, int Fo, void* stream);
 int audiossl_bn_relu_pool_bwd(int dtype, int ydtype, int gdtype, const void* Y, const void* dP, const void* dxl, const float* scale,
                               const float* shift, const float* mean, const float* rstd, float* stat, void* dY,
                               float* dgamma, float* dbeta, int N, int Ti, int Fi, void* stream);
@@ -132,7 +132,7 @@ int audiossl_gemm(int dtype, int trans_a, int trans_b, int M, int N, int K, floa
                   float keep_scale, const void* gate, long ldg, int out_f32, int atomic, int ksplit, void* stream);
 
 /* ---- encoder tail: delores_s/upstream_encoder.py:26-28 ---------------------------------------------------- */
-int audiossl_maxmean_fwd(int dtype, const void* H, void* y, uint8_t* arg, int N, int Tt, int D, void* stream);
+int audiossl_maxmean_fwd(int dtype, int out_f32, const void* H, void* y, uint8_t* arg, int N, int Tt, int D, void* stream);
 int audiossl_maxmean_bwd(int dtype, int gdtype, const void* dy, const uint8_t* arg, const void* H, void* dA, int N, int Tt,
                          int D, void* stream);
 
@@ -172,6 +172,9 @@ int audiossl_relu_bwd(int dtype, const void* g, const void* h, void* out, long n
 int audiossl_bn_eval_affine(const float* gamma, const float* beta, const float* running_mean, const float* running_var,
                             float eps, int C, float* scale, float* shift, void* stream);
 int audiossl_axpy(float* y, const float* x, float a, long n, void* stream);
+/* x = hi + lo, hi = bf16(x), lo = bf16(x - hi): the projector's first GEMM runs on both pieces, because the time-pooled
+ * features it reads have |mean| >> batch-std and a single bf16 rounding would eat their batch variation. */
+int audiossl_split_bf16(const float* x, void* hi, void* lo, long n, void* stream);
 
 /* ---- K14 NT-Xent / ClusterLoss: extras/slicer/contrastive_loss.py:6-92 -----------------------------------------
  * sim [N][N] fp32 = z z^T / tau from audiossl_gemm (N = 2B; positives at (r + B) mod N; the diagonal is excluded).
