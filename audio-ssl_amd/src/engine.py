@@ -86,8 +86,27 @@ def linear_bwd_x(dtype, dY, W, M, Nout, K, alpha=1.0, gate=None, out=None, out_f
     return out
 
 
-GD = N.F32     # storage type of gradients that enter a BatchNorm / pooling backward
-AD = N.F32     # storage type of BatchNorm inputs (conv outputs Y, projector pre-activations a1 / a2 / z)
+GD = N.F32     # storage type of gradients that enter a BatchNorm / pooling backward (free: they are GEMM outputs)
+
+# "bf16_hp" (run.precision): additionally keep BatchNorm INPUTS (conv outputs, projector pre-activations) and the
+# time-pooled features in fp32 and run the projector's first GEMM on hi+lo bf16 pieces.  Costs ~0.6 ms per 512-clip step
+# (fp32 conv outputs are 2x the bytes), buys 2-3x smaller gradient deviation from the fp32 path.
+HP = False
+
+
+def set_high_precision(flag):
+    global HP
+    HP = bool(flag)
+
+
+def _ad(dtype):
+    """storage type of BatchNorm inputs"""
+    return N.F32 if (HP or dtype == N.F32) else dtype
+
+
+def pooled_dtype(dtype):
+    """torch dtype of the time-pooled features handed to the projector"""
+    return torch.float32 if (HP or dtype == N.F32) else torch.bfloat16
 
 
 def colsum_add(dtype, X, M, C, dst, tmp=None):
@@ -135,27 +154,29 @@ def _conv_block_fwd(dtype, Pin, Nimg, Ti, Fi, W, bias, bn, train, update_running
     Wf, Wd = _empty((64, 576), td, like=Pin), _empty((64, 576), td, like=Pin)
     N.call("pack_conv_w", dtype, W, Wf, Wd)
     M = Nimg * Ti * Fi
-    Y = _empty((M, 64), torch.float32, like=Pin)             # BatchNorm input: fp32 on both paths
+    ad = _ad(dtype)
+    Y = _empty((M, 64), N.torch_dtype(ad), like=Pin)          # BatchNorm input: fp32 on the fp32 and bf16_hp paths
     gamma, beta, rm, rv = bn
     fused = dtype == N.BF16 and Fi in (16, 32)
     sq = _empty((2, 64), torch.float64, like=Pin) if (fused and train) else None
     if fused:
-        N.call("conv3x3_fwd", Pin, Wf, bias, Y, 1, None if sq is None else sq[0], None if sq is None else sq[1], Nimg, Ti, Fi)
+        N.call("conv3x3_fwd", Pin, Wf, bias, Y, int(ad == N.F32), None if sq is None else sq[0], None if sq is None else sq[1],
+               Nimg, Ti, Fi)
     else:
         N.call("im2col3x3", dtype, Pin, col, Nimg, Ti, Fi)
-        gemm(dtype, 0, 0, M, 64, 576, col, 576, Wf, 576, Y, 64, bias=bias, out_f32=1)
+        gemm(dtype, 0, 0, M, 64, 576, col, 576, Wf, 576, Y, 64, bias=bias, out_f32=int(ad == N.F32))
     if train and fused:
         st = _empty((4, 64), torch.float32, like=Pin)
         N.call("bn_finalize", sq[0], sq[1], 1, float(M), 64, gamma, beta, rm if update_running else None,
                rv if update_running else None, BN_MOMENTUM, BN_EPS, st[0], st[1], st[2], st[3])
         scale, shift, mean, rstd = st[0], st[1], st[2], st[3]
     elif train:
-        scale, shift, mean, rstd = _bn_train(AD, Y, M, 64, gamma, beta, rm, rv, update_running)
+        scale, shift, mean, rstd = _bn_train(ad, Y, M, 64, gamma, beta, rm, rv, update_running)
     else:
         scale, shift = _bn_eval(Y, 64, gamma, beta, rm, rv)
         mean = rstd = None
     Pout = _empty((Nimg, Ti // 2, Fi // 2, 64), td, like=Pin)
-    N.call("bn_relu_pool_fwd", dtype, AD, Y, scale, shift, Pout, Nimg, Ti, Fi)
+    N.call("bn_relu_pool_fwd", dtype, ad, Y, scale, shift, Pout, Nimg, Ti, Fi)
     return Y, Pout, (scale, shift, mean, rstd), Wf, Wd
 
 
@@ -236,7 +257,7 @@ def _conv_block_bwd(dtype, Y, dP, dxl, st, Nimg, Ti, Fi, Pin, Wd, G_w, G_gamma, 
     M = Nimg * Ti * Fi
     dY = torch.empty((M, 64), dtype=td, device=Y.device)
     stat = _empty((128,), torch.float32, like=Y)
-    N.call("bn_relu_pool_bwd", dtype, AD, GD, Y, dP, dxl, scale, shift, mean, rstd, stat, dY, G_gamma, G_beta, Nimg, Ti, Fi)
+    N.call("bn_relu_pool_bwd", dtype, N.F32 if Y.dtype == torch.float32 else dtype, GD, Y, dP, dxl, scale, shift, mean, rstd, stat, dY, G_gamma, G_beta, Nimg, Ti, Fi)
     # wgrad: dWp[co][tap*64+ci] = sum_pix dY[pix][co] * Pin[pix + off(tap)][ci]
     fused = dtype == N.BF16 and Fi in (16, 32)
     if fused:
@@ -344,10 +365,11 @@ def projector_forward(PP, Y, dtype, groups, B, update_running=True, Wc=None):
     def bn(a, prefix, affine):
         g = PP[prefix + ".weight"] if affine else None
         b = PP[prefix + ".bias"] if affine else None
-        return _bn_train(AD, a, B, D, g, b, PP[prefix + ".running_mean"], PP[prefix + ".running_var"], update_running,
+        return _bn_train(ad, a, B, D, g, b, PP[prefix + ".running_mean"], PP[prefix + ".running_var"], update_running,
                          groups)
     td = N.torch_dtype(dtype)
-    # pre-BatchNorm tensors (a1, a2, z) are fp32 GEMM outputs; the normalised activations (MFMA operands) are `dtype`
+    # pre-BatchNorm tensors (a1, a2, z) are fp32 GEMM outputs on the fp32 / bf16_hp paths; the normalised activations
+    # (MFMA operands) are `dtype`
     if dtype == N.BF16 and Y.dtype == torch.float32:
         # time-pooled post-ReLU features: |mean| >> batch-std, so a single bf16 rounding would eat the batch variation
         # that BatchNorm amplifies.  Run the first GEMM on hi + lo bf16 pieces (fp32 accumulate into the same output).
@@ -358,18 +380,18 @@ def projector_forward(PP, Y, dtype, groups, B, update_running=True, Wc=None):
         gemm(dtype, 0, 0, M, D, kin, c.y_lo, kin, W[0], kin, c.a1, D, out_f32=1, atomic=1)
     else:
         c.y_hi, c.y_lo = Y, None
-        c.a1 = linear_fwd(dtype, Y, W[0], M, D, kin, out_f32=1)
+        c.a1 = linear_fwd(dtype, Y, W[0], M, D, kin, out_f32=o32)
     c.st1 = bn(c.a1, "projector.1", True)
     c.h1 = _empty((M, D), td, like=Y)
-    N.call("colbn_fwd", dtype, AD, c.a1, c.st1[0], c.st1[1], 1, c.h1, groups, B, D)
-    c.a2 = linear_fwd(dtype, c.h1, W[1], M, D, D, out_f32=1)
+    N.call("colbn_fwd", dtype, ad, c.a1, c.st1[0], c.st1[1], 1, c.h1, groups, B, D)
+    c.a2 = linear_fwd(dtype, c.h1, W[1], M, D, D, out_f32=o32)
     c.st2 = bn(c.a2, "projector.4", True)
     c.h2 = _empty((M, D), td, like=Y)
-    N.call("colbn_fwd", dtype, AD, c.a2, c.st2[0], c.st2[1], 1, c.h2, groups, B, D)
-    c.z = linear_fwd(dtype, c.h2, W[2], M, D, D, out_f32=1)
+    N.call("colbn_fwd", dtype, ad, c.a2, c.st2[0], c.st2[1], 1, c.h2, groups, B, D)
+    c.z = linear_fwd(dtype, c.h2, W[2], M, D, D, out_f32=o32)
     c.st0 = bn(c.z, "bn", False)
     c.zn = _empty((M, D), td, like=Y)
-    N.call("colbn_fwd", dtype, AD, c.z, c.st0[0], c.st0[1], 0, c.zn, groups, B, D)
+    N.call("colbn_fwd", dtype, ad, c.z, c.st0[0], c.st0[1], 0, c.zn, groups, B, D)
     return c.zn, c
 
 
@@ -383,15 +405,15 @@ def projector_backward(c, PP, G, dzn, dy_rows=None):
     dz = _empty((M, D), td, like=c.zn)
     # gradients entering a BatchNorm backward (dzn, dh2, dh1) are fp32 GEMM outputs; its outputs (dz, da2, da1) are
     # MFMA operands only and are stored in the activation dtype
-    N.call("colbn_bwd", dtype, AD, GD, c.z, dzn, *c.st0, 0, groups, B, D, tmp, dz, None, None)
+    N.call("colbn_bwd", dtype, c.ad, GD, c.z, dzn, *c.st0, 0, groups, B, D, tmp, dz, None, None)
     linear_bwd_w(dtype, dz, c.h2, G["projector.6.weight"], M, D, D)
     dh2 = linear_bwd_x(dtype, dz, c.W[2], M, D, D, out_f32=1)
     da2 = _empty((M, D), td, like=c.zn)
-    N.call("colbn_bwd", dtype, AD, GD, c.a2, dh2, *c.st2, 1, groups, B, D, tmp, da2, G["projector.4.weight"], G["projector.4.bias"])
+    N.call("colbn_bwd", dtype, c.ad, GD, c.a2, dh2, *c.st2, 1, groups, B, D, tmp, da2, G["projector.4.weight"], G["projector.4.bias"])
     linear_bwd_w(dtype, da2, c.h1, G["projector.3.weight"], M, D, D)
     dh1 = linear_bwd_x(dtype, da2, c.W[1], M, D, D, out_f32=1)
     da1 = _empty((M, D), td, like=c.zn)
-    N.call("colbn_bwd", dtype, AD, GD, c.a1, dh1, *c.st1, 1, groups, B, D, tmp, da1, G["projector.1.weight"], G["projector.1.bias"])
+    N.call("colbn_bwd", dtype, c.ad, GD, c.a1, dh1, *c.st1, 1, groups, B, D, tmp, da1, G["projector.1.weight"], G["projector.1.bias"])
     linear_bwd_w(dtype, da1, c.y_hi, G["projector.0.weight"], M, D, kin)
     if c.y_lo is not None:
         linear_bwd_w(dtype, da1, c.y_lo, G["projector.0.weight"], M, D, kin)

@@ -48,7 +48,9 @@ class Upstream_Expert(FusedExpertMixin, UpstreamModule):
         self.p1 = Projection(2048, lam[0], scale)
         self.p2 = Projection(1024, lam[1], scale)
         self.p3 = Projection(512, lam[2], scale)
-        self.precision = {"fp32": N.F32, "bf16": N.BF16}.get(config.get("run", {}).get("precision"), default_precision())
+        prec = config.get("run", {}).get("precision")
+        self.precision = {"fp32": N.F32, "bf16": N.BF16, "bf16_hp": N.BF16}.get(prec, default_precision())
+        self.high_precision = prec == "bf16_hp"
         self.encoder_q.encoder.precision = self.encoder_k.encoder.precision = self.precision
         self.flat_k = None
         self._key_stream = E.SideStream()
@@ -133,6 +135,7 @@ class Upstream_Expert(FusedExpertMixin, UpstreamModule):
     def fused_loss(self, img_q, img_k, need_grad=True, parts=None):
         dt = self.precision
         td = N.torch_dtype(dt)
+        E.set_high_precision(self.high_precision)
         flat = self.ensure_flat()
         if need_grad:
             flat.zero_grad()
@@ -143,7 +146,7 @@ class Upstream_Expert(FusedExpertMixin, UpstreamModule):
         eq, ek = self.encoder_q, self.encoder_k
         Wq = flat.shadow_dict("encoder_q.")
         # stacked projector inputs: rows [0,B) from the query encoder, [B,2B) from the key encoder
-        Ys = [torch.empty(2 * B, f, dtype=torch.float32, device=dev) for f in (2048, 1024, 512)]     # fp32: engine.projector_forward
+        Ys = [torch.empty(2 * B, f, dtype=E.pooled_dtype(dt), device=dev) for f in (2048, 1024, 512)]
         ddp = _world() > 1
         img_k = img_k.float().contiguous()
         pending_k = self._shuffle_begin(img_k) if ddp else None

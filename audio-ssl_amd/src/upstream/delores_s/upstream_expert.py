@@ -28,7 +28,9 @@ class Upstream_Expert(FusedExpertMixin, UpstreamModule):
         self.datamodule = datamodule
         self.encoder = self.init_encoders(self.base_encoder)
         self.p = Projection(self.config["pretrain"]["projection_dim"], self.config["pretrain"]["lambda_barlow"])
-        self.precision = {"fp32": N.F32, "bf16": N.BF16}.get(config.get("run", {}).get("precision"), default_precision())
+        prec = config.get("run", {}).get("precision")
+        self.precision = {"fp32": N.F32, "bf16": N.BF16, "bf16_hp": N.BF16}.get(prec, default_precision())
+        self.high_precision = prec == "bf16_hp"
         self.encoder.encoder.precision = self.precision
         self.cross_gpu_barlow = bool(config.get("run", {}).get("cross_gpu_barlow", False))
 
@@ -45,6 +47,7 @@ class Upstream_Expert(FusedExpertMixin, UpstreamModule):
     # ------------------------------------------------------------------ fused step
     def fused_loss(self, img_1, img_2, need_grad=True):
         dt = self.precision
+        E.set_high_precision(self.high_precision)
         enc = self.encoder.encoder
         flat = self.ensure_flat()
         if need_grad:
@@ -56,7 +59,7 @@ class Upstream_Expert(FusedExpertMixin, UpstreamModule):
         G = flat.grad_dict("encoder.encoder.")
         Wenc = flat.shadow_dict("encoder.encoder.")
         Wp = flat.shadow_dict("p.")
-        Y = torch.empty(2 * B, enc.d, dtype=torch.float32, device=img_1.device)          # both views, stacked, fp32
+        Y = torch.empty(2 * B, enc.d, dtype=E.pooled_dtype(dt), device=img_1.device)     # both views, stacked
         views = []
         for v, img in enumerate((img_1, img_2)):
             img = img.float().contiguous()

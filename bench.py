@@ -102,7 +102,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=512, help="per-GPU batch (weak scaling)")
-    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "bf16_hp", "fp32"])
     ap.add_argument("--queue", type=int, default=65536)
     ap.add_argument("--cpu-batch", type=int, default=32)
     ap.add_argument("--cpu-steps", type=int, default=4)
@@ -191,7 +191,8 @@ def main():
                 "share_of_step": round(tsec / dt, 3)}
     out = {"metric": "upstream clips/sec (1s@16kHz, 64-mel)", "value": round(B * world * args.steps / dt, 1), "unit": "clips/s",
            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
-           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
+           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16" if args.precision.startswith("bf16") else "f32",
+           "precision_mode": args.precision, "data": "synthetic",
            "config": {"workload": "delores-m upstream step (log-mel + 2 views + q/k conv encoders + MoCo + 3 Barlow heads + bwd + SGD), "
                                   f"1 s @ 16 kHz, 64 mel, batch {B}/GPU, queue {args.queue}", "global_batch": B * world,
                       "parallelism": f"dp{world}"},

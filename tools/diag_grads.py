@@ -19,7 +19,7 @@ a, b = views(B, T, 8800), views(B, T, 8801)
 mq, mk = drop_mask((B, Tp, 2048), 8802), drop_mask((B, Tp, 2048), 8803)
 parts = {}
 lr = ref.training_loss(a, b, mq, mk, parts); lr.backward()
-for prec in ("fp32", "bf16"):
+for prec in ("fp32", "bf16", "bf16_hp"):
     cfg = copy.deepcopy(conftest.CFG_M); cfg["run"]["precision"] = prec
     em = Upstream_Expert(cfg, base_encoder=AudioNTT2020Task6, num_negatives=K)
     fill.fill_state_dict_(em, seed=9)
