@@ -368,6 +368,9 @@ def projector_forward(PP, Y, dtype, groups, B, update_running=True, Wc=None):
         return _bn_train(ad, a, B, D, g, b, PP[prefix + ".running_mean"], PP[prefix + ".running_var"], update_running,
                          groups)
     td = N.torch_dtype(dtype)
+    ad = _ad(dtype)
+    c.ad = ad
+    o32 = int(ad == N.F32)
     # pre-BatchNorm tensors (a1, a2, z) are fp32 GEMM outputs on the fp32 / bf16_hp paths; the normalised activations
     # (MFMA operands) are `dtype`
     if dtype == N.BF16 and Y.dtype == torch.float32:
