@@ -279,8 +279,13 @@ extern "C" int audiossl_colstats(int dtype, const void* x, int groups, long M, i
     ASSL_REQUIRE(x && sum && groups > 0 && M > 0 && C > 0 && (C % 64) == 0 && (ld % 8) == 0);
     ASSL_REQUIRE((dtype == 0 || dtype == 1) && (!want_sq || sumsq));
     hipStream_t s = static_cast<hipStream_t>(stream);
-    if (hipMemsetAsync(sum, 0, sizeof(double) * C * groups, s) != hipSuccess) return ASSL_ELAUNCH;
-    if (want_sq && hipMemsetAsync(sumsq, 0, sizeof(double) * C * groups, s) != hipSuccess) return ASSL_ELAUNCH;
+    const size_t nb = sizeof(double) * C * groups;
+    if (want_sq && sumsq == sum + (size_t)C * groups) {            // contiguous scratch: one memset node
+        if (hipMemsetAsync(sum, 0, 2 * nb, s) != hipSuccess) return ASSL_ELAUNCH;
+    } else {
+        if (hipMemsetAsync(sum, 0, nb, s) != hipSuccess) return ASSL_ELAUNCH;
+        if (want_sq && hipMemsetAsync(sumsq, 0, nb, s) != hipSuccess) return ASSL_ELAUNCH;
+    }
     const int slabs = C / 64;
     long it = (M * slabs * groups + 32L * 2048 - 1) / (32L * 2048);  // aim for ~2048 blocks in total, 1..128 iterations each
     it = it < 1 ? 1 : (it > 128 ? 128 : it);

@@ -287,8 +287,12 @@ extern "C" int audiossl_conv3x3_fwd(const void* X, const void* W, const float* b
     if (!ASSL_ALIGNED16(X) || !ASSL_ALIGNED16(W) || !ASSL_ALIGNED16(Y)) return ASSL_EALIGN;
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (sum) {
-        if (hipMemsetAsync(sum, 0, sizeof(double) * 64, s) != hipSuccess) return ASSL_ELAUNCH;
-        if (hipMemsetAsync(sumsq, 0, sizeof(double) * 64, s) != hipSuccess) return ASSL_ELAUNCH;
+        if (sumsq == sum + 64) {
+            if (hipMemsetAsync(sum, 0, sizeof(double) * 128, s) != hipSuccess) return ASSL_ELAUNCH;
+        } else {
+            if (hipMemsetAsync(sum, 0, sizeof(double) * 64, s) != hipSuccess) return ASSL_ELAUNCH;
+            if (hipMemsetAsync(sumsq, 0, sizeof(double) * 64, s) != hipSuccess) return ASSL_ELAUNCH;
+        }
     }
     const int rows = N * Ti, TT = 256 / Fi, tiles = (rows + TT - 1) / TT;
     ConvArgs a{static_cast<const bf16*>(X), static_cast<const bf16*>(W), bias, static_cast<bf16*>(Y), sum, sumsq, Ti, rows, tiles, out_f32};

@@ -104,12 +104,13 @@ __device__ __forceinline__ void load_patch(float* patch, const float* __restrict
 }
 
 // conv outputs of the 2x2 pooling window at pooled mel row fp: y[p], p = 2*df + dt (torch's scan order)
-__device__ __forceinline__ void conv4(const float* patch, int fp, const float* w, float bias, float* y) {
-    float x[4][4];
+__device__ __forceinline__ void conv4(const float* patch, int fp, const float* w, float bias, float* y, float (*x)[4]) {
 #pragma unroll
-    for (int r = 0; r < 4; ++r)
+    for (int r = 0; r < 4; ++r) {                                              // rows f = 2fp-1 .. 2fp+2, one 16-byte read each
+        const f32x4 row = *reinterpret_cast<const f32x4*>(patch + (2 * fp + r) * 4);
 #pragma unroll
-        for (int k = 0; k < 4; ++k) x[r][k] = patch[(2 * fp + r) * 4 + k];      // rows f = 2fp-1 .. 2fp+2
+        for (int k = 0; k < 4; ++k) x[r][k] = row[k];
+    }
 #pragma unroll
     for (int df = 0; df < 2; ++df)
 #pragma unroll
@@ -141,8 +142,8 @@ __global__ __launch_bounds__(256) void conv1_fwd_kernel(const float* __restrict_
         load_patch(patch, img, n, tp, F, T);
         __syncthreads();
         for (int fp = wv; fp < Fo; fp += 4) {
-            float y[4];
-            conv4(patch, fp, wr, b, y);
+            float y[4], x[4][4];
+            conv4(patch, fp, wr, b, y, x);
             float m = fmaxf(sc * y[0] + sh, 0.f);
 #pragma unroll
             for (int p = 1; p < 4; ++p) m = fmaxf(m, fmaxf(sc * y[p] + sh, 0.f));
@@ -174,8 +175,8 @@ __global__ __launch_bounds__(256) void conv1_bwd_kernel(const float* __restrict_
         load_patch(patch, img, n, tp, F, T);
         __syncthreads();
         for (int fp = wv; fp < Fo; fp += 4) {
-            float y[4];
-            conv4(patch, fp, wr, b, y);
+            float y[4], x[4][4];
+            conv4(patch, fp, wr, b, y, x);
             int best = 0;
             float m = sc * y[0] + sh;
 #pragma unroll
@@ -193,7 +194,7 @@ __global__ __launch_bounds__(256) void conv1_bwd_kernel(const float* __restrict_
 #pragma unroll
                 for (int kh = 0; kh < 3; ++kh)
 #pragma unroll
-                    for (int kw = 0; kw < 3; ++kw) G[kh * 3 + kw] += dm * patch[(2 * fp + df + kh) * 4 + dt + kw];
+                    for (int kw = 0; kw < 3; ++kw) G[kh * 3 + kw] += dm * x[df + kh][dt + kw];      // registers, not LDS
             }
         }
     }

@@ -218,23 +218,33 @@ __global__ __launch_bounds__(64) void rowdot_kernel(const float* __restrict__ a,
 }
 
 // logits row = [lpos, lneg[0..K)] (already divided by temp); CE with label 0, mean over the batch.
+// ONE pass over the row (online softmax: running max + rescaled sum per thread, merged across the block).
+__device__ __forceinline__ void lse_merge(float& m, float& s, float om, float os) {
+    const float nm = fmaxf(m, om);
+    s = s * __expf(m - nm) + os * __expf(om - nm);
+    m = nm;
+}
 __global__ __launch_bounds__(256) void moco_ce_fwd_kernel(const float* __restrict__ lpos, const float* __restrict__ lneg, int K,
                                                           float inv_B, float* __restrict__ lse, float* __restrict__ loss_out) {
-    __shared__ float sh[16];
+    __shared__ float shm[4], shs[4];
     const long b = blockIdx.x;
     const float* row = lneg + b * K;
-    float m = lpos[b];
-    for (int k = threadIdx.x; k < K; k += 256) m = fmaxf(m, row[k]);
-    m = wave_max(m);
+    float m = -3.0e38f, s = 0.f;
+    const int K4 = K & ~3;
+    for (int k = threadIdx.x * 4; k < K4; k += 1024) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(row + k);
+        const float vm = fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3]));
+        if (vm > m) { s *= __expf(m - vm); m = vm; }
+        s += __expf(v[0] - m) + __expf(v[1] - m) + __expf(v[2] - m) + __expf(v[3] - m);
+    }
+    for (int k = K4 + threadIdx.x; k < K; k += 256) lse_merge(m, s, row[k], 1.f);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) lse_merge(m, s, __shfl_xor(m, o, 64), __shfl_xor(s, o, 64));
+    if ((threadIdx.x & 63) == 0) { shm[threadIdx.x >> 6] = m; shs[threadIdx.x >> 6] = s; }
     __syncthreads();
-    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = m;
-    __syncthreads();
-    m = fmaxf(fmaxf(sh[0], sh[1]), fmaxf(sh[2], sh[3]));
-    float s = 0.f;
-    for (int k = threadIdx.x; k < K; k += 256) s += expf(row[k] - m);
-    s = block_sum(s, sh);
     if (threadIdx.x == 0) {
-        s += expf(lpos[b] - m);
+        for (int w = 1; w < 4; ++w) lse_merge(m, s, shm[w], shs[w]);
+        lse_merge(m, s, lpos[b], 1.f);
         const float l = m + logf(s);
         lse[b] = l;
         atomicAdd(loss_out, (l - lpos[b]) * inv_B);
