@@ -226,9 +226,18 @@ __global__ __launch_bounds__(256) void bn_relu_pool_bwd_kernel(const TY* __restr
             const int kind = threadIdx.x >> 6, c = threadIdx.x & 63;
             float t = 0.f;
             for (int r = (c >> 3); r < 256; r += 8) t += red[r][kind * 8 + (c & 7)];
-            atomicAdd(&stat[kind * 64 + c], t);
+            atomicAdd(&stat[128 + (blockIdx.x & 31) * 128 + kind * 64 + c], t);      // one of 32 replicas (contention)
         }
     }
+}
+
+// stat[0..127] = sum over the 32 replicas stat[128 + r*128 + ...]
+__global__ void stat_reduce_kernel(float* stat) {
+    const int i = threadIdx.x;
+    if (i >= 128) return;
+    float t = 0.f;
+    for (int r = 0; r < 32; ++r) t += stat[128 + r * 128 + i];
+    stat[i] = t;
 }
 
 // -------------------------------------------------------------------------------------------- im2col 3x3
@@ -333,7 +342,7 @@ extern "C" int audiossl_tmean_fwd(int dtype, int out_f32, const void* P, void* x
     ASSL_LAUNCH_CHECK();
 }
 
-// stat: 128 floats scratch (zeroed here).  dgamma/dbeta accumulated (+=) by a tiny tail launch.
+// stat: 33*128 floats scratch (zeroed here).  dgamma/dbeta accumulated (+=) by a tiny tail launch.
 namespace {
 __global__ void add_stat_kernel(const float* __restrict__ stat, float* dgamma, float* dbeta) {
     const int c = threadIdx.x;
@@ -348,7 +357,7 @@ extern "C" int audiossl_bn_relu_pool_bwd(int dtype, int ydtype, int gdtype, cons
     ASSL_REQUIRE(N > 0 && Ti >= 2 && Fi >= 2 && (Fi % 2) == 0 && (dtype == 0 || dtype == 1) && (gdtype == 0 || gdtype == dtype));
     ASSL_REQUIRE(ydtype == 0 || ydtype == dtype);
     hipStream_t s = static_cast<hipStream_t>(stream);
-    if (hipMemsetAsync(stat, 0, sizeof(float) * 128, s) != hipSuccess) return ASSL_ELAUNCH;
+    if (hipMemsetAsync(stat, 0, sizeof(float) * 128 * 33, s) != hipSuccess) return ASSL_ELAUNCH;
     const long total = (long)N * ((Ti + 1) / 2) * (Fi / 2) * 8;
     const int grid = ceil_div(total, 256);
     const float inv_To = 1.f / (float)(Ti / 2);
@@ -356,7 +365,8 @@ extern "C" int audiossl_bn_relu_pool_bwd(int dtype, int ydtype, int gdtype, cons
 #define BW(TY, AP, TG, TO) hipLaunchKernelGGL((bn_relu_pool_bwd_kernel<TY, AP, TG, TO>), dim3(grid), dim3(256), 0, s,              \
         static_cast<const TY*>(Y), static_cast<const TG*>(dP), static_cast<const TG*>(dxl), inv_To, scale, shift, mean, rstd, stat, \
         inv_count, static_cast<TO*>(dY), N, Ti, Fi)
-#define BW2(TY, TG, TO) do { BW(TY, false, TG, TO); BW(TY, true, TG, TO); } while (0)
+#define BW2(TY, TG, TO) do { BW(TY, false, TG, TO); hipLaunchKernelGGL(stat_reduce_kernel, dim3(1), dim3(128), 0, s, stat); \
+                             BW(TY, true, TG, TO); } while (0)
     if (dtype == 0) BW2(float, float, float);
     else if (ydtype == 0 && gdtype == 0) BW2(float, float, bf16);
     else if (ydtype == 0) BW2(float, bf16, bf16);

@@ -103,6 +103,27 @@ __device__ __forceinline__ void load_patch(float* patch, const float* __restrict
     }
 }
 
+// Register-staged variant: fetch the NEXT item's patch while the current one is being consumed.
+struct PatchRegs {
+    float v[2];
+    __device__ __forceinline__ void fetch(const float* __restrict__ img, int n, int tp, int F, int T) {
+        const float* im = img + (long)n * F * T;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int i = threadIdx.x + j * 256;
+            const int f = (i >> 2) - 1, t = 2 * tp - 1 + (i & 3);
+            v[j] = (i < (F + 2) * 4 && f >= 0 && f < F && t >= 0 && t < T) ? im[f * T + t] : 0.f;
+        }
+    }
+    __device__ __forceinline__ void put(float* patch, int F) const {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int i = threadIdx.x + j * 256;
+            if (i < (F + 2) * 4) patch[i] = v[j];
+        }
+    }
+};
+
 // conv outputs of the 2x2 pooling window at pooled mel row fp: y[p], p = 2*df + dt (torch's scan order)
 __device__ __forceinline__ void conv4(const float* patch, int fp, const float* w, float bias, float* y, float (*x)[4]) {
 #pragma unroll
@@ -136,11 +157,14 @@ __global__ __launch_bounds__(256) void conv1_fwd_kernel(const float* __restrict_
 #pragma unroll
     for (int i = 0; i < 9; ++i) wr[i] = w[lane * 9 + i];
     const float b = bias[lane], sc = scale[lane], sh = shift[lane];
-    for (int item = blockIdx.x; item < N * To; item += gridDim.x) {
+    PatchRegs pre;
+    int item = blockIdx.x;
+    if (item < N * To) { pre.fetch(img, item / To, item % To, F, T); pre.put(patch, F); }
+    __syncthreads();
+    for (; item < N * To; item += gridDim.x) {
         const int n = item / To, tp = item - n * To;
-        __syncthreads();
-        load_patch(patch, img, n, tp, F, T);
-        __syncthreads();
+        const int nxt = item + gridDim.x;
+        if (nxt < N * To) pre.fetch(img, nxt / To, nxt % To, F, T);
         for (int fp = wv; fp < Fo; fp += 4) {
             float y[4], x[4][4];
             conv4(patch, fp, wr, b, y, x);
@@ -149,6 +173,9 @@ __global__ __launch_bounds__(256) void conv1_fwd_kernel(const float* __restrict_
             for (int p = 1; p < 4; ++p) m = fmaxf(m, fmaxf(sc * y[p] + sh, 0.f));
             out[(((long)n * To + tp) * Fo + fp) * 64 + lane] = from_f32<T_>(m);
         }
+        __syncthreads();
+        if (nxt < N * To) pre.put(patch, F);
+        __syncthreads();
     }
 }
 
@@ -169,20 +196,37 @@ __global__ __launch_bounds__(256) void conv1_bwd_kernel(const float* __restrict_
     for (int i = 0; i < 9; ++i) { wr[i] = w[lane * 9 + i]; G[i] = 0.f; }
     const float b = bias[lane], sc = scale[lane], sh = shift[lane], mu = mean[lane], rs = rstd[lane];
     float dbeta = 0.f, dgamma = 0.f;
-    for (int item = blockIdx.x; item < N * To; item += gridDim.x) {
+    PatchRegs pre;
+    int item = blockIdx.x;
+    if (item < N * To) { pre.fetch(img, item / To, item % To, F, T); pre.put(patch, F); }
+    __syncthreads();
+    for (; item < N * To; item += gridDim.x) {
         const int n = item / To, tp = item - n * To;
-        __syncthreads();
-        load_patch(patch, img, n, tp, F, T);
-        __syncthreads();
-        for (int fp = wv; fp < Fo; fp += 4) {
+        const int nxt = item + gridDim.x;
+        if (nxt < N * To) pre.fetch(img, nxt / To, nxt % To, F, T);
+        // all of this wave's pooled gradients of the item are fetched up front (<= 8 independent loads in flight): the
+        // per-pixel dependent load was the kernel's critical path (latency-bound at 0.5 TB/s)
+        float gin[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int fp = wv + 4 * i;
+            gin[i] = 0.f;
+            if (fp < Fo) {
+                gin[i] = to_f32(dP[(((long)n * To + tp) * Fo + fp) * 64 + lane]);
+                if (dxl) gin[i] += to_f32(dxl[(long)n * Fo * 64 + fp * 64 + lane]) * inv_To;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int fp = wv + 4 * i;
+            if (fp >= Fo) break;
             float y[4], x[4][4];
             conv4(patch, fp, wr, b, y, x);
             int best = 0;
             float m = sc * y[0] + sh;
 #pragma unroll
             for (int p = 1; p < 4; ++p) { const float a = sc * y[p] + sh; if (a > m) { m = a; best = p; } }
-            float g = to_f32(dP[(((long)n * To + tp) * Fo + fp) * 64 + lane]);
-            if (dxl) g += to_f32(dxl[(long)n * Fo * 64 + fp * 64 + lane]) * inv_To;
+            const float g = gin[i];
             const float da = m > 0.f ? g : 0.f;
             const float ybest = best == 0 ? y[0] : best == 1 ? y[1] : best == 2 ? y[2] : y[3];
             dbeta += da;
@@ -197,6 +241,9 @@ __global__ __launch_bounds__(256) void conv1_bwd_kernel(const float* __restrict_
                     for (int kw = 0; kw < 3; ++kw) G[kh * 3 + kw] += dm * x[df + kh][dt + kw];      // registers, not LDS
             }
         }
+        __syncthreads();
+        if (nxt < N * To) pre.put(patch, F);
+        __syncthreads();
     }
 #pragma unroll
     for (int i = 0; i < 9; ++i) red[wv][lane][i] = G[i];
@@ -205,7 +252,8 @@ __global__ __launch_bounds__(256) void conv1_bwd_kernel(const float* __restrict_
     __syncthreads();
     for (int i = threadIdx.x; i < 64 * 11; i += 256) {
         const int c = i / 11, k = i - c * 11;
-        atomicAdd(&acc[i], red[0][c][k] + red[1][c][k] + red[2][c][k] + red[3][c][k]);
+        // 32 replicas of the accumulator (same-address float atomics from every workgroup serialise at the memory side)
+        atomicAdd(&acc[(blockIdx.x & 31) * 704 + i], red[0][c][k] + red[1][c][k] + red[2][c][k] + red[3][c][k]);
     }
 }
 
@@ -216,13 +264,19 @@ __global__ void conv1_bwd_finalize_kernel(const float* __restrict__ acc, const d
                                           float* dgamma, float* dbeta) {
     const int c = threadIdx.x;
     if (c >= 64) return;
-    const double db = acc[c * 11 + 9], dg = acc[c * 11 + 10];
+    double a11[11];
+    for (int k = 0; k < 11; ++k) {
+        double t = 0.0;
+        for (int r = 0; r < 32; ++r) t += (double)acc[r * 704 + c * 11 + k];
+        a11[k] = t;
+    }
+    const double db = a11[9], dg = a11[10];
     const double rs = rstd[c], mu = mean[c], gm = gamma[c];
     for (int t = 0; t < 9; ++t) {
         double wS2 = 0.0;
         for (int a = 0; a < 9; ++a) wS2 += (double)w[c * 9 + a] * mom[9 + (a <= t ? tri(a, t) : tri(t, a))];
         const double yhat_x = rs * (wS2 + ((double)bias[c] - mu) * mom[t]);           // sum_pos yhat_c * x_tap
-        const double v = gm * rs * ((double)acc[c * 11 + t] - db / count * mom[t] - dg / count * yhat_x);
+        const double v = gm * rs * (a11[t] - db / count * mom[t] - dg / count * yhat_x);
         dW[c * 9 + t] += (float)v;
     }
     dgamma[c] += (float)dg;
@@ -250,7 +304,7 @@ extern "C" int audiossl_conv1_stats(const float* img, int N, int F, int T, const
 
 extern "C" int audiossl_conv1_fwd(int dtype, const float* img, int N, int F, int T, const float* w, const float* bias,
                                   const float* scale, const float* shift, void* out, void* stream) {
-    ASSL_REQUIRE(img && w && bias && scale && shift && out && N > 0 && F >= 2 && T >= 2 && (F % 2) == 0);
+    ASSL_REQUIRE(img && w && bias && scale && shift && out && N > 0 && F >= 2 && F <= 126 && T >= 2 && (F % 2) == 0);
     ASSL_REQUIRE(dtype == 0 || dtype == 1);
     hipStream_t s = static_cast<hipStream_t>(stream);
     const int grid = min(N * (T / 2), 2048);
@@ -264,16 +318,16 @@ extern "C" int audiossl_conv1_fwd(int dtype, const float* img, int N, int F, int
     ASSL_LAUNCH_CHECK();
 }
 
-// acc: 64*11 floats of scratch (zeroed here).  dxl may be null.  Grad outputs are accumulated (+=).
+// acc: 32*64*11 floats of scratch (zeroed here).  dxl may be null.  Grad outputs are accumulated (+=).
 extern "C" int audiossl_conv1_bwd(int dtype, const float* img, int N, int F, int T, const float* w, const float* bias,
                                   const float* gamma, const float* scale, const float* shift, const float* mean,
                                   const float* rstd, const double* mom, const void* dP, const void* dxl, float* acc,
                                   float* dW, float* dbias, float* dgamma, float* dbeta, void* stream) {
     ASSL_REQUIRE(img && w && bias && gamma && scale && shift && mean && rstd && mom && dP && acc && dW && dgamma && dbeta);
-    ASSL_REQUIRE(N > 0 && F >= 2 && T >= 2 && (F % 2) == 0 && (dtype == 0 || dtype == 1));
+    ASSL_REQUIRE(N > 0 && F >= 2 && F <= 64 && T >= 2 && (F % 2) == 0 && (dtype == 0 || dtype == 1));
     hipStream_t s = static_cast<hipStream_t>(stream);
-    if (hipMemsetAsync(acc, 0, sizeof(float) * 64 * 11, s) != hipSuccess) return ASSL_ELAUNCH;
-    const int grid = min(N * (T / 2), 1024);
+    if (hipMemsetAsync(acc, 0, sizeof(float) * 32 * 64 * 11, s) != hipSuccess) return ASSL_ELAUNCH;
+    const int grid = min(N * (T / 2), 2048);
     const size_t lds = sizeof(float) * (F + 2) * 4;
     const float inv_To = 1.f / (float)(T / 2);
     if (dtype == 0)

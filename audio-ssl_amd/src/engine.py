@@ -256,7 +256,7 @@ def _conv_block_bwd(dtype, Y, dP, dxl, st, Nimg, Ti, Fi, Pin, Wd, G_w, G_gamma, 
     scale, shift, mean, rstd = st
     M = Nimg * Ti * Fi
     dY = torch.empty((M, 64), dtype=td, device=Y.device)
-    stat = _empty((128,), torch.float32, like=Y)
+    stat = _empty((33 * 128,), torch.float32, like=Y)
     N.call("bn_relu_pool_bwd", dtype, N.F32 if Y.dtype == torch.float32 else dtype, GD, Y, dP, dxl, scale, shift, mean, rstd, stat, dY, G_gamma, G_beta, Nimg, Ti, Fi)
     # wgrad: dWp[co][tap*64+ci] = sum_pix dY[pix][co] * Pin[pix + off(tap)][ci]
     fused = dtype == N.BF16 and Fi in (16, 32)
@@ -317,7 +317,7 @@ def encoder_backward(c, G, dA2=None, dH2=None, dx1=None, dx2=None, dx3=None):
                           G["features_3.1.weight"], G["features_3.1.bias"], True, col, keep)
     dP1 = _conv_block_bwd(dtype, c.Y2, dP2, dx2, c.st2, Nimg, T1, F1, c.P1, c.W2d, G["features_2.0.weight"],
                           G["features_2.1.weight"], G["features_2.1.bias"], True, col, keep)
-    acc = _empty((64 * 11,), torch.float32, like=c.H2)
+    acc = _empty((32 * 64 * 11,), torch.float32, like=c.H2)
     P = c.P
     N.call("conv1_bwd", GD, c.img, Nimg, c.F, c.T, P["features_1.0.weight"].reshape(64, 9), P["features_1.0.bias"],
            P["features_1.1.weight"], c.sc1, c.sh1, c.mean1, c.rstd1, c.mom1, dP1, dx1, acc,

@@ -78,7 +78,8 @@ int audiossl_mask_fill(float* x, const int* tab, int n_img, int max_masks, int F
  * conv1_stats: batch statistics of Conv2d(1,64,3,p=1) output from 54 tap moments (`mom`, fp64 scratch, kept for
  *   the backward); updates running stats; writes scale = gamma*rstd, shift = beta - mean*scale, mean, rstd.
  * conv1_fwd : img [N][F][T] f32 -> pooled [N][T/2][F/2][64] (dtype), conv recomputed, nothing else stored.
- * conv1_bwd : dP (+ dxl [N][F/2*64] / (T/2), may be NULL) -> dW [64][9], dgamma, dbeta (dbias == 0). */
+ * conv1_bwd : dP (+ dxl [N][F/2*64] / (T/2), may be NULL) -> dW [64][9], dgamma, dbeta (dbias == 0); acc = 32*704
+ *             floats of scratch. */
 int audiossl_conv1_stats(const float* img, int N, int F, int T, const float* w, const float* bias, const float* gamma,
                          const float* beta, float* running_mean, float* running_var, float momentum, float eps,
                          double* mom, float* scale, float* shift, float* save_mean, float* save_rstd, void* stream);
@@ -95,7 +96,7 @@ int audiossl_conv1_bwd(int dtype, const float* img, int N, int F, int T, const f
  * bn_finalize: train-mode BatchNorm statistics -> per-group scale/shift/mean/rstd [G][C]; running stats (momentum 0.1)
  *            are updated group after group, as the reference's successive module calls do.
  * bn_relu_pool_fwd: Y [N][Ti][Fi][64] -> P [N][Ti/2][Fi/2][64].   tmean_fwd: P -> xl [N][Fo*64] (x_1/x_2/x_3).
- * bn_relu_pool_bwd: dP (+dxl/To) -> dY at every position, dgamma, dbeta (stat = 128 floats scratch).
+ * bn_relu_pool_bwd: dP (+dxl/To) -> dY at every position, dgamma, dbeta (stat = 33*128 floats scratch).
  * im2col3x3 / pack_conv_w / unpack_conv_dw: implicit-GEMM plumbing, tap = kh*3+kw, kh on mel, kw on time. */
 int audiossl_colstats(int dtype, const void* x, int groups, long M, int C, long ld, int want_sq, double* sum,
                       double* sumsq, void* stream);

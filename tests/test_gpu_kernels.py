@@ -228,7 +228,7 @@ def test_conv1_block_fwd_bwd(N, dtype, T):
 
     dP = dev(gP.permute(0, 3, 2, 1)).to(td)
     dxl = dev(gX1).to(td)
-    acc = torch.empty(64 * 11, device="cuda")
+    acc = torch.empty(32 * 64 * 11, device="cuda")
     dW, db, dg, dbt = (torch.zeros(s, device="cuda") for s in ((64, 9), (64,), (64,), (64,)))
     N.call("conv1_bwd", dtype, img, Nimg, F_, T, w, b, gamma, scale, shift, mean, rstd, mom, dP, dxl, acc, dW, db, dg, dbt)
     torch.cuda.synchronize()
