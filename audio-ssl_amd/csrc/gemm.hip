@@ -16,8 +16,10 @@
 
 namespace {
 
-constexpr int BM = 128, BN = 128, BK = 32;
-constexpr int NT_PITCH = BK + 8;      // elements; [row][k] image, conflict-free 16-byte row reads
+constexpr int BM = 128, BN = 128;
+// K-step per launch: bf16 64 when the grid fills the chip several times over (73 KB of LDS -> 2 workgroups / CU), 128 when
+// there is at most one workgroup per CU anyway (the loop is then latency-bound per step: fewer, fatter steps win;
+// measured 40 -> 26 us on 1024x2048x2048).  fp32 (validation path): 32.
 constexpr int TR_PITCH = 128 + 32;    // elements; [k][row] image: 80-dword rows keep ds_read_b64_tr_b16 conflict-free
 
 struct GemmArgs {
@@ -54,9 +56,13 @@ template <> struct Mma<float> {
 };
 
 // One operand's staging: 128 rows x 32 k per step, two Vec8 per thread.
-template <typename T, bool TRANS>
+template <typename T, bool TRANS, int BK_>
 struct Stage {
-    Vec8<T> r[2];
+    static constexpr int BK = BK_;
+    static constexpr int NT_PITCH = BK + 8;          // elements; [row][k] image, conflict-free 16-byte row reads
+    static constexpr int NV = BM * BK / 8 / 256;     // 8-element vectors per thread and step
+    static constexpr int VPR = BK / 8;               // vectors per row of the [row][k] image
+    Vec8<T> r[NV];
     // Branch-free staging loads: a raw buffer load per 16 bytes, out-of-range vectors get an offset past the
     // descriptor's extent and come back as zeros (no exec-masked branches -> the compiler keeps counted vmcnt waits).
     // rows = extent of the row dimension (M or N); kend = exclusive K bound of this split
@@ -74,11 +80,11 @@ struct Stage {
     __device__ __forceinline__ void load(__amdgpu_buffer_rsrc_t rs, long ld, int row0, int rows, int k0, int kend) {
         const int t = threadIdx.x;
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
+        for (int i = 0; i < NV; ++i) {
             const int v = t + i * 256;
             int row, k;
             long idx;
-            if (!TRANS) { row = row0 + (v >> 2); k = k0 + (v & 3) * 8; idx = (long)row * ld + k; }
+            if (!TRANS) { row = row0 + v / VPR; k = k0 + (v % VPR) * 8; idx = (long)row * ld + k; }
             else        { k = k0 + (v >> 4); row = row0 + (v & 15) * 8; idx = (long)k * ld + row; }
             const unsigned off = (row < rows && k < kend) ? (unsigned)(idx * (long)sizeof(T)) : 0xFFFFFFE0u;
             r[i] = select_load(rs, off, (T*)nullptr);
@@ -89,9 +95,9 @@ struct Stage {
     __device__ __forceinline__ void put(T* lds) const {
         const int t = threadIdx.x;
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
+        for (int i = 0; i < NV; ++i) {
             const int v = t + i * 256;
-            if (!TRANS) r[i].store(lds + (v >> 2) * NT_PITCH + (v & 3) * 8);
+            if (!TRANS) r[i].store(lds + (v / VPR) * NT_PITCH + (v % VPR) * 8);
             else        r[i].store(lds + (v >> 4) * TR_PITCH + (v & 15) * 8);
         }
     }
@@ -123,10 +129,10 @@ struct Stage {
     static constexpr int LDS_ELEMS = TRANS ? BK * TR_PITCH : BM * NT_PITCH;
 };
 
-template <typename T, bool TA, bool TB>
+template <typename T, bool TA, bool TB, int BK>
 __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
-    using SA = Stage<T, TA>;
-    using SB = Stage<T, TB>;
+    using SA = Stage<T, TA, BK>;
+    using SB = Stage<T, TB, BK>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     T* const ldsA0 = reinterpret_cast<T*>(smem);                 // two A buffers, then two B buffers
     T* const ldsB0 = ldsA0 + 2 * SA::LDS_ELEMS;
@@ -213,26 +219,26 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
         }
 }
 
-template <typename T, bool TA, bool TB>
+template <typename T, bool TA, bool TB, int BK>
 int launch(const GemmArgs& g, hipStream_t s) {
-    const size_t lds = sizeof(T) * 2 * (Stage<T, TA>::LDS_ELEMS + Stage<T, TB>::LDS_ELEMS);
+    const size_t lds = sizeof(T) * 2 * (Stage<T, TA, BK>::LDS_ELEMS + Stage<T, TB, BK>::LDS_ELEMS);
     static bool attr_set = false;
     if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<T, TA, TB>),
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<T, TA, TB, BK>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return ASSL_ELAUNCH;
         attr_set = true;
     }
     const int tiles = ceil_div(g.M, BM) * ceil_div(g.N, BN);
-    hipLaunchKernelGGL((gemm_kernel<T, TA, TB>), dim3(tiles, 1, g.ksplit), dim3(256), lds, s, g);
+    hipLaunchKernelGGL((gemm_kernel<T, TA, TB, BK>), dim3(tiles, 1, g.ksplit), dim3(256), lds, s, g);
     ASSL_LAUNCH_CHECK();
 }
 
-template <typename T>
+template <typename T, int BK>
 int dispatch(const GemmArgs& g, int ta, int tb, hipStream_t s) {
-    if (!ta && !tb) return launch<T, false, false>(g, s);
-    if (!ta && tb) return launch<T, false, true>(g, s);
-    if (ta && tb) return launch<T, true, true>(g, s);
-    return launch<T, true, false>(g, s);
+    if (!ta && !tb) return launch<T, false, false, BK>(g, s);
+    if (!ta && tb) return launch<T, false, true, BK>(g, s);
+    if (ta && tb) return launch<T, true, true, BK>(g, s);
+    return launch<T, true, false, BK>(g, s);
 }
 
 }  // namespace
@@ -256,5 +262,7 @@ extern "C" int audiossl_gemm(int dtype, int trans_a, int trans_b, int M, int N, 
     GemmArgs g{A, B, C, M, N, K, lda, ldb, ldc, alpha, bias, relu, keep, ldk, keep_scale, gate, ldg,
                (dtype == 0) ? 1 : out_f32, atomic, ksplit, (unsigned)a_ext, (unsigned)b_ext};
     hipStream_t s = static_cast<hipStream_t>(stream);
-    return dtype == 0 ? dispatch<float>(g, trans_a, trans_b, s) : dispatch<bf16>(g, trans_a, trans_b, s);
+    if (dtype == 0) return dispatch<float, 32>(g, trans_a, trans_b, s);
+    const long blocks = (long)ceil_div(M, BM) * ceil_div(N, BN) * ksplit;
+    return blocks <= 256 && K >= 512 ? dispatch<bf16, 128>(g, trans_a, trans_b, s) : dispatch<bf16, 64>(g, trans_a, trans_b, s);
 }
