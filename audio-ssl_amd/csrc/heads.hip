@@ -283,14 +283,22 @@ __global__ __launch_bounds__(64) void l2norm_bwd_kernel(const float* __restrict_
 // queue[:, ptr:ptr+B] = keys^T  (fp32 master [D][K] + T_ shadow)
 template <typename T_>
 __global__ __launch_bounds__(256) void enqueue_kernel(const float* __restrict__ keys, int B, int D, int K, int ptr,
-                                                      float* __restrict__ queue, T_* __restrict__ shadow) {
+                                                      const long long* __restrict__ ptr_dev, float* __restrict__ queue,
+                                                      T_* __restrict__ shadow) {
     const int idx = blockIdx.x * 256 + threadIdx.x;
     if (idx >= B * D) return;
+    if (ptr_dev) {                                      // write position kept on the device (hipGraph replay)
+        const long long pd = ptr_dev[0];
+        if (pd < 0 || pd + B > K) return;
+        ptr = (int)pd;
+    }
     const int d = idx / B, b = idx % B;
     const float v = keys[(long)b * D + d];
     queue[(long)d * K + ptr + b] = v;
     if (shadow) shadow[(long)d * K + ptr + b] = from_f32<T_>(v);
 }
+
+__global__ void advance_ptr_kernel(long long* ptr_dev, int B, int K) { ptr_dev[0] = (ptr_dev[0] + B) % K; }
 
 // --------------------------------------------------------------------------------------------- flat-buffer plumbing
 // torch.optim.SGD: g += wd*p; buf = first ? g : mom*buf + g; p -= lr*buf
@@ -339,7 +347,9 @@ __global__ __launch_bounds__(256) void cast_back_kernel(const T_* __restrict__ s
 }
 
 // counter-based keep mask: keep iff hash(seed, index) >= p * 2^32  (splitmix64 finaliser)
-__global__ __launch_bounds__(256) void dropout_mask_kernel(uint8_t* __restrict__ keep, long n, unsigned long long seed, float p) {
+__global__ __launch_bounds__(256) void dropout_mask_kernel(uint8_t* __restrict__ keep, long n, unsigned long long seed, float p,
+                                                           const long long* __restrict__ counter) {
+    if (counter) seed = (seed + (unsigned long long)counter[0]) & 0xFFFFFFFFFFFFull;
     const unsigned int thr = (unsigned int)fminf(p * 4294967296.f, 4294967295.f);
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
         unsigned long long z = seed + 0x9E3779B97F4A7C15ull * (unsigned long long)(i + 1);
@@ -466,11 +476,14 @@ extern "C" int audiossl_l2norm_bwd(int dtype, const float* dqn, const float* dlp
     ASSL_LAUNCH_CHECK();
 }
 
-extern "C" int audiossl_enqueue(int dtype, const float* keys, int B, int D, int K, int ptr, float* queue, void* shadow, void* stream) {
-    ASSL_REQUIRE(keys && queue && B > 0 && D > 0 && K > 0 && ptr >= 0 && ptr + B <= K && (dtype == 0 || dtype == 1));
+extern "C" int audiossl_enqueue(int dtype, const float* keys, int B, int D, int K, int ptr, long long* ptr_dev, float* queue,
+                                void* shadow, void* stream) {
+    ASSL_REQUIRE(keys && queue && B > 0 && D > 0 && K > 0 && B <= K && (dtype == 0 || dtype == 1));
+    ASSL_REQUIRE(ptr_dev || (ptr >= 0 && ptr + B <= K));
     const int grid = ceil_div((long)B * D, 256);
-    if (dtype == 0) hipLaunchKernelGGL(enqueue_kernel<float>, dim3(grid), dim3(256), 0, S_(stream), keys, B, D, K, ptr, queue, (float*)shadow);
-    else            hipLaunchKernelGGL(enqueue_kernel<bf16>, dim3(grid), dim3(256), 0, S_(stream), keys, B, D, K, ptr, queue, (bf16*)shadow);
+    if (dtype == 0) hipLaunchKernelGGL(enqueue_kernel<float>, dim3(grid), dim3(256), 0, S_(stream), keys, B, D, K, ptr, ptr_dev, queue, (float*)shadow);
+    else            hipLaunchKernelGGL(enqueue_kernel<bf16>, dim3(grid), dim3(256), 0, S_(stream), keys, B, D, K, ptr, ptr_dev, queue, (bf16*)shadow);
+    if (ptr_dev) hipLaunchKernelGGL(advance_ptr_kernel, dim3(1), dim3(1), 0, S_(stream), ptr_dev, B, K);
     ASSL_LAUNCH_CHECK();
 }
 
@@ -506,10 +519,10 @@ extern "C" int audiossl_cast_back(int dtype, const void* src, float* dst, long n
     ASSL_LAUNCH_CHECK();
 }
 
-extern "C" int audiossl_dropout_mask(uint8_t* keep, long n, unsigned long long seed, float p, void* stream) {
+extern "C" int audiossl_dropout_mask(uint8_t* keep, long n, unsigned long long seed, float p, const long long* counter, void* stream) {
     ASSL_REQUIRE(keep && n > 0 && p >= 0.f && p < 1.f);
     const int grid = (int)min((long)4096, (n + 255) / 256);
-    hipLaunchKernelGGL(dropout_mask_kernel, dim3(grid), dim3(256), 0, S_(stream), keep, n, seed, p);
+    hipLaunchKernelGGL(dropout_mask_kernel, dim3(grid), dim3(256), 0, S_(stream), keep, n, seed, p, counter);
     ASSL_LAUNCH_CHECK();
 }
 

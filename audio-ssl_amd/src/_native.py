@@ -75,23 +75,44 @@ def _ptr(x):
     return int(x)
 
 
-def call(name, *args):
-    """Call `audiossl_<name>`; the trailing `stream` argument is filled with torch's current HIP stream."""
+_FAST = {}            # short or full name -> (full name, bound ctypes function, per-argument "is a pointer" flags)
+_raw_stream = torch._C._cuda_getCurrentRawStream
+_cur_device = torch._C._cuda_getDevice
+
+
+def _entry(name):
     full = name if name.startswith("audiossl_") else "audiossl_" + name
     proto = PROTOS[full]
     if proto[-1][0] != "stream":
         raise TypeError(f"{full} is a host entry point; use call_host")
-    if len(args) != len(proto) - 1:
-        raise TypeError(f"{full} takes {len(proto) - 1} arguments (+stream), got {len(args)}")
+    e = _FAST[name] = (full, getattr(lib(), full), tuple(ty is ctypes.c_void_p for _, ty in proto[:-1]))
+    return e
+
+
+def call(name, *args):
+    """Call `audiossl_<name>`; the trailing `stream` argument is filled with torch's current HIP stream.
+    This wrapper is on the launch path of every kernel (about 270 per training step), so it is kept flat."""
+    e = _FAST.get(name)
+    if e is None:
+        e = _entry(name)
+    full, fn, is_ptr = e
+    if len(args) != len(is_ptr):
+        raise TypeError(f"{full} takes {len(is_ptr)} arguments (+stream), got {len(args)}")
     conv = []
-    for (an, ty), v in zip(proto, args):
-        conv.append(_ptr(v) if ty is ctypes.c_void_p else v)
-    conv.append(torch.cuda.current_stream().cuda_stream)
+    for p, v in zip(is_ptr, args):
+        if p and v is not None and not isinstance(v, int):
+            if not v.is_cuda:
+                raise RuntimeError("audiossl HIP kernels need device tensors (no CPU fallback exists)")
+            if not v.is_contiguous():
+                raise RuntimeError("audiossl HIP kernels need contiguous tensors")
+            v = v.data_ptr()
+        conv.append(v)
+    conv.append(_raw_stream(_cur_device()))
     prof = PROFILE.get(full) if PROFILE is not None else None
     if prof is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-    rc = getattr(lib(), full)(*conv)
+    rc = fn(*conv)
     if prof is not None:
         e1.record()
         prof.append((e0, e1, tuple(a for a in args if isinstance(a, (int, float)))))

@@ -274,6 +274,22 @@ class AugmentationModule:
         if self.bank is None and n is not None:
             self.bank = torch.zeros(self.R, n, dtype=torch.float32, device=device)
 
+    def _upload(self, key, arr, dev, depth=4):
+        """Host table -> device through a small ring of PINNED staging buffers.  A pageable source would make the copy
+        synchronous, i.e. one host/device rendezvous per step that keeps the launch side from running ahead."""
+        ring = self.__dict__.setdefault("_staging", {}).setdefault((key, arr.shape, arr.dtype.str), {"i": 0, "slots": []})
+        if len(ring["slots"]) < depth:
+            ring["slots"].append([torch.from_numpy(np.empty_like(arr)).pin_memory(), None])
+        slot = ring["slots"][ring["i"] % len(ring["slots"])]
+        ring["i"] += 1
+        if slot[1] is not None:
+            slot[1].synchronize()                       # the copy that last used this slot (depth steps ago)
+        slot[0].numpy()[...] = arr
+        out = slot[0].to(dev, non_blocking=True)
+        slot[1] = torch.cuda.Event()
+        slot[1].record()
+        return out
+
     def _ensure_bank(self, B, n, device):
         self._ensure_ring(B, n, device)
 
@@ -307,8 +323,8 @@ class AugmentationModule:
         N.call("aug_normalize", lms, mu, sd, self.bank, slot0, self.R, B, n)
         ip, fp, (ch, cw), masks = plan
         self.last_plan = (ip, fp, masks)
-        ip_d = torch.from_numpy(ip).to(dev, non_blocking=True)
-        fp_d = torch.from_numpy(fp).to(dev, non_blocking=True)
+        ip_d = self._upload("ip", ip, dev)
+        fp_d = self._upload("fp", fp, dev)
         v1 = torch.empty(B, 1, F, T, dtype=torch.float32, device=dev)
         v2 = torch.empty(B, 1, F, T, dtype=torch.float32, device=dev)
         log_mix = 1 if (self.mix is None or self.mix.log_mixup_exp) else 0
@@ -320,7 +336,7 @@ class AugmentationModule:
                 for k, (axis, st, en) in enumerate(ms):
                     tab[idx // 2, idx % 2, k] = (axis, st, en, 0)
             for v, view in enumerate((v1, v2)):
-                t = torch.from_numpy(np.ascontiguousarray(tab[:, v])).to(dev)
+                t = self._upload(f"mask{v}", np.ascontiguousarray(tab[:, v]), dev)
                 N.call("mask_fill", view, t, B, K, F, T, int(self.spec.zero))
         return v1, v2
 

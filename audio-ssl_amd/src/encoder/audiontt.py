@@ -48,15 +48,22 @@ class DropoutMasks:
     (the reference draws from torch's CPU generator, which a GPU cannot reproduce - masks are inputs of parity tests)."""
 
     def __init__(self, p=0.3, seed=0x5EED):
-        self.p, self.seed, self.calls, self.queue = p, seed, 0, []
+        self.p, self.seed, self.queue = p, seed, []
+        self.counter = None          # device int64: masks drawn so far (kept on the GPU so a hipGraph replay advances it)
+
+    @property
+    def calls(self):
+        return 0 if self.counter is None else int(self.counter[0])
 
     def next(self, M, d, device):
         if self.queue:
             m = self.queue.pop(0)
             return m.reshape(M, d).to(device=device, dtype=torch.uint8).contiguous()
         keep = torch.empty(M, d, dtype=torch.uint8, device=device)
-        self.calls += 1
-        N.call("dropout_mask", keep, M * d, (self.seed * 0x9E3779B1 + self.calls) & 0xFFFFFFFFFFFF, self.p)
+        if self.counter is None or self.counter.device != keep.device:
+            self.counter = torch.zeros(1, dtype=torch.int64, device=device)
+        self.counter.add_(1)
+        N.call("dropout_mask", keep, M * d, (self.seed * 0x9E3779B1) & 0xFFFFFFFFFFFF, self.p, self.counter)
         return keep
 
 
@@ -105,9 +112,8 @@ class AudioNTT2020Task6(nn.Module, NetworkCommonMixIn):
 
     def param_dict(self):
         """Reference-keyed fp32 tensors (parameters and BatchNorm buffers)."""
-        P = {n: p.data for n, p in self.named_parameters()}
-        P.update({n: b for n, b in self.named_buffers()})
-        return P
+        from src.flat import cached_param_dict
+        return cached_param_dict(self)
 
     def next_keep_mask(self, n_img, T):
         if not self.training:

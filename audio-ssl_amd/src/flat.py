@@ -12,6 +12,18 @@ def _align(n, a=64):
     return (n + a - 1) // a * a
 
 
+def cached_param_dict(mod):
+    """name -> fp32 tensor for every parameter and buffer of `mod`.  The step asks for this several times per
+    iteration; the dictionary is rebuilt only when the storage moved (`.to()`, re-flattening)."""
+    p0 = next(mod.parameters())
+    c = mod.__dict__.get("_pd_cache")
+    if c is None or c[0] != p0.data_ptr():
+        P = {n: p.data for n, p in mod.named_parameters()}
+        P.update({n: b for n, b in mod.named_buffers()})
+        c = mod.__dict__["_pd_cache"] = (p0.data_ptr(), P)
+    return c[1]
+
+
 class FlatGroup:
     def __init__(self, named_params, device=None):
         self.names = [n for n, _ in named_params]
@@ -26,10 +38,17 @@ class FlatGroup:
         self.grad = torch.zeros(off, dtype=torch.float32, device=device)
         self.momentum = None
         self._shadow = None
+        self._views = {}                       # cached view dictionaries (the step asks for the same ones every time)
         for p, o in zip(self.params, self.offsets):
             v = self.data[o:o + p.numel()].view(p.shape)
             v.copy_(p.data)
             p.data = v
+
+    def intact(self):
+        """True while the parameters still alias this buffer (a `.to()` / re-assignment of p.data breaks it)."""
+        p0, pl = self.params[0], self.params[-1]
+        base = self.data.data_ptr()
+        return p0.data_ptr() == base and pl.data_ptr() == base + 4 * self.offsets[-1] and p0.device == self.data.device
 
     def refresh_shadow(self, dtype):
         """One cast launch over the whole buffer: bf16 copies of every weight for the MFMA GEMMs of this step."""
@@ -44,22 +63,34 @@ class FlatGroup:
     def shadow_dict(self, prefix=""):
         """name (prefix stripped) -> weight in the activation dtype (the fp32 parameter itself on the fp32 path)."""
         src = self.data if self._shadow is None else self._shadow
-        out = {}
-        for n, p, o in zip(self.names, self.params, self.offsets):
-            if n.startswith(prefix):
-                out[n[len(prefix):]] = src[o:o + p.numel()].view(p.shape)
+        key = ("w", prefix, src.data_ptr())
+        out = self._views.get(key)
+        if out is None:
+            out = {}
+            for n, p, o in zip(self.names, self.params, self.offsets):
+                if n.startswith(prefix):
+                    out[n[len(prefix):]] = src[o:o + p.numel()].view(p.shape)
+            self._views[key] = out
         return out
 
     def grad_view(self, i):
         p, o = self.params[i], self.offsets[i]
         return self.grad[o:o + p.numel()].view(p.shape)
 
+    def grad_views(self):
+        key = ("g", self.grad.data_ptr())
+        out = self._views.get(key)
+        if out is None:
+            out = self._views[key] = [self.grad_view(i) for i in range(len(self.params))]
+        return out
+
     def grad_dict(self, prefix=""):
         """name (with `prefix` stripped) -> fp32 view into the flat gradient."""
-        out = {}
-        for i, n in enumerate(self.names):
-            if n.startswith(prefix):
-                out[n[len(prefix):]] = self.grad_view(i)
+        key = ("gd", prefix, self.grad.data_ptr())
+        out = self._views.get(key)
+        if out is None:
+            gv = self.grad_views()
+            out = self._views[key] = {n[len(prefix):]: gv[i] for i, n in enumerate(self.names) if n.startswith(prefix)}
         return out
 
     def param_dict(self, prefix=""):
@@ -72,13 +103,12 @@ class FlatGroup:
         """Expose the flat gradient through p.grad (alias when p.grad is None, else accumulate)."""
         if scale is not None:
             self.grad.mul_(scale)
-        for i, p in enumerate(self.params):
+        for p, g in zip(self.params, self.grad_views()):
             if not p.requires_grad:
                 continue
-            g = self.grad_view(i)
             if p.grad is None:
                 p.grad = g
-            elif p.grad.data_ptr() != g.data_ptr():
+            elif p.grad is not g and p.grad.data_ptr() != g.data_ptr():
                 p.grad.add_(g)
 
     def to(self, device):
@@ -88,6 +118,8 @@ class FlatGroup:
         self.data = new
         self.grad = torch.zeros_like(new)
         self.momentum = None
+        self._shadow = None
+        self._views = {}
         for p, o in zip(self.params, self.offsets):
             p.data = new[o:o + p.numel()].view(p.shape)
             p.grad = None

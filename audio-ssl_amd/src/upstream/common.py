@@ -4,7 +4,8 @@ import torch.nn as nn
 
 from src import _native as N
 from src import engine as E
-from src.flat import FlatGroup
+from src.flat import FlatGroup, cached_param_dict
+
 
 
 class Projection(nn.Module):
@@ -25,9 +26,7 @@ class Projection(nn.Module):
         self.bn = nn.BatchNorm1d(sizes[-1], affine=False)
 
     def param_dict(self):
-        P = {n: p.data for n, p in self.named_parameters()}
-        P.update({n: b for n, b in self.named_buffers()})
-        return P
+        return cached_param_dict(self)
 
     def forward(self, y1, y2):
         return _ProjectionFn.apply(self, y1, y2, *[p for p in self.parameters()])
@@ -90,6 +89,59 @@ class FusedStepFn(torch.autograd.Function):
         return (None, None, None, None) + (None,) * len(ex.flat.params)
 
 
+class GraphedStep:
+    """The whole training step of one rank - zero the flat gradient, fused forward + backward, optimiser - captured once
+    into a hipGraph and replayed with a single launch per step.
+
+    Why: the step is ~270 kernels of 5-200 us each; issued one by one the launch side costs as much wall time as the GPU
+    needs to run them.  What makes the capture valid: every per-step scalar that changes (dropout
+    counter, MoCo queue pointer, BatchNorm batch counters) lives in device memory, shapes are fixed, and the side
+    streams (key encoder, loss heads, weight gradients) fork from and rejoin the capturing stream.
+
+    The first `eager_steps` calls run the ordinary eager path (they size the allocator pools, initialise the momentum
+    buffer and set the kernels' LDS attributes); the next call captures, every call from then on copies the two views
+    into the graph's input buffers and replays.  A change of batch shape or of the optimiser's hyper-parameters triggers
+    a new capture.  Data-parallel runs (world size > 1) keep the eager path: their collectives stay on RCCL's stream.
+    """
+
+    def __init__(self, expert, optimizer, eager_steps=2):
+        self.expert, self.opt, self.eager_steps = expert, optimizer, eager_steps
+        self.calls = 0
+        self.graph = None
+        self.key = None
+        self.replays = 0
+
+    def _hyper(self):
+        g = self.opt.param_groups[0]
+        return tuple((k, g[k]) for k in sorted(g) if k != "params" and isinstance(g[k], (int, float)))
+
+    def _eager(self, img_1, img_2):
+        loss = self.expert.fused_loss(img_1, img_2, True)
+        self.opt.grad_scale_tensor = None
+        self.opt.step()
+        return loss
+
+    @torch.no_grad()
+    def __call__(self, img_1, img_2):
+        self.calls += 1
+        if self.calls <= self.eager_steps:
+            return self._eager(img_1, img_2)
+        key = (tuple(img_1.shape), tuple(img_2.shape), img_1.dtype, img_2.dtype, self._hyper(), self.expert.training,
+               self.expert.flat.data.data_ptr())
+        if self.graph is None or key != self.key:
+            self.in_1, self.in_2 = torch.empty_like(img_1), torch.empty_like(img_2)
+            torch.cuda.synchronize()
+            self.graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graph):
+                self.loss = self._eager(self.in_1, self.in_2)
+            self.key = key
+        self.in_1.copy_(img_1)
+        self.in_2.copy_(img_2)
+        self.graph.replay()
+        self.replays += 1
+        return self.loss
+
+
 class FusedExpertMixin:
     """Flat storage + optimiser + gradient publication shared by the experts."""
     flat = None
@@ -100,24 +152,29 @@ class FusedExpertMixin:
         return [(n, p) for n, p in self.named_parameters() if p.requires_grad]
 
     def ensure_flat(self):
+        if self.flat is not None and self.flat.intact():       # per-step fast path: no walk over the module tree
+            return self.flat
         named = self.trainable_named()
-        dev = named[0][1].device
-        ok = self.flat is not None and self.flat.data.device == dev and len(self.flat.params) == len(named)
-        if ok:
-            p0, pl = named[0][1], named[-1][1]
-            ok = p0.data_ptr() == self.flat.data.data_ptr() and \
-                pl.data_ptr() == self.flat.data.data_ptr() + 4 * self.flat.offsets[-1]
-        if not ok:
-            for _, p in named:
-                p.grad = None
-            self.flat = FlatGroup(named)
-            self.on_reflatten()
-            if self.hip_optimizer is not None:
-                self.hip_optimizer.flat_groups = [self.flat]
+        for _, p in named:
+            p.grad = None
+        self.flat = FlatGroup(named)
+        self.on_reflatten()
+        if self.hip_optimizer is not None:
+            self.hip_optimizer.flat_groups = [self.flat]
         return self.flat
 
     def on_reflatten(self):
         pass
+
+    def graphed_step(self, optimizer=None, eager_steps=2):
+        """-> callable(img_1, img_2) -> loss that runs zero_grad + fused forward/backward + optimiser as one hipGraph
+        replay (single-GPU runs).  The returned loss tensor is overwritten by the next call."""
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            raise RuntimeError("graphed_step is the single-rank path; data-parallel runs use training_step + all_reduce_grads")
+        opt = optimizer or self.hip_optimizer or self.configure_optimizers()
+        self.ensure_flat()
+        return GraphedStep(self, opt, eager_steps)
 
     def publish_grads(self, g):
         if self.hip_optimizer is None:

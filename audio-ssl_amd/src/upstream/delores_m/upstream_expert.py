@@ -54,7 +54,6 @@ class Upstream_Expert(FusedExpertMixin, UpstreamModule):
         self.encoder_q.encoder.precision = self.encoder_k.encoder.precision = self.precision
         self.flat_k = None
         self._key_stream = E.SideStream()
-        self._ptr = 0                      # host mirror of queue_ptr (no device sync in the step)
 
     def init_encoders(self, base_encoder):
         return DELORES_M_ENCODER(self.config, base_encoder), DELORES_M_ENCODER(self.config, base_encoder)
@@ -69,10 +68,6 @@ class Upstream_Expert(FusedExpertMixin, UpstreamModule):
     def on_reflatten(self):
         self.flat_k = FlatGroup([(n, p) for n, p in self.encoder_k.named_parameters()])
 
-    def _load_from_state_dict(self, state_dict, prefix, *args, **kwargs):
-        super()._load_from_state_dict(state_dict, prefix, *args, **kwargs)
-        self._ptr = int(self.queue_ptr[0])
-
     @torch.no_grad()
     def _momentum_update_key_encoder(self):
         self.ensure_flat()
@@ -85,9 +80,9 @@ class Upstream_Expert(FusedExpertMixin, UpstreamModule):
         batch_size = keys32.shape[0]
         K = self.hparams.num_negatives
         assert K % batch_size == 0  # for simplicity
-        N.call("enqueue", self.precision, keys32, batch_size, keys32.shape[1], K, self._ptr, self.queue, shadow)
-        self._ptr = (self._ptr + batch_size) % K
-        self.queue_ptr.fill_(self._ptr)
+        # the write position lives in the `queue_ptr` buffer and is advanced on the device (no host mirror: the step
+        # can be captured in a hipGraph and replayed)
+        N.call("enqueue", self.precision, keys32, batch_size, keys32.shape[1], K, 0, self.queue_ptr, self.queue, shadow)
 
     @torch.no_grad()
     def _shuffle_begin(self, x):
@@ -225,7 +220,7 @@ class Upstream_Expert(FusedExpertMixin, UpstreamModule):
 
     def training_step(self, batch, batch_idx):
         img_1, img_2 = batch
-        params = [p for _, p in self.trainable_named()]
+        params = self.ensure_flat().params
         loss = FusedStepFn.apply(self, torch.is_grad_enabled(), img_1, img_2, *params)
         self.log_dict({'train_loss': loss})
         return loss

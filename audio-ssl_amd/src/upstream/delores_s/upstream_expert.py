@@ -87,7 +87,7 @@ class Upstream_Expert(FusedExpertMixin, UpstreamModule):
 
     def training_step(self, batch, batch_idx):
         img_1, img_2 = batch
-        params = [p for _, p in self.trainable_named()]
+        params = self.ensure_flat().params
         loss = FusedStepFn.apply(self, torch.is_grad_enabled(), img_1, img_2, *params)
         self.log_dict({'train_loss': loss})
         return loss

@@ -31,7 +31,8 @@ from src.dataset import BaselineDataModule  # noqa: E402
 
 
 class HipTrainer:
-    def __init__(self, max_epochs=1, save_dir=None, resume_from_checkpoint=None, log_every=10, max_steps=None):
+    def __init__(self, max_epochs=1, save_dir=None, resume_from_checkpoint=None, log_every=10, max_steps=None, use_graph=True):
+        self.use_graph = use_graph
         self.max_epochs, self.save_dir, self.resume, self.log_every = max_epochs, save_dir, resume_from_checkpoint, log_every
         self.max_steps = max_steps
         self.rank = int(os.environ.get("RANK", 0))
@@ -71,6 +72,8 @@ class HipTrainer:
             model.load_state_dict(ck["state_dict"], strict=False)
             self.epoch, self.global_step = ck.get("epoch", 0), ck.get("global_step", 0)
         best = float("inf")
+        # one rank: the step is a single hipGraph replay; data-parallel: eager launches around the RCCL collectives
+        gstep = model.graphed_step(opt) if (self.world == 1 and self.use_graph and hasattr(model, "graphed_step")) else None
         for epoch in range(self.epoch, self.max_epochs):
             self.epoch = epoch
             if sampler is not None:
@@ -78,11 +81,14 @@ class HipTrainer:
             t0, clips = time.time(), 0
             for i, (waves, plan) in enumerate(loader):
                 img_1, img_2 = dm.front_end(waves.to(dev, non_blocking=True), plan)
-                opt.zero_grad()
-                loss = model.training_step((img_1, img_2), i)
-                loss.backward()
-                model.all_reduce_grads()
-                opt.step()
+                if gstep is not None:
+                    loss = gstep(img_1, img_2)
+                else:
+                    opt.zero_grad()
+                    loss = model.training_step((img_1, img_2), i)
+                    loss.backward()
+                    model.all_reduce_grads()
+                    opt.step()
                 self.global_step += 1
                 clips += waves.shape[0] * self.world
                 if self.rank == 0 and self.global_step % self.log_every == 0:

@@ -158,7 +158,10 @@ int audiossl_moco_ce_bwd(int dtype, const float* lpos, const float* lneg, const 
                          void* P, float* dlpos, void* stream);
 int audiossl_l2norm_bwd(int dtype, const float* dqn, const float* dlpos, const float* kn32, const float* qn32,
                         const float* inv_norm, int B, int D, void* dq, void* stream);
-int audiossl_enqueue(int dtype, const float* keys, int B, int D, int K, int ptr, float* queue, void* shadow, void* stream);
+/* ptr_dev (optional, int64 on the device = the reference's `queue_ptr` buffer): when given, the write position is read
+ * from it and advanced by B (mod K) on the device, so the call can sit inside a captured hipGraph; `ptr` is then ignored. */
+int audiossl_enqueue(int dtype, const float* keys, int B, int D, int K, int ptr, long long* ptr_dev, float* queue, void* shadow,
+                     void* stream);
 int audiossl_ema_update(float* pk, const float* pq, long n, float m, void* stream);
 
 /* ---- K17 optimiser + plumbing: delores_s/upstream_expert.py:236-243 (torch.optim.SGD) ---------------------- */
@@ -166,7 +169,9 @@ int audiossl_sgd_momentum(float* p, const float* g, float* buf, long n, float lr
                           int first, float grad_scale, const float* grad_scale_dev, void* stream);
 int audiossl_cast(int dtype, const float* src, void* dst, long n, void* stream);
 int audiossl_cast_back(int dtype, const void* src, float* dst, long n, void* stream);
-int audiossl_dropout_mask(uint8_t* keep, long n, unsigned long long seed, float p, void* stream);
+/* keep[i] = splitmix64(seed', i) >= p; seed' = (seed + *counter) mod 2^48 when `counter` (device int64) is given, so that
+ * a replayed hipGraph draws a fresh mask every step. */
+int audiossl_dropout_mask(uint8_t* keep, long n, unsigned long long seed, float p, const long long* counter, void* stream);
 /* out = g where h > 0 else 0 (nn.ReLU backward on the stored activation); eval-mode BatchNorm folded to scale/shift
  * (audiontt.py:47,53,58 under model.eval()); y += a*x on fp32 buffers. */
 int audiossl_relu_bwd(int dtype, const void* g, const void* h, void* out, long n, void* stream);

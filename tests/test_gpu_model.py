@@ -221,6 +221,51 @@ def test_delores_m_b32_vs_oracle(cfg_m, prec):
         assert rel_l2(gp, gr) < {"fp32": 2e-3, "bf16": 0.25, "bf16_hp": 0.16}[prec], n
 
 
+# ------------------------------------------------------------------------------------------------ hipGraph replay
+@pytest.mark.parametrize("which", ["delores_m", "delores_s"])
+def test_graphed_step_matches_eager(cfg_m, cfg_s, which):
+    """Six training steps on changing batches: two eager, then capture + replays, against six eager steps of a twin.
+    Dropout counters, the MoCo queue pointer and the queue contents must advance identically (they live on the device);
+    weights agree up to the order of the fp32 atomic accumulations."""
+    from src.encoder import AudioNTT2020Task6
+    if which == "delores_m":
+        from src.upstream.delores_m.upstream_expert import Upstream_Expert
+        make = lambda: Upstream_Expert(_cfg(cfg_m, "bf16"), base_encoder=AudioNTT2020Task6, num_negatives=256)
+    else:
+        from src.upstream.delores_s.upstream_expert import Upstream_Expert
+        make = lambda: Upstream_Expert(_cfg(cfg_s, "bf16"), base_encoder=AudioNTT2020Task6)
+    B, T, steps = 16, 96, 6
+    twins = []
+    for _ in range(2):
+        m = make()
+        fill.fill_state_dict_(m, seed=21)
+        if which == "delores_m":
+            for pq, pk in zip(m.encoder_q.parameters(), m.encoder_k.parameters()):
+                pk.data.copy_(pq.data)
+            m.queue.copy_(closed_queue(128, 256))
+        twins.append(m.cuda().train())
+    eager, graphed = twins
+    opt_e, opt_g = eager.configure_optimizers(), graphed.configure_optimizers()
+    gstep = graphed.graphed_step(opt_g, eager_steps=2)
+    losses_e, losses_g = [], []
+    for s in range(steps):
+        a, b = views(B, T, 9100 + 2 * s).cuda(), views(B, T, 9101 + 2 * s).cuda()
+        opt_e.zero_grad()
+        le = eager.training_step((a, b), s)
+        le.backward()
+        opt_e.step()
+        losses_e.append(float(le))
+        losses_g.append(float(gstep(a, b)))
+    assert gstep.replays == steps - 2
+    np.testing.assert_allclose(losses_g, losses_e, rtol=2e-3)
+    if which == "delores_m":
+        assert int(graphed.queue_ptr[0]) == int(eager.queue_ptr[0]) == (steps * B) % 256
+        assert rel_l2(graphed.queue.cpu(), eager.queue.cpu()) < 2e-2
+        assert graphed.encoder_q.encoder.dropout_masks.calls == eager.encoder_q.encoder.dropout_masks.calls == steps
+    for (n, pe), (_, pg) in zip(eager.named_parameters(), graphed.named_parameters()):
+        assert rel_l2(pg.detach().cpu(), pe.detach().cpu()) < 2e-2, n
+
+
 # ------------------------------------------------------------------------------------------------ harness / checkpoints
 def _synth_csv(tmp_path, n=40):
     import pandas as pd
