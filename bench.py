@@ -35,6 +35,25 @@ PEAK_TFLOPS = {0: 157.3, 1: 2500.0}          # MI355X_MICROARCH.md: f32-in MFMA 
 GEMM_SYMBOL = {(0, 0): "NT", (0, 1): "NN", (1, 1): "TN", (1, 0): "TT"}
 
 
+def pmc_traffic(ta, tb):
+    """HBM bytes per launch of the bf16 GEMM instantiations with these transposes, from the committed PMC passes
+    (profiles/r01_pmc_traffic.json, made by tools/pmc_summary.py; counters cannot be read live from inside the process)."""
+    import re
+    path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+    if not os.path.exists(path):
+        return None
+    tot, n = 0.0, 0
+    for name, v in json.load(open(path))["kernels"].items():
+        if "gemm_kernel" not in name or v["read_bytes_per_launch"] is None:
+            continue
+        m = re.search(r"gemm_kernelIDF16bLb(\d)ELb(\d)ELi\d+E", name)
+        key = (int(m.group(1)), int(m.group(2))) if m else ((1, 1) if re.search(r"E, true, \d+>", name) else None)
+        if key == (ta, tb):
+            tot += (v["read_bytes_per_launch"] + (v["write_bytes_per_launch"] or 0)) * v["launches"]
+            n += v["launches"]
+    return round(tot / n) if n else None
+
+
 def synth_waves(B, L, seed):
     """Seeded uniform noise x0.1 + 440 Hz + 3 kHz tones; last two clips: silence / full scale."""
     g = np.random.RandomState(seed)
@@ -87,8 +106,9 @@ def cpu_baseline(B, steps, queue):
     for _ in range(steps):
         step()
         done += 1
-        print(f"[bench] cpu_baseline step {done}: {time.perf_counter() - t0:.1f} s", file=sys.stderr, flush=True)
-        if time.perf_counter() - t0 > 25.0:
+        if done % 8 == 0:
+            print(f"[bench] cpu_baseline step {done}: {time.perf_counter() - t0:.1f} s", file=sys.stderr, flush=True)
+        if time.perf_counter() - t0 > 20.0:
             break
     steps = done
     dt = time.perf_counter() - t0
@@ -105,7 +125,7 @@ def main():
     ap.add_argument("--precision", default="bf16", choices=["bf16", "bf16_hp", "fp32"])
     ap.add_argument("--queue", type=int, default=65536)
     ap.add_argument("--cpu-batch", type=int, default=32)
-    ap.add_argument("--cpu-steps", type=int, default=4)
+    ap.add_argument("--cpu-steps", type=int, default=80, help="upper bound; the CPU leg also stops after ~20 s")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="issue the step kernel by kernel instead of replaying the hipGraph")
     args = ap.parse_args()
@@ -209,7 +229,7 @@ def main():
     (dtype, ta, tb), (tsec, flops, launches) = max(groups.items(), key=lambda kv: kv[1][0])
     achieved = flops / tsec / 1e12
     roofline = {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_TFLOPS[dtype], "unit": "TFLOP/s",
-                "frac": round(achieved / PEAK_TFLOPS[dtype], 4), "traffic": None,
+                "frac": round(achieved / PEAK_TFLOPS[dtype], 4), "traffic": pmc_traffic(ta, tb) if dtype == 1 else None,
                 "kernel": f"gemm_kernel<{'bf16' if dtype else 'f32'},{GEMM_SYMBOL[(ta, tb)]}>", "launches_per_step": launches / prof_steps,
                 "avg_launch_us": round(tsec / launches * 1e6, 2), "flop_per_launch": flops / launches,
                 "share_of_step": round(tsec / prof_steps / (dt / args.steps), 3),
