@@ -1,0 +1,90 @@
+"""GPU: the data-parallel training step with world_size 2.  Both ranks share the box's single GPU and talk over gloo
+(RCCL refuses two ranks on one device); every kernel, stream fork and collective call site of the multi-GPU path runs
+exactly as it does under `torch.distributed.run` on 8 GPUs - only the transport differs."""
+import copy
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from conftest import CFG_M, CFG_S
+
+pytestmark = pytest.mark.gpu
+
+
+def _worker(rank, world, port, which, steps, ret):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from oracle import fill
+        from helpers import closed_queue, views
+        from src.encoder import AudioNTT2020Task6
+        B, T, K = 16, 96, 256
+        if which == "delores_m":
+            from src.upstream.delores_m.upstream_expert import Upstream_Expert
+            cfg = copy.deepcopy(CFG_M)
+            cfg["run"]["precision"] = "bf16"
+            m = Upstream_Expert(cfg, base_encoder=AudioNTT2020Task6, num_negatives=K)
+        else:
+            from src.upstream.delores_s.upstream_expert import Upstream_Expert
+            cfg = copy.deepcopy(CFG_S)
+            cfg["run"]["precision"] = "bf16"
+            m = Upstream_Expert(cfg, base_encoder=AudioNTT2020Task6)
+        fill.fill_state_dict_(m, seed=33)                      # identical weights on both ranks
+        if which == "delores_m":
+            for pq, pk in zip(m.encoder_q.parameters(), m.encoder_k.parameters()):
+                pk.data.copy_(pq.data)
+            m.queue.copy_(closed_queue(128, K))
+        m = m.cuda().train()
+        opt = m.configure_optimizers()
+        step = m.graphed_step(opt) if os.environ.get("AUDIOSSL_TEST_DDP_GRAPH") == "1" else None
+        losses = []
+        for s in range(steps):
+            a = views(B, T, 9300 + 10 * s + rank).cuda()       # different clips per rank
+            b = views(B, T, 9350 + 10 * s + rank).cuda()
+            if step is not None:
+                loss = step(a, b)
+            else:
+                opt.zero_grad()
+                loss = m.training_step((a, b), s)
+                loss.backward()
+                m.all_reduce_grads()
+                opt.step()
+            losses.append(float(loss))
+        torch.cuda.synchronize()
+        out = {"losses": losses, "w": {n: p.detach().float().cpu().numpy() for n, p in m.named_parameters()}}
+        if which == "delores_m":
+            out["queue"] = m.queue.cpu().numpy()
+            out["ptr"] = int(m.queue_ptr[0])
+        ret[rank] = out
+    finally:
+        dist.destroy_process_group()
+
+
+def _run(which, steps=3, world=2):
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker, args=(world, port, which, steps, ret), nprocs=world, join=True)
+    return [ret[r] for r in range(world)]
+
+
+@pytest.mark.parametrize("which", ["delores_m", "delores_s"])
+def test_two_rank_step_keeps_replicas_identical(which):
+    r0, r1 = _run(which)
+    assert all(np.isfinite(r0["losses"])) and all(np.isfinite(r1["losses"]))
+    assert r0["losses"] != r1["losses"]                        # local losses differ (different clips) ...
+    for n in r0["w"]:                                          # ... the all-reduced update does not
+        np.testing.assert_array_equal(r0["w"][n], r1["w"][n], err_msg=n)
+    if which == "delores_m":
+        assert r0["ptr"] == r1["ptr"] == (3 * 2 * 16) % 256    # the queue advances by the GLOBAL batch
+        np.testing.assert_array_equal(r0["queue"], r1["queue"])
+        # trainable weights moved, key encoder moved by the EMA only
+        assert not np.array_equal(r0["w"]["encoder_q.fc.weight"], r0["w"]["encoder_k.fc.weight"])
