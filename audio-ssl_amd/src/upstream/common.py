@@ -89,6 +89,67 @@ class FusedStepFn(torch.autograd.Function):
         return (None, None, None, None) + (None,) * len(ex.flat.params)
 
 
+class EagerPhases:
+    """Phase runner of the eagerly issued step: a phase is just a call, buffers are fresh allocations."""
+
+    def phase(self, name, fn):
+        return fn()
+
+    def static(self, name, t):
+        return t
+
+    def alloc(self, name, make):
+        return make()
+
+
+EAGER = EagerPhases()
+
+
+class GraphPhases:
+    """Phase runner of the data-parallel graph step.  The step is cut at its collectives into phases (query encoder,
+    key encoder, loss heads, encoder backward); each phase is captured into its own hipGraph the first time it runs and
+    replayed afterwards on whatever stream is current, so the key encoder still overlaps the query encoder.  The RCCL
+    calls between the phases stay ordinary eager calls.  Tensors handed from a phase to a later one are outputs of the
+    capture (fixed addresses); tensors produced by a collective are copied into fixed buffers with `static`."""
+
+    def __init__(self):
+        self.graphs, self.results, self.buffers = {}, {}, {}
+        self.broken = None                 # set to the exception text if a capture failed: phases then run eagerly
+
+    def phase(self, name, fn):
+        if self.broken is not None:
+            return fn()
+        g = self.graphs.get(name)
+        if g is None:
+            g = torch.cuda.CUDAGraph()
+            try:
+                # thread-local capture mode: RCCL's watchdog thread polls its events while we capture
+                with torch.cuda.graph(g, capture_error_mode="thread_local"):
+                    self.results[name] = fn()
+            except RuntimeError as e:          # nothing of the phase has executed yet: issue it eagerly from now on
+                import warnings
+                self.broken = f"{name}: {e}"
+                warnings.warn(f"hipGraph capture of phase '{name}' failed ({e}); this rank issues the step eagerly")
+                return fn()
+            self.graphs[name] = g
+        g.replay()
+        return self.results[name]
+
+    def static(self, name, t):
+        buf = self.buffers.get(name)
+        if buf is None or buf.shape != t.shape or buf.dtype != t.dtype:
+            if name in self.buffers:
+                raise RuntimeError(f"graph step: shape of '{name}' changed; build a new graphed step")
+            buf = self.buffers[name] = torch.empty_like(t)
+        buf.copy_(t)
+        return buf
+
+    def alloc(self, name, make):
+        if name not in self.buffers:
+            self.buffers[name] = make()
+        return self.buffers[name]
+
+
 class GraphedStep:
     """The whole training step of one rank - zero the flat gradient, fused forward + backward, optimiser - captured once
     into a hipGraph and replayed with a single launch per step.
@@ -101,13 +162,16 @@ class GraphedStep:
     The first `eager_steps` calls run the ordinary eager path (they size the allocator pools, initialise the momentum
     buffer and set the kernels' LDS attributes); the next call captures, every call from then on copies the two views
     into the graph's input buffers and replays.  A change of batch shape or of the optimiser's hyper-parameters triggers
-    a new capture.  Data-parallel runs (world size > 1) keep the eager path: their collectives stay on RCCL's stream.
+    a new capture.  Data-parallel ranks (world size > 1) cannot put RCCL calls inside one graph: there the step is cut
+    at its collectives and every collective-free phase is its own graph (`GraphPhases`).
     """
 
-    def __init__(self, expert, optimizer, eager_steps=2):
-        self.expert, self.opt, self.eager_steps = expert, optimizer, eager_steps
+    def __init__(self, expert, optimizer, eager_steps=2, world=1, phases=False):
+        self.expert, self.opt, self.eager_steps, self.world = expert, optimizer, eager_steps, world
+        self.use_phases = phases or world > 1
         self.calls = 0
         self.graph = None
+        self.phases = None                 # GraphPhases of the data-parallel variant
         self.key = None
         self.replays = 0
 
@@ -115,8 +179,10 @@ class GraphedStep:
         g = self.opt.param_groups[0]
         return tuple((k, g[k]) for k in sorted(g) if k != "params" and isinstance(g[k], (int, float)))
 
-    def _eager(self, img_1, img_2):
-        loss = self.expert.fused_loss(img_1, img_2, True)
+    def _eager(self, img_1, img_2, runner=None):
+        loss = self.expert.fused_loss(img_1, img_2, True) if runner is None else \
+            self.expert.fused_loss(img_1, img_2, True, runner=runner)
+        self.expert.all_reduce_grads()             # no-op on one rank
         self.opt.grad_scale_tensor = None
         self.opt.step()
         return loss
@@ -128,6 +194,13 @@ class GraphedStep:
             return self._eager(img_1, img_2)
         key = (tuple(img_1.shape), tuple(img_2.shape), img_1.dtype, img_2.dtype, self._hyper(), self.expert.training,
                self.expert.flat.data.data_ptr())
+        if self.use_phases:
+            # data parallel: one graph per collective-free phase, RCCL calls in between
+            if self.phases is None or key != self.key:
+                self.phases, self.key = GraphPhases(), key
+            a, b = self.phases.static("img_1", img_1), self.phases.static("img_2", img_2)
+            self.replays += 1
+            return self._eager(a, b, runner=self.phases)
         if self.graph is None or key != self.key:
             self.in_1, self.in_2 = torch.empty_like(img_1), torch.empty_like(img_2)
             torch.cuda.synchronize()
@@ -166,15 +239,20 @@ class FusedExpertMixin:
     def on_reflatten(self):
         pass
 
-    def graphed_step(self, optimizer=None, eager_steps=2):
-        """-> callable(img_1, img_2) -> loss that runs zero_grad + fused forward/backward + optimiser as one hipGraph
-        replay (single-GPU runs).  The returned loss tensor is overwritten by the next call."""
+    def graphed_step(self, optimizer=None, eager_steps=2, phases=False):
+        """-> callable(img_1, img_2) -> loss that runs zero_grad + fused forward/backward [+ gradient all-reduce] +
+        optimiser from captured hipGraphs: ONE graph on a single rank, one graph per collective-free phase with the RCCL
+        calls in between on data-parallel ranks.  The returned loss tensor is overwritten by the next call."""
         import torch.distributed as dist
-        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-            raise RuntimeError("graphed_step is the single-rank path; data-parallel runs use training_step + all_reduce_grads")
+        world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+        if world > 1 and not self.graph_phases_supported():
+            raise RuntimeError("this configuration has a collective inside a phase; use training_step + all_reduce_grads")
         opt = optimizer or self.hip_optimizer or self.configure_optimizers()
         self.ensure_flat()
-        return GraphedStep(self, opt, eager_steps)
+        return GraphedStep(self, opt, eager_steps, world, phases)
+
+    def graph_phases_supported(self):
+        return True
 
     def publish_grads(self, g):
         if self.hip_optimizer is None:

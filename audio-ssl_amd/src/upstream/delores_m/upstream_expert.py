@@ -16,7 +16,7 @@ from src import engine as E
 from src.encoder.audiontt import default_precision
 from src.flat import FlatGroup
 from src.module_base import UpstreamModule
-from src.upstream.common import FusedExpertMixin, FusedStepFn, Projection, strip
+from src.upstream.common import EAGER, FusedExpertMixin, FusedStepFn, Projection, strip
 from src.upstream.delores_m.upstream_encoder import DELORES_M as DELORES_M_ENCODER
 from src.utils import concat_all_gather
 
@@ -127,88 +127,107 @@ class Upstream_Expert(FusedExpertMixin, UpstreamModule):
         return x_gather[idx_this]
 
     # ------------------------------------------------------------------ fused step
-    def fused_loss(self, img_q, img_k, need_grad=True, parts=None):
+    def fused_loss(self, img_q, img_k, need_grad=True, parts=None, runner=None):
+        """Forward + backward of the whole step.  The work is written as collective-free *phases* (query encoder, key
+        encoder, loss heads, encoder backward) handed to `runner`: the default runs them in place; the data-parallel
+        graph step captures each one into a hipGraph (common.GraphPhases).  Collectives sit between the phases."""
+        R = runner or EAGER
         dt = self.precision
-        td = N.torch_dtype(dt)
         E.set_high_precision(self.high_precision)
         flat = self.ensure_flat()
-        if need_grad:
-            flat.zero_grad()
-        flat.refresh_shadow(dt)
         dev = img_q.device
         B = img_q.shape[0]
-        loss = torch.zeros(4, dtype=torch.float32, device=dev)          # [ce, barlow1, barlow2, barlow3]
         eq, ek = self.encoder_q, self.encoder_k
-        Wq = flat.shadow_dict("encoder_q.")
-        # stacked projector inputs: rows [0,B) from the query encoder, [B,2B) from the key encoder
-        Ys = [torch.empty(2 * B, f, dtype=E.pooled_dtype(dt), device=dev) for f in (2048, 1024, 512)]
         ddp = _world() > 1
         img_k = img_k.float().contiguous()
+        img_q = img_q.float().contiguous()
         pending_k = self._shuffle_begin(img_k) if ddp else None
         main = torch.cuda.current_stream()
-        wq = Wq["fc.weight"]
+        G = flat.grad_dict
+        # stacked projector inputs: rows [0,B) from the query encoder, [B,2B) from the key encoder
+        Ys = R.alloc("Ys", lambda: [torch.empty(2 * B, f, dtype=E.pooled_dtype(dt), device=dev) for f in (2048, 1024, 512)])
 
         # ---- key encoder (no gradient) on its own stream, concurrent with the query encoder: EMA first, then forward
-        def key_branch():
-            x = img_k
-            idx_unshuffle = None
+        def key_phase(x):
             self._momentum_update_key_encoder()
             self.flat_k.refresh_shadow(dt)
             Wk = self.flat_k.shadow_dict()
-            if ddp:
-                x, idx_unshuffle = self._shuffle_end(pending_k, B)
             keepk = ek.encoder.next_keep_mask(B, x.shape[-1])
             _, _, _, Hk, _ = E.encoder_forward(ek.encoder.param_dict(), x, dt, keep=keepk, p_drop=0.3, train=self.training,
                                                Wc=strip(Wk, "encoder."), layer_out=tuple(y[B:] for y in Ys))
             yk, _ = E.maxmean_forward(dt, Hk)
-            kk = E.linear_fwd(dt, yk, Wk["fc.weight"], B, wq.shape[0], wq.shape[1], bias=ek.fc.bias.data, out_f32=1)
+            wk = Wk["fc.weight"]
+            return E.linear_fwd(dt, yk, wk, B, wk.shape[0], wk.shape[1], bias=ek.fc.bias.data, out_f32=1)
+
+        def key_branch():
+            x, idx_unshuffle = img_k, None
             if ddp:
-                kk = self._batch_unshuffle_ddp(kk, idx_unshuffle)
+                x, idx_unshuffle = self._shuffle_end(pending_k, B)
+                x = R.static("key_in", x)
+            kk = R.phase("key", lambda: key_phase(x))
+            if ddp:
+                kk = R.static("key_out", self._batch_unshuffle_ddp(kk, idx_unshuffle))
             return kk
         k = self._key_stream.run(dev, key_branch)
+
         # ---- query encoder (main stream)
-        img_q = img_q.float().contiguous()
-        keep = eq.encoder.next_keep_mask(B, img_q.shape[-1])
-        _, _, _, Hq, cq = E.encoder_forward(eq.encoder.param_dict(), img_q, dt, keep=keep, p_drop=0.3, train=self.training,
-                                            Wc=strip(Wq, "encoder."), layer_out=tuple(y[:B] for y in Ys))
-        yq, argq = E.maxmean_forward(dt, Hq)
-        q = E.linear_fwd(dt, yq, wq, B, wq.shape[0], wq.shape[1], bias=eq.fc.bias.data, out_f32=1)
+        def query_phase():
+            if need_grad:
+                flat.zero_grad()
+            flat.refresh_shadow(dt)
+            Wq = flat.shadow_dict("encoder_q.")
+            wq = Wq["fc.weight"]
+            loss = torch.zeros(4, dtype=torch.float32, device=dev)          # [ce, barlow1, barlow2, barlow3]
+            keep = eq.encoder.next_keep_mask(B, img_q.shape[-1])
+            _, _, _, Hq, cq = E.encoder_forward(eq.encoder.param_dict(), img_q, dt, keep=keep, p_drop=0.3, train=self.training,
+                                                Wc=strip(Wq, "encoder."), layer_out=tuple(y[:B] for y in Ys))
+            yq, argq = E.maxmean_forward(dt, Hq)
+            q = E.linear_fwd(dt, yq, wq, B, wq.shape[0], wq.shape[1], bias=eq.fc.bias.data, out_f32=1)
+            return loss, wq, Hq, cq, yq, argq, q
+        loss, wq, Hq, cq, yq, argq, q = R.phase("query", query_phase)
         self._key_stream.join(dev)
         k.record_stream(main)
-        # ---- the three Barlow heads are independent of each other and of the MoCo head: one side stream each
-        G = flat.grad_dict
-        dys = [None, None, None]
-        for i, p in enumerate((self.p1, self.p2, self.p3)):
-            st = self._streams(dev)[i]
-            st.wait_stream(main)
-            with torch.cuda.stream(st):
-                Wp = flat.shadow_dict(f"p{i + 1}.")
-                dys[i] = E.barlow_forward_backward(p.param_dict(), G(f"p{i + 1}."), Ys[i], dt, p.lambd, p.scale_loss,
-                                                   loss[i + 1:i + 2], need_dy1=True, need_dy2=False,
-                                                   update_running=self.training, backward=need_grad,
-                                                   Wc=tuple(Wp[f"projector.{j}.weight"] for j in (0, 3, 6)))
-        # ---- InfoNCE against the queue, then enqueue the keys (main stream, concurrent with the heads)
-        shadow = E.cast(dt, self.queue) if dt != N.F32 else self.queue
-        dq, kn32 = E.moco_forward_backward(dt, q, k, self.queue, shadow, float(self.hparams.softmax_temperature),
-                                           loss[0:1], backward=need_grad)
-        self._dequeue_and_enqueue(kn32, None)
-        if need_grad:
-            Gq = G("encoder_q.")
-            E.linear_bwd_w(dt, dq, yq, Gq["fc.weight"], B, wq.shape[0], wq.shape[1])
-            E.colsum_add(dt, dq, B, wq.shape[0], Gq["fc.bias"])
-            dyq = E.linear_bwd_x(dt, dq, wq, B, wq.shape[0], wq.shape[1], out_f32=1)
-            dA2 = E.maxmean_backward(dt, dyq, argq, Hq)
-        for st in self._streams(dev):
-            main.wait_stream(st)
-        for y in Ys + [d for d in dys if d is not None]:
-            y.record_stream(main)
+
+        # ---- loss heads: the three Barlow heads are independent of each other and of the MoCo head (one side stream
+        #      each); InfoNCE against the queue runs on the main stream concurrently
+        def heads_phase():
+            here = torch.cuda.current_stream()
+            dys = [None, None, None]
+            for i, p in enumerate((self.p1, self.p2, self.p3)):
+                st = self._streams(dev)[i]
+                st.wait_stream(here)
+                with torch.cuda.stream(st):
+                    Wp = flat.shadow_dict(f"p{i + 1}.")
+                    dys[i] = E.barlow_forward_backward(p.param_dict(), G(f"p{i + 1}."), Ys[i], dt, p.lambd, p.scale_loss,
+                                                       loss[i + 1:i + 2], need_dy1=True, need_dy2=False,
+                                                       update_running=self.training, backward=need_grad,
+                                                       Wc=tuple(Wp[f"projector.{j}.weight"] for j in (0, 3, 6)))
+            shadow = E.cast(dt, self.queue) if dt != N.F32 else self.queue
+            dq, kn32 = E.moco_forward_backward(dt, q, k, self.queue, shadow, float(self.hparams.softmax_temperature),
+                                               loss[0:1], backward=need_grad)
+            dA2 = None
+            if need_grad:
+                Gq = G("encoder_q.")
+                E.linear_bwd_w(dt, dq, yq, Gq["fc.weight"], B, wq.shape[0], wq.shape[1])
+                E.colsum_add(dt, dq, B, wq.shape[0], Gq["fc.bias"])
+                dyq = E.linear_bwd_x(dt, dq, wq, B, wq.shape[0], wq.shape[1], out_f32=1)
+                dA2 = E.maxmean_backward(dt, dyq, argq, Hq)
+            for st in self._streams(dev):
+                here.wait_stream(st)
+            for d in dys:
+                if d is not None:
+                    d.record_stream(here)
+            return kn32, dA2, dys, loss.sum()
+        kn32, dA2, dys, total = R.phase("heads", heads_phase)
+        self._dequeue_and_enqueue(kn32, None)               # after the logits and dq GEMMs have read the queue
         if need_grad:
             self.reduce_begin("heads")                      # p1-p3 gradients complete: their all-reduce overlaps the encoder bwd
-            E.encoder_backward(cq, G("encoder_q.encoder."), dA2=dA2, dx1=dys[0], dx2=dys[1], dx3=dys[2])
+            R.phase("encoder_bwd", lambda: E.encoder_backward(cq, G("encoder_q.encoder."), dA2=dA2, dx1=dys[0], dx2=dys[1],
+                                                              dx3=dys[2]))
             self.reduce_begin("enc")
         if parts is not None:
             parts["losses"] = loss
-        return loss.sum()
+        return total
 
     def _streams(self, dev):
         if getattr(self, "_side_streams", None) is None or self._side_streams[0].device != dev:

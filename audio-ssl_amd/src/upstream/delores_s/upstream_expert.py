@@ -12,7 +12,7 @@ from src import _native as N
 from src import engine as E
 from src.encoder.audiontt import default_precision
 from src.module_base import UpstreamModule
-from src.upstream.common import FusedExpertMixin, FusedStepFn, Projection
+from src.upstream.common import EAGER, FusedExpertMixin, FusedStepFn, Projection
 from src.upstream.delores_s.upstream_encoder import DELORES_S as DELORES_S_ENCODER
 
 
@@ -45,39 +45,54 @@ class Upstream_Expert(FusedExpertMixin, UpstreamModule):
         return self.encoder(img_q), self.encoder(img_k)
 
     # ------------------------------------------------------------------ fused step
-    def fused_loss(self, img_1, img_2, need_grad=True):
+    def fused_loss(self, img_1, img_2, need_grad=True, runner=None):
+        """Forward + backward of the step as two collective-free phases (see common.GraphPhases): both views through the
+        encoder + the Barlow head, then the encoder backward; the gradient all-reduces start between / after them."""
+        R = runner or EAGER
         dt = self.precision
         E.set_high_precision(self.high_precision)
         enc = self.encoder.encoder
         flat = self.ensure_flat()
-        if need_grad:
-            flat.zero_grad()
-        flat.refresh_shadow(dt)
         B = img_1.shape[0]
-        loss = torch.zeros(1, dtype=torch.float32, device=img_1.device)
-        P = enc.param_dict()
         G = flat.grad_dict("encoder.encoder.")
-        Wenc = flat.shadow_dict("encoder.encoder.")
-        Wp = flat.shadow_dict("p.")
-        Y = torch.empty(2 * B, enc.d, dtype=E.pooled_dtype(dt), device=img_1.device)     # both views, stacked
-        views = []
-        for v, img in enumerate((img_1, img_2)):
-            img = img.float().contiguous()
-            keep = enc.next_keep_mask(B, img.shape[-1])
-            _, _, _, H, c = E.encoder_forward(P, img, dt, keep=keep, p_drop=enc.fc[2].p, train=self.training,
-                                              want_layers=False, Wc=Wenc)
-            _, arg = E.maxmean_forward(dt, H, out=Y[v * B:(v + 1) * B])
-            views.append((c, H, arg))
-        ar, gb = self._barlow_reduce()
-        dY = E.barlow_forward_backward(self.p.param_dict(), flat.grad_dict("p."), Y, dt, self.p.lambd, self.p.scale_loss,
-                                       loss, update_running=self.training, all_reduce=ar, global_batch=gb(B),
-                                       backward=need_grad, Wc=tuple(Wp[f"projector.{i}.weight"] for i in (0, 3, 6)))
+
+        def forward_phase():
+            if need_grad:
+                flat.zero_grad()
+            flat.refresh_shadow(dt)
+            loss = torch.zeros(1, dtype=torch.float32, device=img_1.device)
+            P = enc.param_dict()
+            Wenc = flat.shadow_dict("encoder.encoder.")
+            Wp = flat.shadow_dict("p.")
+            Y = torch.empty(2 * B, enc.d, dtype=E.pooled_dtype(dt), device=img_1.device)     # both views, stacked
+            views = []
+            for v, img in enumerate((img_1, img_2)):
+                img = img.float().contiguous()
+                keep = enc.next_keep_mask(B, img.shape[-1])
+                _, _, _, H, c = E.encoder_forward(P, img, dt, keep=keep, p_drop=enc.fc[2].p, train=self.training,
+                                                  want_layers=False, Wc=Wenc)
+                _, arg = E.maxmean_forward(dt, H, out=Y[v * B:(v + 1) * B])
+                views.append((c, H, arg))
+            ar, gb = self._barlow_reduce()
+            dY = E.barlow_forward_backward(self.p.param_dict(), flat.grad_dict("p."), Y, dt, self.p.lambd, self.p.scale_loss,
+                                           loss, update_running=self.training, all_reduce=ar, global_batch=gb(B),
+                                           backward=need_grad, Wc=tuple(Wp[f"projector.{i}.weight"] for i in (0, 3, 6)))
+            dA = [E.maxmean_backward(dt, dY[v * B:(v + 1) * B], arg, H) for v, (c, H, arg) in enumerate(views)] if need_grad else []
+            return loss, views, dA
+        loss, views, dA = R.phase("forward", forward_phase)
         if need_grad:
             self.reduce_begin("heads")                      # projector gradients are complete: start their all-reduce
-            for v, (c, H, arg) in enumerate(views):
-                E.encoder_backward(c, G, dA2=E.maxmean_backward(dt, dY[v * B:(v + 1) * B], arg, H))
+
+            def backward_phase():
+                for (c, H, arg), d in zip(views, dA):
+                    E.encoder_backward(c, G, dA2=d)
+            R.phase("encoder_bwd", backward_phase)
             self.reduce_begin("enc")
         return loss[0]
+
+    def graph_phases_supported(self):
+        ar, _ = self._barlow_reduce()
+        return ar is None                                   # cross-GPU Barlow has an all-reduce inside the forward phase
 
     def _barlow_reduce(self):
         import torch.distributed as dist

@@ -72,8 +72,10 @@ class HipTrainer:
             model.load_state_dict(ck["state_dict"], strict=False)
             self.epoch, self.global_step = ck.get("epoch", 0), ck.get("global_step", 0)
         best = float("inf")
-        # one rank: the step is a single hipGraph replay; data-parallel: eager launches around the RCCL collectives
-        gstep = model.graphed_step(opt) if (self.world == 1 and self.use_graph and hasattr(model, "graphed_step")) else None
+        # one rank: the step is a single hipGraph replay; data-parallel: one graph per collective-free phase
+        gstep = None
+        if self.use_graph and hasattr(model, "graphed_step") and (self.world == 1 or model.graph_phases_supported()):
+            gstep = model.graphed_step(opt)
         for epoch in range(self.epoch, self.max_epochs):
             self.epoch = epoch
             if sampler is not None:

@@ -128,6 +128,7 @@ def main():
     ap.add_argument("--cpu-steps", type=int, default=80, help="upper bound; the CPU leg also stops after ~20 s")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="issue the step kernel by kernel instead of replaying the hipGraph")
+    ap.add_argument("--graph-phases", action="store_true", help="single rank: use the data-parallel variant (one graph per phase)")
     args = ap.parse_args()
 
     rank, world = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
@@ -161,8 +162,8 @@ def main():
     waves = torch.from_numpy(synth_waves(B, 16000, 1234 + rank)).to(dev)
 
     # single rank: the product's step is one hipGraph replay (zero_grad + fused fwd/bwd + SGD) behind the eager front end;
-    # data-parallel ranks issue the step eagerly around the RCCL collectives.
-    gstep = model.graphed_step(opt) if (world == 1 and not args.no_graph) else None
+    # data-parallel ranks replay one graph per collective-free phase with the RCCL calls in between.
+    gstep = None if args.no_graph else model.graphed_step(opt, phases=args.graph_phases)
 
     def step(i):
         img_1, img_2 = front(waves)

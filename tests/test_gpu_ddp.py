@@ -16,11 +16,12 @@ from conftest import CFG_M, CFG_S
 pytestmark = pytest.mark.gpu
 
 
-def _worker(rank, world, port, which, steps, ret):
+def _worker(rank, world, port, which, steps, graph, ret):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     os.environ["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
     torch.cuda.set_device(0)
+    torch.manual_seed(77)                                       # the MoCo batch-shuffle permutation comes from torch's generator
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         from oracle import fill
@@ -44,7 +45,7 @@ def _worker(rank, world, port, which, steps, ret):
             m.queue.copy_(closed_queue(128, K))
         m = m.cuda().train()
         opt = m.configure_optimizers()
-        step = m.graphed_step(opt) if os.environ.get("AUDIOSSL_TEST_DDP_GRAPH") == "1" else None
+        step = m.graphed_step(opt, eager_steps=1) if graph else None
         losses = []
         for s in range(steps):
             a = views(B, T, 9300 + 10 * s + rank).cuda()       # different clips per rank
@@ -59,7 +60,8 @@ def _worker(rank, world, port, which, steps, ret):
                 opt.step()
             losses.append(float(loss))
         torch.cuda.synchronize()
-        out = {"losses": losses, "w": {n: p.detach().float().cpu().numpy() for n, p in m.named_parameters()}}
+        out = {"losses": losses, "w": {n: p.detach().float().cpu().numpy() for n, p in m.named_parameters()},
+               "graphs": None if step is None else (sorted(step.phases.graphs), step.phases.broken)}
         if which == "delores_m":
             out["queue"] = m.queue.cpu().numpy()
             out["ptr"] = int(m.queue_ptr[0])
@@ -68,11 +70,11 @@ def _worker(rank, world, port, which, steps, ret):
         dist.destroy_process_group()
 
 
-def _run(which, steps=3, world=2):
+def _run(which, steps=4, world=2, graph=False):
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     mgr = mp.Manager()
     ret = mgr.dict()
-    mp.spawn(_worker, args=(world, port, which, steps, ret), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, port, which, steps, graph, ret), nprocs=world, join=True)
     return [ret[r] for r in range(world)]
 
 
@@ -84,7 +86,26 @@ def test_two_rank_step_keeps_replicas_identical(which):
     for n in r0["w"]:                                          # ... the all-reduced update does not
         np.testing.assert_array_equal(r0["w"][n], r1["w"][n], err_msg=n)
     if which == "delores_m":
-        assert r0["ptr"] == r1["ptr"] == (3 * 2 * 16) % 256    # the queue advances by the GLOBAL batch
+        assert r0["ptr"] == r1["ptr"] == (4 * 2 * 16) % 256    # the queue advances by the GLOBAL batch
         np.testing.assert_array_equal(r0["queue"], r1["queue"])
         # trainable weights moved, key encoder moved by the EMA only
         assert not np.array_equal(r0["w"]["encoder_q.fc.weight"], r0["w"]["encoder_k.fc.weight"])
+
+
+@pytest.mark.parametrize("which", ["delores_m", "delores_s"])
+def test_two_rank_graph_phases_match_eager(which):
+    """Data-parallel graph step (one hipGraph per collective-free phase, collectives in between) against the eagerly
+    issued data-parallel step on the same clips: same losses / weights up to fp32 atomic order, replicas identical."""
+    from helpers import rel_l2
+    e0, _ = _run(which, graph=False)
+    g0, g1 = _run(which, graph=True)
+    want = ["encoder_bwd", "heads", "key", "query"] if which == "delores_m" else ["encoder_bwd", "forward"]
+    assert g0["graphs"] == (want, None) and g1["graphs"] == (want, None)
+    for n in g0["w"]:
+        np.testing.assert_array_equal(g0["w"][n], g1["w"][n], err_msg=n)
+    np.testing.assert_allclose(g0["losses"], e0["losses"], rtol=2e-3)
+    for n in g0["w"]:
+        assert rel_l2(torch.from_numpy(g0["w"][n]), torch.from_numpy(e0["w"][n])) < 2e-2, n
+    if which == "delores_m":
+        assert g0["ptr"] == e0["ptr"]
+        assert rel_l2(torch.from_numpy(g0["queue"]), torch.from_numpy(e0["queue"])) < 2e-2
