@@ -136,6 +136,35 @@ __global__ __launch_bounds__(256) void ce_rows_kernel(const float* __restrict__ 
             dlogits[r * K + c] = from_f32<T_>(valid ? (expf(row[c] - l) - (c == t ? 1.f : 0.f)) * inv : 0.f);
 }
 
+// ---------------------------------------------------------------------------------------------------- row softmax
+// nn.Softmax(dim=1) of SLICER's cluster projector (`src/upstream/slicer/upstream_encoder.py:19`): one wave per row.
+__global__ __launch_bounds__(256) void softmax_rows_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, int M, int C) {
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (r >= M) return;
+    const float* row = x + (long)r * C;
+    float m = -3.0e38f;
+    for (int c = lane; c < C; c += 64) m = fmaxf(m, row[c]);
+    m = wave_max(m);
+    float s = 0.f;
+    for (int c = lane; c < C; c += 64) s += expf(row[c] - m);
+    s = wave_sum(s);
+    const float inv = 1.f / s;
+    for (int c = lane; c < C; c += 64) y[(long)r * C + c] = expf(row[c] - m) * inv;
+}
+
+// dx = y * (gy - sum_c gy*y)
+__global__ __launch_bounds__(256) void softmax_rows_bwd_kernel(const float* __restrict__ y, const float* __restrict__ gy,
+                                                               float* __restrict__ gx, int M, int C) {
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (r >= M) return;
+    const float* yr = y + (long)r * C;
+    const float* gr = gy + (long)r * C;
+    float d = 0.f;
+    for (int c = lane; c < C; c += 64) d += yr[c] * gr[c];
+    d = wave_sum(d);
+    for (int c = lane; c < C; c += 64) gx[(long)r * C + c] = yr[c] * (gr[c] - d);
+}
+
 // ---------------------------------------------------------------------------------------------------- LARS
 // seg[i] = {offset, numel, flags}: flags bit0 = apply weight decay, bit1 = apply the trust ratio
 // norms[i] = {sum p^2, sum dp^2} with dp = g + wd*p (if bit0)
@@ -232,6 +261,18 @@ extern "C" int audiossl_ce_rows(int dtype, const float* logits, const long long*
     hipLaunchKernelGGL(count_valid_kernel, dim3(1), dim3(256), 0, s, target, B, ignore_index, cnt);
     if (dtype == 0) hipLaunchKernelGGL(ce_rows_kernel<float>, dim3(B), dim3(256), 0, s, logits, target, K, ignore_index, cnt, loss_out, (float*)dlogits);
     else            hipLaunchKernelGGL(ce_rows_kernel<bf16>, dim3(B), dim3(256), 0, s, logits, target, K, ignore_index, cnt, loss_out, (bf16*)dlogits);
+    ASSL_LAUNCH_CHECK();
+}
+
+extern "C" int audiossl_softmax_rows_fwd(const float* x, float* y, int M, int C, void* stream) {
+    ASSL_REQUIRE(x && y && M > 0 && C > 0);
+    hipLaunchKernelGGL(softmax_rows_fwd_kernel, dim3(ceil_div(M, 4)), dim3(256), 0, S_(stream), x, y, M, C);
+    ASSL_LAUNCH_CHECK();
+}
+
+extern "C" int audiossl_softmax_rows_bwd(const float* y, const float* gy, float* gx, int M, int C, void* stream) {
+    ASSL_REQUIRE(y && gy && gx && M > 0 && C > 0);
+    hipLaunchKernelGGL(softmax_rows_bwd_kernel, dim3(ceil_div(M, 4)), dim3(256), 0, S_(stream), y, gy, gx, M, C);
     ASSL_LAUNCH_CHECK();
 }
 

@@ -60,4 +60,4 @@ class DownstreamEncoder(nn.Module):
             x = x[self.output_layer]
         if x.dim() == 3:
             x = MeanTFn.apply(x)                       # time pooling of the [N, T, d] embedding
-        return LinearFn.apply(x, self.final.weight, self.final.bias)
+        return LinearFn.apply(x, self.final.weight, self.final.bias, False)

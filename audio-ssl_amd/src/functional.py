@@ -34,36 +34,82 @@ class MaxMeanFn(torch.autograd.Function):
 
 
 class LinearFn(torch.autograd.Function):
-    """y = x W^T + b on the MFMA GEMM; x in the activation dtype, W / b fp32 parameters; y fp32."""
+    """y = x W^T + b [ReLU] on the MFMA GEMM; x in the activation dtype, W / b fp32 parameters; y fp32."""
 
     @staticmethod
-    def forward(ctx, x, W, b):
+    def forward(ctx, x, W, b, relu):
         x = x.contiguous()
         dt = _dtype_of(x)
         M, K = x.shape
         Wc = E.cast(dt, W.data)
-        y = E.linear_fwd(dt, x, Wc, M, W.shape[0], K, bias=None if b is None else b.data, out_f32=1)
-        ctx.save_for_backward(x, Wc)
+        y = E.linear_fwd(dt, x, Wc, M, W.shape[0], K, bias=None if b is None else b.data, relu=int(relu), out_f32=1)
+        ctx.save_for_backward(x, Wc, y if relu else None)
         ctx.has_bias = b is not None
         return y
 
     @staticmethod
     def backward(ctx, gy):
-        x, Wc = ctx.saved_tensors
+        x, Wc, y = ctx.saved_tensors
         dt = _dtype_of(x)
         M, K = x.shape
         Nout = Wc.shape[0]
-        g = gy.to(x.dtype).contiguous()
+        if y is not None:                           # ReLU gate on the stored output
+            gated = torch.empty_like(y)
+            N.call("relu_bwd", N.F32, gy.float().contiguous(), y, gated, y.numel())
+            gy = gated
+        g32 = gy.float().contiguous()
+        g = g32.to(x.dtype)
         Np = (Nout + 63) // 64 * 64                 # the kernels vectorise by 8 (GEMM) / 64 (column sums): pad the class axis
         if Np != Nout:
             g = torch.nn.functional.pad(g, (0, Np - Nout))
+            g32 = torch.nn.functional.pad(g32, (0, Np - Nout))
             Wc = torch.nn.functional.pad(Wc, (0, 0, 0, Np - Nout))
         dW = torch.zeros(Np, K, dtype=torch.float32, device=x.device)
         E.linear_bwd_w(dt, g, x, dW, M, Np, K)
         db = None
         if ctx.has_bias:
             db = torch.zeros(Np, dtype=torch.float32, device=x.device)
-            E.colsum_add(dt, g, M, Np, db)
+            E.colsum_add(N.F32, g32, M, Np, db)       # bias gradient from the unrounded fp32 gradient
             db = db[:Nout]
         dx = E.linear_bwd_x(dt, g, Wc, M, Np, K)
-        return dx, dW[:Nout], db
+        return dx, dW[:Nout], db, None
+
+
+class SoftmaxRowsFn(torch.autograd.Function):
+    """nn.Softmax(dim=1) on fp32 [M, C] (`src/upstream/slicer/upstream_encoder.py:19`)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        x = x.float().contiguous()
+        y = torch.empty_like(x)
+        N.call("softmax_rows_fwd", x, y, x.shape[0], x.shape[1])
+        ctx.save_for_backward(y)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        y, = ctx.saved_tensors
+        gx = torch.empty_like(y)
+        N.call("softmax_rows_bwd", y, gy.float().contiguous(), gx, y.shape[0], y.shape[1])
+        return gx
+
+
+class MocoCEFn(torch.autograd.Function):
+    """InfoNCE of MoCo against the queue: normalise q and k, logits [B, 1+K] / T, CE(label 0)
+    (`src/upstream/slicer/upstream_expert.py:196-218, 229-230`).  Forward also computes dq (one fused launch sequence);
+    returns (loss, normalised keys fp32 for the enqueue)."""
+
+    @staticmethod
+    def forward(ctx, q, k, queue, temperature, dtype):
+        loss = torch.zeros(1, dtype=torch.float32, device=q.device)
+        shadow = E.cast(dtype, queue) if dtype != N.F32 else queue
+        dq, kn32 = E.moco_forward_backward(dtype, q.float().contiguous(), k.float().contiguous(), queue, shadow,
+                                           float(temperature), loss, backward=True)
+        ctx.save_for_backward(dq)
+        ctx.mark_non_differentiable(kn32)
+        return loss[0].clone(), kn32
+
+    @staticmethod
+    def backward(ctx, g, _):
+        dq, = ctx.saved_tensors
+        return dq.float() * g, None, None, None, None

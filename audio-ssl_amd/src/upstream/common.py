@@ -5,6 +5,7 @@ import torch.nn as nn
 from src import _native as N
 from src import engine as E
 from src.flat import FlatGroup, cached_param_dict
+from src.utils import concat_all_gather
 
 
 
@@ -213,6 +214,80 @@ class GraphedStep:
         self.graph.replay()
         self.replays += 1
         return self.loss
+
+
+def _world():
+    import torch.distributed as dist
+    return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+
+
+class MocoQueueMixin:
+    """MoCo-v2 machinery shared by the experts with a query/key encoder pair and a negatives queue (delores_m, slicer):
+    EMA of the key encoder as ONE launch over the flat buffers, enqueue with the write pointer on the device, and the
+    data-parallel batch shuffle / unshuffle (`src/upstream/delores_m/upstream_expert.py:147-219` of the reference; the
+    removed `trainer.use_ddp` switch is replaced by the state of the process group)."""
+    flat_k = None
+
+    def on_reflatten(self):
+        self.flat_k = FlatGroup([(n, p) for n, p in self.encoder_k.named_parameters()])
+
+    @torch.no_grad()
+    def _momentum_update_key_encoder(self):
+        self.ensure_flat()
+        N.call("ema_update", self.flat_k.data, self.flat.data, self.flat_k.numel, float(self.hparams.encoder_momentum))
+
+    @torch.no_grad()
+    def _dequeue_and_enqueue(self, keys32, shadow):
+        if _world() > 1:
+            keys32 = concat_all_gather(keys32)
+        batch_size = keys32.shape[0]
+        K = self.hparams.num_negatives
+        assert K % batch_size == 0  # for simplicity
+        # the write position lives in the `queue_ptr` buffer and is advanced on the device (no host mirror: the step
+        # can be captured in a hipGraph and replayed)
+        N.call("enqueue", self.precision, keys32, batch_size, keys32.shape[1], K, 0, self.queue_ptr, self.queue, shadow)
+
+    @torch.no_grad()
+    def _shuffle_begin(self, x):
+        """Start the key-batch all-gather (13 MB per rank at B=512) on RCCL's stream; it overlaps the query encoder."""
+        import torch.distributed as dist
+        out = torch.empty((_world() * x.shape[0],) + tuple(x.shape[1:]), dtype=x.dtype, device=x.device)
+        return out, dist.all_gather_into_tensor(out, x.contiguous(), async_op=True)
+
+    @torch.no_grad()
+    def _shuffle_end(self, pending, batch_size_this):
+        import torch.distributed as dist
+        x_gather, work = pending
+        work.wait()
+        batch_size_all = x_gather.shape[0]
+        num_gpus = batch_size_all // batch_size_this
+        idx_shuffle = torch.randperm(batch_size_all, device=x_gather.device)
+        dist.broadcast(idx_shuffle, src=0)
+        idx_unshuffle = torch.argsort(idx_shuffle)
+        idx_this = idx_shuffle.view(num_gpus, -1)[dist.get_rank()]
+        return x_gather[idx_this], idx_unshuffle
+
+    @torch.no_grad()
+    def _batch_shuffle_ddp(self, x):
+        import torch.distributed as dist
+        batch_size_this = x.shape[0]
+        x_gather = concat_all_gather(x)
+        batch_size_all = x_gather.shape[0]
+        num_gpus = batch_size_all // batch_size_this
+        idx_shuffle = torch.randperm(batch_size_all, device=x.device)
+        dist.broadcast(idx_shuffle, src=0)
+        idx_unshuffle = torch.argsort(idx_shuffle)
+        idx_this = idx_shuffle.view(num_gpus, -1)[dist.get_rank()]
+        return x_gather[idx_this], idx_unshuffle
+
+    @torch.no_grad()
+    def _batch_unshuffle_ddp(self, x, idx_unshuffle):
+        import torch.distributed as dist
+        batch_size_this = x.shape[0]
+        x_gather = concat_all_gather(x)
+        num_gpus = x_gather.shape[0] // batch_size_this
+        idx_this = idx_unshuffle.view(num_gpus, -1)[dist.get_rank()]
+        return x_gather[idx_this]
 
 
 class FusedExpertMixin:

@@ -19,5 +19,5 @@ class DELORES_M(nn.Module):
         if self.return_all_layers is False:
             raise NotImplementedError("DELORES_M need return_all_layers = True to be set in the config!")
         l1, l2, l3, x = self.encoder(x)
-        x = LinearFn.apply(MaxMeanFn.apply(x), self.fc.weight, self.fc.bias)
+        x = LinearFn.apply(MaxMeanFn.apply(x), self.fc.weight, self.fc.bias, False)
         return x, l1, l2, l3

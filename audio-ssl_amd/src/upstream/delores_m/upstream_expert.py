@@ -16,7 +16,7 @@ from src import engine as E
 from src.encoder.audiontt import default_precision
 from src.flat import FlatGroup
 from src.module_base import UpstreamModule
-from src.upstream.common import EAGER, FusedExpertMixin, FusedStepFn, Projection, strip
+from src.upstream.common import EAGER, FusedExpertMixin, FusedStepFn, MocoQueueMixin, Projection, strip
 from src.upstream.delores_m.upstream_encoder import DELORES_M as DELORES_M_ENCODER
 from src.utils import concat_all_gather
 
@@ -26,7 +26,7 @@ def _world():
     return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
 
 
-class Upstream_Expert(FusedExpertMixin, UpstreamModule):
+class Upstream_Expert(MocoQueueMixin, FusedExpertMixin, UpstreamModule):
     def __init__(self, config, base_encoder, datamodule=None, emb_dim: int = 128, num_negatives: int = 65536,
                  encoder_momentum: float = 0.999, softmax_temperature: float = 0.07, learning_rate: float = 0.03,
                  momentum: float = 0.9, weight_decay: float = 1e-4, data_dir: str = './', batch_size: int = 256,
@@ -64,67 +64,6 @@ class Upstream_Expert(FusedExpertMixin, UpstreamModule):
         named = [(n, p) for n, p in self.named_parameters() if n.startswith("encoder_q.")]
         named += [(n, p) for n, p in self.named_parameters() if n.startswith(("p1.", "p2.", "p3."))]
         return named
-
-    def on_reflatten(self):
-        self.flat_k = FlatGroup([(n, p) for n, p in self.encoder_k.named_parameters()])
-
-    @torch.no_grad()
-    def _momentum_update_key_encoder(self):
-        self.ensure_flat()
-        N.call("ema_update", self.flat_k.data, self.flat.data, self.flat_k.numel, float(self.hparams.encoder_momentum))
-
-    @torch.no_grad()
-    def _dequeue_and_enqueue(self, keys32, shadow):
-        if _world() > 1:
-            keys32 = concat_all_gather(keys32)
-        batch_size = keys32.shape[0]
-        K = self.hparams.num_negatives
-        assert K % batch_size == 0  # for simplicity
-        # the write position lives in the `queue_ptr` buffer and is advanced on the device (no host mirror: the step
-        # can be captured in a hipGraph and replayed)
-        N.call("enqueue", self.precision, keys32, batch_size, keys32.shape[1], K, 0, self.queue_ptr, self.queue, shadow)
-
-    @torch.no_grad()
-    def _shuffle_begin(self, x):
-        """Start the key-batch all-gather (13 MB per rank at B=512) on RCCL's stream; it overlaps the query encoder."""
-        import torch.distributed as dist
-        out = torch.empty((_world() * x.shape[0],) + tuple(x.shape[1:]), dtype=x.dtype, device=x.device)
-        return out, dist.all_gather_into_tensor(out, x.contiguous(), async_op=True)
-
-    @torch.no_grad()
-    def _shuffle_end(self, pending, batch_size_this):
-        import torch.distributed as dist
-        x_gather, work = pending
-        work.wait()
-        batch_size_all = x_gather.shape[0]
-        num_gpus = batch_size_all // batch_size_this
-        idx_shuffle = torch.randperm(batch_size_all, device=x_gather.device)
-        dist.broadcast(idx_shuffle, src=0)
-        idx_unshuffle = torch.argsort(idx_shuffle)
-        idx_this = idx_shuffle.view(num_gpus, -1)[dist.get_rank()]
-        return x_gather[idx_this], idx_unshuffle
-
-    @torch.no_grad()
-    def _batch_shuffle_ddp(self, x):
-        import torch.distributed as dist
-        batch_size_this = x.shape[0]
-        x_gather = concat_all_gather(x)
-        batch_size_all = x_gather.shape[0]
-        num_gpus = batch_size_all // batch_size_this
-        idx_shuffle = torch.randperm(batch_size_all, device=x.device)
-        dist.broadcast(idx_shuffle, src=0)
-        idx_unshuffle = torch.argsort(idx_shuffle)
-        idx_this = idx_shuffle.view(num_gpus, -1)[dist.get_rank()]
-        return x_gather[idx_this], idx_unshuffle
-
-    @torch.no_grad()
-    def _batch_unshuffle_ddp(self, x, idx_unshuffle):
-        import torch.distributed as dist
-        batch_size_this = x.shape[0]
-        x_gather = concat_all_gather(x)
-        num_gpus = x_gather.shape[0] // batch_size_this
-        idx_this = idx_unshuffle.view(num_gpus, -1)[dist.get_rank()]
-        return x_gather[idx_this]
 
     # ------------------------------------------------------------------ fused step
     def fused_loss(self, img_q, img_k, need_grad=True, parts=None, runner=None):

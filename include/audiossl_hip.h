@@ -199,6 +199,11 @@ int audiossl_kmeans_update(const float* sums, const int* counts, int K, int D, f
 int audiossl_ce_rows(int dtype, const float* logits, const long long* target, int B, int K, int ignore_index, int* cnt,
                      float* loss_out, void* dlogits, void* stream);
 
+/* ---- row softmax: nn.Softmax(dim=1) closing SLICER's cluster projector (src/upstream/slicer/upstream_encoder.py:15-20);
+ * fp32 [M][C]; bwd: gx = y * (gy - sum_c gy*y). */
+int audiossl_softmax_rows_fwd(const float* x, float* y, int M, int C, void* stream);
+int audiossl_softmax_rows_bwd(const float* y, const float* gy, float* gx, int M, int C, void* stream);
+
 /* ---- LARS: extras/delores-s/multi_proc.py:4-43, on the flat parameter buffer ---------------------------------------
  * seg: n_seg x {int64 offset, int64 numel, int32 flags (bit0 weight decay, bit1 trust ratio), int32 pad} (device);
  * lr: per-segment learning rate (device); norms: 2*n_seg doubles of scratch. */

@@ -257,6 +257,70 @@ class DeloresMExpert(nn.Module):
         return ce + b1 + b2 + b3
 
 
+class SLICER(nn.Module):
+    """`src/upstream/slicer/upstream_encoder.py:4-35`: encoder -> max_T + mean_T -> instance Linear and cluster MLP+Softmax."""
+
+    def __init__(self, config, base_encoder=AudioNTT2020Task6):
+        super().__init__()
+        pre = config["pretrain"]
+        d = pre["base_encoder"]["output_dim"]
+        self.encoder = base_encoder(pre["input"]["n_mels"], d, pre["base_encoder"]["return_all_layers"])
+        self.instance_projector = nn.Linear(d, pre["instance_contrastive_dim"])
+        self.cluster_projector = nn.Sequential(nn.Linear(d, d), nn.ReLU(), nn.Linear(d, pre["cluster_contrastive_dim"]),
+                                               nn.Softmax(dim=1))
+
+    def forward(self, x, drop_mask=None):
+        x = _maxmean(self.encoder(x, drop_mask))
+        return self.instance_projector(x), self.cluster_projector(x)
+
+
+class SlicerExpert(nn.Module):
+    """`src/upstream/slicer/upstream_expert.py:13-276`, single process: symmetric MoCo InfoNCE (two forward calls with the
+    views swapped; each call updates the key encoder and enqueues its keys) + ClusterLoss(class_num, temperature 1) on
+    the query-side soft assignments of the two calls.  The shipped training_step returns the first call's CE only
+    (`:237`); `parts` carries every term it logs, the return value is the logged `train_loss`."""
+
+    def __init__(self, config, emb_dim=128, num_negatives=65536, encoder_momentum=0.999, softmax_temperature=0.07,
+                 learning_rate=0.03, momentum=0.9, weight_decay=1e-4):
+        super().__init__()
+        self.encoder_q = SLICER(config)
+        self.encoder_k = SLICER(config)
+        for pq, pk in zip(self.encoder_q.parameters(), self.encoder_k.parameters()):
+            pk.data.copy_(pq.data)
+            pk.requires_grad = False
+        self.register_buffer("queue", F.normalize(torch.randn(emb_dim, num_negatives), dim=0))
+        self.register_buffer("queue_ptr", torch.zeros(1, dtype=torch.long))
+        self.m, self.T, self.K = encoder_momentum, softmax_temperature, num_negatives
+        self.hp = dict(lr=learning_rate, momentum=momentum, weight_decay=weight_decay)
+
+    @torch.no_grad()
+    def momentum_update(self):
+        for pq, pk in zip(self.encoder_q.parameters(), self.encoder_k.parameters()):
+            pk.data = pk.data * self.m + pq.data * (1.0 - self.m)
+
+    def one_direction(self, img_q, img_k, mask_q, mask_k):
+        q, q_cluster = self.encoder_q(img_q, mask_q)
+        q = F.normalize(q, dim=1)
+        with torch.no_grad():
+            self.momentum_update()
+            k, _ = self.encoder_k(img_k, mask_k)
+            k = F.normalize(k, dim=1)
+        logits = moco_logits(q, k, self.queue, self.T)
+        with torch.no_grad():
+            self.queue_ptr[0] = moco_enqueue(self.queue, int(self.queue_ptr), k)
+        ce = F.cross_entropy(logits.float(), torch.zeros(logits.shape[0], dtype=torch.long))
+        return ce, q_cluster
+
+    def training_loss(self, img_1, img_2, masks=(None, None, None, None), parts=None):
+        """masks: dropout keep-masks in call order (q on view 1, k on view 2, q on view 2, k on view 1)."""
+        ce_a, qc_a = self.one_direction(img_1, img_2, masks[0], masks[1])
+        ce_b, qc_b = self.one_direction(img_2, img_1, masks[2], masks[3])
+        cl = cluster_loss(qc_a, qc_b, 1.0)
+        if parts is not None:
+            parts.update(ce_first=ce_a.detach(), sym=(ce_a + ce_b).detach(), cluster=cl.detach())
+        return ce_a + ce_b + cl
+
+
 # ---------------------------------------------------------------- optimisers
 @torch.no_grad()
 def sgd_momentum_step(params, bufs, lr, momentum, weight_decay):

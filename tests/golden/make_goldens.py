@@ -395,6 +395,57 @@ def g10_lars(MP):
     save("lars", p0=t2n(ps[0]), p1=t2n(ps[1]), p2=t2n(ps[2]))
 
 
+CFG_SL = {"pretrain": dict(CFG_S["pretrain"], instance_contrastive_dim=128, cluster_contrastive_dim=128)}
+
+
+def g11_slicer(CL, ENC):
+    """SLICER expert (`src/upstream/slicer/upstream_expert.py`): the plugin imports `ClusterLoss` from `src.utils`, where
+    the reference forgot to put it; the class of `extras/slicer/contrastive_loss.py` is attached to the
+    imported `src.utils` module object before the plugin is imported.  Two steps, B=8, queue 256."""
+    import src.utils as ref_utils
+    ref_utils.ClusterLoss = CL.ClusterLoss
+    XSL = importlib.import_module("src.upstream.slicer.upstream_expert")
+    B, T, Tp, K = 8, 101, 12, 256
+    torch.manual_seed(0)
+    ex = XSL.Upstream_Expert(CFG_SL, base_encoder=ENC.AudioNTT2020Task6, num_negatives=K)
+    fill.fill_state_dict_(ex, seed=5)
+    for pq, pk in zip(ex.encoder_q.parameters(), ex.encoder_k.parameters()):
+        pk.data.copy_(pq.data)
+    ex.queue.copy_(_closed_queue(128, K))
+    ex.trainer = _Trainer()
+    fq, fk = FixedMaskDropout(0.3), FixedMaskDropout(0.3)
+    ex.encoder_q.encoder.fc[2] = fq
+    ex.encoder_k.encoder.fc[2] = fk
+    ex.train()
+    opt = ex.configure_optimizers()
+    logged = []
+    ex.log_dict = lambda d, *a, **k: logged.append(d)
+    returned, combine, sym, cluster, ptrs = [], [], [], [], []
+    for s in range(2):
+        fq.masks = [drop_mask((B, Tp, 2048), 8100 + 4 * s), drop_mask((B, Tp, 2048), 8102 + 4 * s)]     # q: view 1, view 2
+        fk.masks = [drop_mask((B, Tp, 2048), 8101 + 4 * s), drop_mask((B, Tp, 2048), 8103 + 4 * s)]     # k: view 2, view 1
+        a, b = views(B, T, 8000 + 2 * s), views(B, T, 8001 + 2 * s)
+        opt.zero_grad()
+        loss = ex.training_step((a, b), s)
+        log = logged[-1]
+        log["train_loss"].backward()            # gradient of the logged total (the shipped step returns the first CE only)
+        if s == 0:
+            gd0 = grad_digest(ex)
+        opt.step()
+        returned.append(float(loss))
+        combine.append(float(log["train_loss"]))
+        sym.append(float(log["sym_instance_loss"]))
+        cluster.append(float(log["train_loss_cluster"]))
+        ptrs.append(int(ex.queue_ptr))
+    sd = ex.state_dict()
+    save("step_slicer", returned=np.array(returned), combine=np.array(combine), sym=np.array(sym), cluster=np.array(cluster),
+         ptrs=np.array(ptrs), g_names=gd0["names"], g_norms=gd0["norms"], g_heads=gd0["heads"],
+         queue_cols=t2n(sd["queue"][:, :32]),
+         wq_conv1=t2n(sd["encoder_q.encoder.features_1.0.weight"]).ravel(),
+         wq_cluster=t2n(sd["encoder_q.cluster_projector.2.weight"]).ravel()[:256],
+         wk_inst=t2n(sd["encoder_k.instance_projector.weight"]).ravel()[:256])
+
+
 def main():
     _install_shims()
     sys.path.insert(0, REF)
@@ -408,6 +459,9 @@ def main():
     CL = _load_by_path("ref_closs", os.path.join(REF, "extras/slicer/contrastive_loss.py"))
     MP = _load_by_path("ref_multiproc", os.path.join(REF, "extras/delores-s/multi_proc.py"))
     torch.set_num_threads(8)
+    if len(sys.argv) > 1 and sys.argv[1] == "slicer":          # regenerate one fixture without touching the others
+        g11_slicer(CL, ENC)
+        return
     g1_window(U)
     g2_runnorm(A)
     g3_aug(A_pkg)
@@ -418,6 +472,7 @@ def main():
     g8_contrastive(CL)
     g10_lars(MP)
     g7_g9_steps(XS, XM, ENC)
+    g11_slicer(CL, ENC)
 
 
 if __name__ == "__main__":

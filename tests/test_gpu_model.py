@@ -221,6 +221,53 @@ def test_delores_m_b32_vs_oracle(cfg_m, prec):
         assert rel_l2(gp, gr) < {"fp32": 2e-3, "bf16": 0.25, "bf16_hp": 0.16}[prec], n
 
 
+@pytest.mark.parametrize("prec", ["fp32", "bf16"])
+def test_slicer_steps_vs_reference_golden(golden, cfg_s, prec):
+    """SLICER: symmetric MoCo + ClusterLoss, two SGD steps, against numbers produced by the reference's own plugin
+    (tests/golden/make_goldens.py g11): every logged loss term, gradient norms of the logged total, queue, weights."""
+    from src.encoder import AudioNTT2020Task6
+    from src.upstream.slicer.upstream_expert import Upstream_Expert
+    g = golden("step_slicer")
+    cfg = _cfg(cfg_s, prec)
+    cfg["pretrain"].update(instance_contrastive_dim=128, cluster_contrastive_dim=128)
+    K = 256
+    ex = Upstream_Expert(cfg, base_encoder=AudioNTT2020Task6, num_negatives=K)
+    fill.fill_state_dict_(ex, seed=5)
+    for pq, pk in zip(ex.encoder_q.parameters(), ex.encoder_k.parameters()):
+        pk.data.copy_(pq.data)
+    ex.queue.copy_(closed_queue(128, K))
+    ex = ex.cuda().train()
+    B, T, Tp = 8, 101, 12
+    logs = []
+
+    def masks(s):
+        if s > 0:
+            logs.append({k: float(v) for k, v in ex.logged.items()})
+        m = [drop_mask((B, Tp, 2048), 8100 + 4 * s + i) for i in range(4)]          # q(v1), k(v2), q(v2), k(v1)
+        ex.encoder_q.encoder.dropout_masks.queue = [m[0], m[2]]
+        ex.encoder_k.encoder.dropout_masks.queue = [m[1], m[3]]
+    losses, (names, norms, heads) = _run_steps(
+        ex, lambda s: (views(B, T, 8000 + 2 * s).cuda(), views(B, T, 8001 + 2 * s).cuda()), masks, 2)
+    logs.append({k: float(v) for k, v in ex.logged.items()})
+    assert names == [str(n) for n in g["g_names"]]
+    np.testing.assert_allclose(losses, g["combine"], rtol=LOSS_TOL[prec])
+    np.testing.assert_allclose([l["sym_instance_loss"] for l in logs], g["sym"], rtol=LOSS_TOL[prec])
+    np.testing.assert_allclose([l["train_loss_cluster"] for l in logs], g["cluster"], rtol=LOSS_TOL[prec])
+    for n, got, want in zip(names, norms, g["g_norms"]):
+        if n.endswith(".0.bias") and "features" in n:
+            continue
+        # the cluster head sits at its uniform fixed point (loss = log 255): its gradients are ~1e-6 of the encoder's,
+        # pure cancellation - compared with a floor relative to the largest gradient in the model
+        assert abs(got - want) <= GRAD_TOL[prec] * want + 1e-5 * float(np.max(g["g_norms"])), (n, got, want)
+    sd = ex.state_dict()
+    assert int(sd["queue_ptr"]) == int(g["ptrs"][-1]) == 32
+    tol = 2e-3 if prec == "fp32" else 3e-2
+    assert rel_l2(sd["queue"][:, :32].cpu(), g["queue_cols"]) < tol
+    assert rel_l2(sd["encoder_k.instance_projector.weight"].cpu().ravel()[:256], g["wk_inst"]) < tol
+    if prec == "fp32":
+        np.testing.assert_allclose(sd["encoder_q.cluster_projector.2.weight"].cpu().numpy().ravel()[:256], g["wq_cluster"], rtol=5e-3, atol=3e-4)
+
+
 # ------------------------------------------------------------------------------------------------ hipGraph replay
 @pytest.mark.parametrize("which", ["delores_m", "delores_s"])
 def test_graphed_step_matches_eager(cfg_m, cfg_s, which):

@@ -250,3 +250,53 @@ def test_delores_m_three_steps(golden, cfg_m):
     np.testing.assert_allclose(sd["queue"][:, :24].numpy(), g["queue_cols"], rtol=1e-4, atol=1e-6)
     np.testing.assert_allclose(sd["encoder_k.encoder.features_1.0.weight"].numpy().ravel(), g["wk_conv1"], rtol=1e-5, atol=1e-7)
     np.testing.assert_allclose(sd["encoder_q.encoder.features_1.0.weight"].numpy().ravel(), g["wq_conv1"], rtol=1e-4, atol=1e-6)
+
+
+CFG_SL_EXTRA = dict(instance_contrastive_dim=128, cluster_contrastive_dim=128)
+
+
+def slicer_cfg(cfg_s):
+    import copy
+    c = copy.deepcopy(cfg_s)
+    c["pretrain"].update(CFG_SL_EXTRA)
+    return c
+
+
+def test_slicer_two_steps(golden, cfg_s):
+    """SLICER (symmetric MoCo + ClusterLoss): every logged loss term, the gradient of the logged total, queue, weights."""
+    g = golden("step_slicer")
+    K = 256
+    ex = OM.SlicerExpert(slicer_cfg(cfg_s), num_negatives=K)
+    fill.fill_state_dict_(ex, seed=5)
+    for pq, pk in zip(ex.encoder_q.parameters(), ex.encoder_k.parameters()):
+        pk.data.copy_(pq.data)
+    ex.queue.copy_(closed_queue(128, K))
+    ex.train()
+    B, T, Tp = 8, 101, 12
+    bufs, ptrs, got = {}, [], {"returned": [], "combine": [], "sym": [], "cluster": []}
+    params = [p for p in ex.parameters() if p.requires_grad]
+    for s in range(2):
+        for p in params:
+            p.grad = None
+        masks = [drop_mask((B, Tp, 2048), 8100 + 4 * s + i) for i in range(4)]     # q(v1), k(v2), q(v2), k(v1)
+        parts = {}
+        loss = ex.training_loss(views(B, T, 8000 + 2 * s), views(B, T, 8001 + 2 * s), masks, parts)
+        loss.backward()
+        if s == 0:
+            names, norms, _ = grad_digest(ex)
+            assert names == [str(n) for n in g["g_names"]]
+            np.testing.assert_allclose(norms, g["g_norms"], rtol=5e-4)
+        OM.sgd_momentum_step(params, bufs, lr=0.03, momentum=0.9, weight_decay=1e-4)
+        got["returned"].append(float(parts["ce_first"]))
+        got["combine"].append(float(loss))
+        got["sym"].append(float(parts["sym"]))
+        got["cluster"].append(float(parts["cluster"]))
+        ptrs.append(int(ex.queue_ptr))
+    for k, v in got.items():
+        np.testing.assert_allclose(v, g[k], rtol=3e-5, err_msg=k)
+    assert ptrs == list(g["ptrs"]) == [16, 32]
+    sd = ex.state_dict()
+    np.testing.assert_allclose(sd["queue"][:, :32].numpy(), g["queue_cols"], rtol=1e-4, atol=1e-6)
+    np.testing.assert_allclose(sd["encoder_q.encoder.features_1.0.weight"].numpy().ravel(), g["wq_conv1"], rtol=1e-4, atol=1e-6)
+    np.testing.assert_allclose(sd["encoder_q.cluster_projector.2.weight"].numpy().ravel()[:256], g["wq_cluster"], rtol=1e-4, atol=1e-6)
+    np.testing.assert_allclose(sd["encoder_k.instance_projector.weight"].numpy().ravel()[:256], g["wk_inst"], rtol=1e-5, atol=1e-7)
