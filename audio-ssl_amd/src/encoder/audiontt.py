@@ -72,6 +72,8 @@ class _EncoderFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, mod, x, keep, *params):
+        """params: the encoder's parameters in the order of `mod.engine_param_names()` (autograd hands their gradients
+        back in that order).  `mod.param_dict()` is keyed the way the launch sequences expect (`features_1.0.weight` ...)."""
         P = mod.param_dict()
         x1, x2, x3, h, c = E.encoder_forward(P, x, mod.precision, keep=keep, p_drop=mod.fc[2].p, train=mod.training)
         ctx.mod, ctx.c = mod, c
@@ -81,13 +83,15 @@ class _EncoderFn(torch.autograd.Function):
     def backward(ctx, g1, g2, g3, gh):
         mod, c = ctx.mod, ctx.c
         td = N.torch_dtype(c.dtype)
-        G = {n: torch.zeros_like(p, dtype=torch.float32) for n, p in mod.named_parameters()}
+        P = mod.param_dict()
+        names = mod.engine_param_names()
+        G = {n: torch.zeros_like(P[n], dtype=torch.float32) for n in names}
 
         def prep(g, like):
             return None if g is None else g.float().contiguous()         # layer-mean gradients enter pool backwards: fp32
         gh = torch.zeros_like(c.H2.view(c.N, -1, c.d)) if gh is None else gh.to(td).contiguous()
         E.encoder_backward(c, G, dH2=gh.view(c.M, c.d), dx1=prep(g1, None), dx2=prep(g2, None), dx3=prep(g3, None))
-        return (None, None, None) + tuple(G[n] for n, _ in mod.named_parameters())
+        return (None, None, None) + tuple(G[n] for n in names)
 
 
 class AudioNTT2020Task6(nn.Module, NetworkCommonMixIn):
@@ -114,6 +118,9 @@ class AudioNTT2020Task6(nn.Module, NetworkCommonMixIn):
         """Reference-keyed fp32 tensors (parameters and BatchNorm buffers)."""
         from src.flat import cached_param_dict
         return cached_param_dict(self)
+
+    def engine_param_names(self):
+        return [n for n, _ in self.named_parameters()]
 
     def next_keep_mask(self, n_img, T):
         if not self.training:

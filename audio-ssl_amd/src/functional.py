@@ -113,3 +113,38 @@ class MocoCEFn(torch.autograd.Function):
     def backward(ctx, g, _):
         dq, = ctx.saved_tensors
         return dq.float() * g, None, None, None, None
+
+
+class BatchNorm1dFn(torch.autograd.Function):
+    """nn.BatchNorm1d (+ optional ReLU) on a fp32 pre-activation [M, C]: batch statistics in fp64 sums (`colstats` +
+    `bn_finalize`, which also updates the running buffers), normalise + ReLU into the activation dtype (`colbn_fwd`);
+    backward is the two-pass `colbn_bwd`.  Eval mode folds the running statistics into an affine map."""
+
+    @staticmethod
+    def forward(ctx, a, weight, bias, running_mean, running_var, dtype, relu, training):
+        a = a.float().contiguous()
+        M, C = a.shape
+        if training:
+            st = E._bn_train(N.F32, a, M, C, weight.data, bias.data, running_mean, running_var, True)
+        else:
+            st = E._bn_eval(a, C, weight.data, bias.data, running_mean, running_var) + (None, None)
+        h = torch.empty(M, C, dtype=N.torch_dtype(dtype), device=a.device)
+        N.call("colbn_fwd", dtype, N.F32, a, st[0], st[1], int(relu), h, 1, M, C)
+        ctx.save_for_backward(a, *[t for t in st if t is not None])
+        ctx.meta = (dtype, int(relu), training)
+        return h
+
+    @staticmethod
+    def backward(ctx, dh):
+        dtype, relu, training = ctx.meta
+        if not training:
+            raise RuntimeError("BatchNorm1dFn: backward through eval-mode statistics is not part of the HIP path")
+        a, scale, shift, mean, rstd = ctx.saved_tensors
+        M, C = a.shape
+        tmp = torch.empty(2 * C, dtype=torch.float64, device=a.device)
+        da = torch.empty(M, C, dtype=N.torch_dtype(dtype), device=a.device)
+        dgamma = torch.zeros(C, dtype=torch.float32, device=a.device)
+        dbeta = torch.zeros(C, dtype=torch.float32, device=a.device)
+        N.call("colbn_bwd", dtype, N.F32, N.F32, a, dh.float().contiguous(), scale, shift, mean, rstd, relu, 1, M, C, tmp, da,
+               dgamma, dbeta)
+        return da.float(), dgamma, dbeta, None, None, None, None, None

@@ -321,6 +321,52 @@ class SlicerExpert(nn.Module):
         return ce_a + ce_b + cl
 
 
+class DecarV2Model(nn.Module):
+    """`extras/decar-v2/models_delores.py:33-122` (AudioNTT2020): the Task6 encoder written as ONE `features` Sequential
+    (state_dict keys `features.{0,1,4,5,8,9}.*`, `fc.{0,3}.*`), max_T + mean_T, projection head
+    Linear(d, 2048)-BN-ReLU-Linear(2048, out_dim), one bias-free prototype layer per k-means head (`MultiPrototypes`,
+    utils.py:134-145: `prototypes.prototypes<i>.weight`).  forward(batch) -> (embedding of view 1, [scores of view 2])."""
+
+    def __init__(self, out_dim=512, n_mels=64, d=2048, nmb_prototypes=(1024,), p_drop=0.3):
+        super().__init__()
+        layers = []
+        for cin in (1, 64, 64):
+            layers += [nn.Conv2d(cin, 64, 3, stride=1, padding=1), nn.BatchNorm2d(64), nn.ReLU(), nn.MaxPool2d(2, stride=2)]
+        self.features = nn.Sequential(*layers)
+        self.fc = nn.Sequential(nn.Linear(64 * (n_mels // 8), d), nn.ReLU(), nn.Dropout(p=p_drop), nn.Linear(d, d), nn.ReLU())
+        self.p_drop = p_drop
+        self.projection_head = nn.Sequential(nn.Linear(d, 2048), nn.BatchNorm1d(2048), nn.ReLU(inplace=True),
+                                             nn.Linear(2048, out_dim))
+        self.prototypes = nn.Module()
+        for i, k in enumerate(nmb_prototypes):
+            self.prototypes.add_module(f"prototypes{i}", nn.Linear(out_dim, k, bias=False))
+        self.n_heads = len(nmb_prototypes)
+
+    def encode(self, x, drop_mask=None):
+        x = self.features(x)                                        # (batch, ch, mel, time)
+        x = x.permute(0, 3, 2, 1)
+        B, T, D, C = x.shape
+        x = F.relu(self.fc[0](x.reshape(B, T, C * D)))
+        if drop_mask is not None:
+            x = x * drop_mask.to(x.dtype) / (1.0 - self.p_drop)
+        return F.relu(self.fc[3](x))
+
+    def forward(self, batch, masks=(None, None)):
+        z = _maxmean(self.encode(batch[0], masks[0]))
+        z_new = _maxmean(self.encode(batch[1], masks[1]))
+        x = self.projection_head(z)
+        x_new = self.projection_head(z_new)
+        return x, [getattr(self.prototypes, f"prototypes{i}")(x_new) for i in range(self.n_heads)]
+
+
+def decar_v2_loss(scores, targets):
+    """`extras/decar-v2/main.py:205, 226-233`: mean over heads of CrossEntropy(ignore_index=-100)(scores / 1.0, target)."""
+    loss = 0
+    for h, sc in enumerate(scores):
+        loss = loss + F.cross_entropy(sc / 1.0, targets[h], ignore_index=-100)
+    return loss / len(scores)
+
+
 # ---------------------------------------------------------------- optimisers
 @torch.no_grad()
 def sgd_momentum_step(params, bufs, lr, momentum, weight_decay):

@@ -446,6 +446,45 @@ def g11_slicer(CL, ENC):
          wk_inst=t2n(sd["encoder_k.instance_projector.weight"]).ravel()[:256])
 
 
+def g12_decar(ENC):
+    """DeepCluster-v2 model + loss (`extras/decar-v2/models_delores.py:79-122`, `main.py:205-233`): one forward/backward,
+    B=8.  The module imports `utils` from its own directory, which imports tensorflow and librosa at module level -
+    both absent here and unused by the classes exercised - so empty stand-in modules are registered for the import."""
+    sys.modules.setdefault("tensorflow", types.ModuleType("tensorflow"))
+    d = os.path.join(REF, "extras/decar-v2")
+    sys.path.insert(0, d)
+    saved_utils = sys.modules.pop("utils", None)
+    try:
+        MD = _load_by_path("ref_decar_models", os.path.join(d, "models_delores.py"))
+    finally:
+        sys.path.remove(d)
+        sys.modules.pop("utils", None)
+        if saved_utils is not None:
+            sys.modules["utils"] = saved_utils
+    args = types.SimpleNamespace(nmb_prototypes=[1024], crops_for_assign=[0])
+    B, T, Tp = 8, 101, 12
+    torch.manual_seed(0)
+    m = MD.AudioNTT2020(args, 512, n_mels=64, d=2048, nmb_prototypes=[1024])
+    fill.fill_state_dict_(m, seed=6)
+    fmd = FixedMaskDropout(0.3)
+    m.fc[2] = fmd
+    m.train()
+    fmd.masks = [drop_mask((B, Tp, 2048), 8500), drop_mask((B, Tp, 2048), 8501)]
+    emb, output = m([views(B, T, 8400), views(B, T, 8401)])
+    targets = torch.tensor([(37 * i + 5) % 1024 for i in range(B)])
+    targets[3] = -100                                            # an unseen clip (ignore_index)
+    ce = nn.CrossEntropyLoss(ignore_index=-100)
+    loss = ce(output[0] / 1.0, targets)
+    loss.backward()
+    gd = grad_digest(m)
+    sd = m.state_dict()
+    save("decar_v2_model", loss=float(loss), emb_head=t2n(emb[:, :16]), emb_norm=float(emb.norm()),
+         scores_head=t2n(output[0][:, :16]), scores_norm=float(output[0].norm()), targets=t2n(targets),
+         g_names=gd["names"], g_norms=gd["norms"], g_heads=gd["heads"],
+         bn_rm=t2n(sd["projection_head.1.running_mean"])[:64], bn_rv=t2n(sd["projection_head.1.running_var"])[:64],
+         state_keys=np.array(list(sd.keys())))
+
+
 def main():
     _install_shims()
     sys.path.insert(0, REF)
@@ -462,6 +501,9 @@ def main():
     if len(sys.argv) > 1 and sys.argv[1] == "slicer":          # regenerate one fixture without touching the others
         g11_slicer(CL, ENC)
         return
+    if len(sys.argv) > 1 and sys.argv[1] == "decar":
+        g12_decar(ENC)
+        return
     g1_window(U)
     g2_runnorm(A)
     g3_aug(A_pkg)
@@ -473,6 +515,7 @@ def main():
     g10_lars(MP)
     g7_g9_steps(XS, XM, ENC)
     g11_slicer(CL, ENC)
+    g12_decar(ENC)
 
 
 if __name__ == "__main__":

@@ -103,3 +103,85 @@ def test_prototype_cross_entropy():
     loss.backward()
     assert abs(float(loss) - float(want)) < 1e-5
     assert rel_l2(x.grad.cpu(), logits.grad) < 1e-5
+
+
+# ------------------------------------------------------------------------------------------------ DeepCluster-v2 model
+def _decar_model(prec):
+    import types
+    from src import _native as N
+    from src.upstream.decar_v2.model import AudioNTT2020
+    args = types.SimpleNamespace(nmb_prototypes=[1024], crops_for_assign=[0])
+    m = AudioNTT2020(args, 512, n_mels=64, d=2048, nmb_prototypes=[1024])
+    m.precision = {"fp32": N.F32, "bf16": N.BF16}[prec]
+    return m
+
+
+@pytest.mark.parametrize("prec", ["fp32", "bf16"])
+def test_decar_v2_model_vs_reference_golden(golden, prec):
+    """`extras/decar-v2/models_delores.py` AudioNTT2020 + prototype CE: state_dict keys, embedding, scores, loss, every
+    gradient norm and the BatchNorm1d running buffers against numbers produced by the reference classes."""
+    from helpers import drop_mask, grad_digest, views
+    from src.upstream.decar_v2.kmeans import prototype_cross_entropy
+    g = golden("decar_v2_model")
+    m = _decar_model(prec)
+    assert list(m.state_dict().keys()) == [str(k) for k in g["state_keys"]]
+    fill.fill_state_dict_(m, seed=6)
+    m = m.cuda().train()
+    B, T, Tp = 8, 101, 12
+    m.dropout_masks.queue = [drop_mask((B, Tp, 2048), 8500), drop_mask((B, Tp, 2048), 8501)]
+    emb, out = m([views(B, T, 8400).cuda(), views(B, T, 8401).cuda()])
+    targets = torch.from_numpy(g["targets"]).cuda()
+    loss = prototype_cross_entropy(out[0], targets)
+    loss.backward()
+    tol = {"fp32": 2e-4, "bf16": 2e-2}[prec]
+    assert abs(float(loss) - float(g["loss"])) <= tol * float(g["loss"])
+    assert rel_l2(emb[:, :16].float().cpu(), g["emb_head"]) < tol * 2
+    assert rel_l2(out[0][:, :16].float().cpu(), g["scores_head"]) < tol * 2
+    names, norms, _ = grad_digest(m)
+    assert names == [str(n) for n in g["g_names"]]
+    gt = {"fp32": 2e-3, "bf16": 1e-1}[prec]
+    for n, got, want in zip(names, norms, g["g_norms"]):
+        if n in ("features.0.bias", "features.4.bias", "features.8.bias", "projection_head.0.bias"):
+            continue                  # a bias in front of a BatchNorm cancels: its exact gradient is 0, both sides hold noise
+        assert abs(got - want) <= gt * want + 1e-6 * float(np.max(g["g_norms"])), (n, got, want)
+    sd = m.state_dict()
+    assert rel_l2(sd["projection_head.1.running_mean"][:64].cpu(), g["bn_rm"]) < tol * 2
+    assert rel_l2(sd["projection_head.1.running_var"][:64].cpu(), g["bn_rv"]) < tol * 2
+
+
+def test_decar_v2_epoch_end_to_end():
+    """init_memory -> distributed k-means (world 1) -> two training steps: assignments cover every clip, prototypes equal
+    the centroids and stay frozen, encoder weights move, memory bank rows are overwritten by the new embeddings."""
+    from helpers import views
+    from src.optim import HipSGD
+    from src.upstream.decar_v2.train import DeepClusterState, cluster_epoch, init_memory, train_step
+    m = _decar_model("bf16")
+    fill.fill_state_dict_(m, seed=7)
+    m = m.cuda().train()
+    n_clips, B, T, K = 64, 16, 96, 1024
+    st = DeepClusterState(m, HipSGD, 512, n_clips, lr=0.005, momentum=0.9, weight_decay=1e-6)
+    data = [(torch.arange(i * B, (i + 1) * B), [views(B, T, 9500 + i), views(B, T, 9600 + i)]) for i in range(n_clips // B)]
+    init_memory(st, data)
+    assert float(st.local_memory_embeddings.abs().sum()) > 0 and st.local_memory_index.tolist() == list(range(n_clips))
+    # the reference L2-normalises nothing before k-means either; K must not exceed the bank: use a small K on this toy bank
+    torch.manual_seed(3)
+    with pytest.raises(AssertionError):
+        cluster_epoch(st, n_clips, (K,))                                         # 1024 centroids from 64 clips: refused
+    m.prototypes.prototypes0 = torch.nn.Linear(512, 32, bias=False).cuda()
+    st = DeepClusterState(m, HipSGD, 512, n_clips, lr=0.005, momentum=0.9, weight_decay=1e-6)
+    init_memory(st, data)
+    assign = cluster_epoch(st, n_clips, (32,))
+    assert assign.shape == (1, n_clips) and int(assign.min()) >= 0 and int(assign.max()) < 32
+    w0 = m.prototypes.prototypes0.weight.detach().clone()
+    np.testing.assert_allclose(w0.norm(dim=1).cpu().numpy(), 1.0, rtol=1e-4)     # centroids are L2-normalised
+    enc0 = m.fc[3].weight.detach().clone()
+    mem0 = st.local_memory_embeddings.clone()
+    start, losses = 0, []
+    for idx, inputs in data[:2]:
+        loss, start = train_step(st, idx, [x.cuda() for x in inputs], assign, start)
+        losses.append(float(loss))
+    assert all(np.isfinite(losses)) and start == 2 * B
+    assert torch.equal(m.prototypes.prototypes0.weight.detach(), w0)             # frozen prototypes
+    assert not torch.equal(m.fc[3].weight.detach(), enc0)
+    assert not torch.equal(st.local_memory_embeddings[0, :2 * B], mem0[0, :2 * B])
+    assert torch.equal(st.local_memory_embeddings[0, 2 * B:], mem0[0, 2 * B:])

@@ -300,3 +300,27 @@ def test_slicer_two_steps(golden, cfg_s):
     np.testing.assert_allclose(sd["encoder_q.encoder.features_1.0.weight"].numpy().ravel(), g["wq_conv1"], rtol=1e-4, atol=1e-6)
     np.testing.assert_allclose(sd["encoder_q.cluster_projector.2.weight"].numpy().ravel()[:256], g["wq_cluster"], rtol=1e-4, atol=1e-6)
     np.testing.assert_allclose(sd["encoder_k.instance_projector.weight"].numpy().ravel()[:256], g["wk_inst"], rtol=1e-5, atol=1e-7)
+
+
+def test_decar_v2_model_and_loss(golden):
+    """DeepCluster-v2 model forward (both views), prototype scores, CE with ignore_index, all gradients."""
+    g = golden("decar_v2_model")
+    m = OM.DecarV2Model(512, n_mels=64, d=2048, nmb_prototypes=(1024,))
+    assert list(m.state_dict().keys()) == [str(k) for k in g["state_keys"]]
+    fill.fill_state_dict_(m, seed=6)
+    m.train()
+    B, T, Tp = 8, 101, 12
+    emb, scores = m([views(B, T, 8400), views(B, T, 8401)], (drop_mask((B, Tp, 2048), 8500), drop_mask((B, Tp, 2048), 8501)))
+    targets = torch.from_numpy(g["targets"])
+    assert int(targets[3]) == -100
+    loss = OM.decar_v2_loss(scores, [targets])
+    loss.backward()
+    assert abs(float(loss) - float(g["loss"])) < 2e-5 * float(g["loss"])
+    np.testing.assert_allclose(emb[:, :16].detach().numpy(), g["emb_head"], rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(scores[0][:, :16].detach().numpy(), g["scores_head"], rtol=1e-4, atol=1e-5)
+    names, norms, _ = grad_digest(m)
+    assert names == [str(n) for n in g["g_names"]]
+    np.testing.assert_allclose(norms, g["g_norms"], rtol=5e-4, atol=1e-9)
+    sd = m.state_dict()
+    np.testing.assert_allclose(sd["projection_head.1.running_mean"][:64].numpy(), g["bn_rm"], rtol=1e-4, atol=1e-6)
+    np.testing.assert_allclose(sd["projection_head.1.running_var"][:64].numpy(), g["bn_rv"], rtol=1e-4, atol=1e-6)
