@@ -37,6 +37,8 @@ struct GemmArgs {
     int out_f32;              // C is float even when T is bf16
     int atomic;               // C (float) += via atomicAdd (split-K / multi-source accumulation)
     int ksplit;               // gridDim.z
+    const float* resid;       // fp32 [M][ldr] added to the result (out-of-place residual connection) or null
+    long ldr;
     unsigned a_bytes, b_bytes; // extents of A and B for the buffer descriptors (hardware bounds check)
 };
 
@@ -211,6 +213,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
                 if (g.relu) v = fmaxf(v, 0.f);
                 if (g.keep) v = g.keep[(long)row * g.ldk + col] ? v * g.keep_scale : 0.f;
                 if (gate) v = to_f32(gate[(long)row * g.ldg + col]) > 0.f ? v : 0.f;
+                if (g.resid) v += g.resid[(long)row * g.ldr + col];
                 const long o = (long)row * g.ldc + col;
                 if (g.atomic)       atomicAdd(static_cast<float*>(g.C) + o, v);
                 else if (g.out_f32) static_cast<float*>(g.C)[o] = v;
@@ -247,11 +250,13 @@ int dispatch(const GemmArgs& g, int ta, int tb, hipStream_t s) {
 extern "C" int audiossl_gemm(int dtype, int trans_a, int trans_b, int M, int N, int K, float alpha,
                              const void* A, long lda, const void* B, long ldb, void* C, long ldc,
                              const float* bias, int relu, const uint8_t* keep, long ldk, float keep_scale,
-                             const void* gate, long ldg, int out_f32, int atomic, int ksplit, void* stream) {
+                             const void* gate, long ldg, int out_f32, int atomic, int ksplit, const float* resid, long ldr,
+                             void* stream) {
     ASSL_REQUIRE(A && B && C && M > 0 && N > 0 && K > 0 && ksplit >= 1);
     ASSL_REQUIRE(dtype == 0 || dtype == 1);
     ASSL_REQUIRE(!atomic || out_f32 || dtype == 0);
     ASSL_REQUIRE(ksplit == 1 || atomic);
+    ASSL_REQUIRE(!resid || (ksplit == 1 && !atomic));
     // vector (8-element) dimension of each operand must be a multiple of 8 and its rows 16-byte aligned
     ASSL_REQUIRE((trans_a ? M : K) % 8 == 0 && (trans_b ? N : K) % 8 == 0);
     if (!ASSL_ALIGNED16(A) || !ASSL_ALIGNED16(B) || lda % 8 || ldb % 8) return ASSL_EALIGN;
@@ -260,7 +265,7 @@ extern "C" int audiossl_gemm(int dtype, int trans_a, int trans_b, int M, int N, 
     const long b_ext = (trans_b ? ((long)(K - 1) * ldb + N) : ((long)(N - 1) * ldb + K)) * esz;
     ASSL_REQUIRE(a_ext < 0xFFFFFF00L && b_ext < 0xFFFFFF00L);            // 32-bit buffer offsets
     GemmArgs g{A, B, C, M, N, K, lda, ldb, ldc, alpha, bias, relu, keep, ldk, keep_scale, gate, ldg,
-               (dtype == 0) ? 1 : out_f32, atomic, ksplit, (unsigned)a_ext, (unsigned)b_ext};
+               (dtype == 0) ? 1 : out_f32, atomic, ksplit, resid, ldr, (unsigned)a_ext, (unsigned)b_ext};
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (dtype == 0) return dispatch<float, 32>(g, trans_a, trans_b, s);
     const long blocks = (long)ceil_div(M, BM) * ceil_div(N, BN) * ksplit;

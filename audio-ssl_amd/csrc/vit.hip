@@ -1,0 +1,238 @@
+// Transformer-block plumbing of the AST / MAST encoder on gfx950 (the GEMMs are gemm.hip, attention is attention.hip):
+//   layernorm_fwd / _bwd : nn.LayerNorm(768, eps=1e-6) of the pre-norm ViT block (`ast_work.py:70-81` builds timm's
+//                          VisionTransformer; its blocks are LN -> MHA -> +res, LN -> MLP(GELU) -> +res)
+//   gelu_fwd / _bwd      : exact (erf) GELU of the MLP
+//   patch_unfold         : 16x16 patches with stride (fstride, tstride) of `ASTModel`'s patch embedding Conv2d
+//                          (`ast_work.py:101`), written as GEMM rows
+//   adamw                : torch.optim.AdamW of `Moco_v2.configure_optimizers` (`moco_model.py:373-379`), one launch over
+//                          the flat parameter buffer, step count read from device memory (graph replay advances it)
+// The residual stream is fp32; LayerNorm writes the bf16 MFMA operand; every gradient entering a LayerNorm backward is fp32.
+#include "common.h"
+
+namespace {
+
+constexpr int LN_MAX = 16;       // columns per lane: C <= 1024
+
+// one wave per row
+__global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                            const float* __restrict__ beta, bf16* __restrict__ y,
+                                                            float* __restrict__ mean, float* __restrict__ rstd, int M, int C,
+                                                            float eps) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= M) return;
+    const float* xr = x + (long)row * C;
+    const int n = C / 64;
+    float v[LN_MAX];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < LN_MAX; ++i)
+        if (i < n) { v[i] = xr[lane + 64 * i]; s += v[i]; }
+    const float mu = wave_sum(s) / (float)C;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < LN_MAX; ++i)
+        if (i < n) { const float d = v[i] - mu; q += d * d; }
+    const float rs = rsqrtf(wave_sum(q) / (float)C + eps);
+#pragma unroll
+    for (int i = 0; i < LN_MAX; ++i)
+        if (i < n) {
+            const int c = lane + 64 * i;
+            y[(long)row * C + c] = (bf16)((v[i] - mu) * rs * gamma[c] + beta[c]);
+        }
+    if (lane == 0) { mean[row] = mu; rstd[row] = rs; }
+}
+
+// dres[row] += dx,  dx = rstd * (g - mean_c(g) - xhat * mean_c(g * xhat)),  g = dy * gamma
+// dgamma += sum_rows dy * xhat, dbeta += sum_rows dy   (per-workgroup partials in LDS, then one atomic per column)
+constexpr int LN_ROWS = 64;      // rows per workgroup (16 per wave)
+__global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                            const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                            const float* __restrict__ gamma, float* __restrict__ dres,
+                                                            float* __restrict__ dgamma, float* __restrict__ dbeta, int M, int C) {
+    __shared__ float sg[1024], sb[1024];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int n = C / 64;
+    for (int c = threadIdx.x; c < C; c += 256) { sg[c] = 0.f; sb[c] = 0.f; }
+    __syncthreads();
+    float pg[LN_MAX], pb[LN_MAX], gm[LN_MAX];
+#pragma unroll
+    for (int i = 0; i < LN_MAX; ++i) { pg[i] = 0.f; pb[i] = 0.f; gm[i] = i < n ? gamma[lane + 64 * i] : 0.f; }
+    for (int k = 0; k < LN_ROWS / 4; ++k) {
+        const int row = blockIdx.x * LN_ROWS + wave * (LN_ROWS / 4) + k;
+        if (row >= M) break;
+        const float mu = mean[row], rs = rstd[row];
+        float g[LN_MAX], xh[LN_MAX];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < LN_MAX; ++i)
+            if (i < n) {
+                const long o = (long)row * C + lane + 64 * i;
+                const float d = dy[o];
+                xh[i] = (x[o] - mu) * rs;
+                g[i] = d * gm[i];
+                s1 += g[i];
+                s2 += g[i] * xh[i];
+                pg[i] += d * xh[i];
+                pb[i] += d;
+            }
+        s1 = wave_sum(s1) / (float)C;
+        s2 = wave_sum(s2) / (float)C;
+#pragma unroll
+        for (int i = 0; i < LN_MAX; ++i)
+            if (i < n) {
+                const long o = (long)row * C + lane + 64 * i;
+                dres[o] += rs * (g[i] - s1 - xh[i] * s2);
+            }
+    }
+#pragma unroll
+    for (int i = 0; i < LN_MAX; ++i)
+        if (i < n) { atomicAdd(&sg[lane + 64 * i], pg[i]); atomicAdd(&sb[lane + 64 * i], pb[i]); }
+    __syncthreads();
+    for (int c = threadIdx.x; c < C; c += 256) { atomicAdd(dgamma + c, sg[c]); atomicAdd(dbeta + c, sb[c]); }
+}
+
+__device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752f)); }
+__device__ __forceinline__ float gelu_d(float x) {
+    return 0.5f * (1.f + erff(x * 0.70710678118654752f)) + x * 0.3989422804014327f * __expf(-0.5f * x * x);
+}
+
+__global__ __launch_bounds__(256) void gelu_fwd_kernel(const bf16* __restrict__ a, bf16* __restrict__ h, long n8) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n8) return;
+    const Vec8<bf16> v = Vec8<bf16>::load(a + i * 8);
+    Vec8<bf16> o;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) o.set(k, gelu_f(v.get(k)));
+    o.store(h + i * 8);
+}
+
+__global__ __launch_bounds__(256) void gelu_bwd_kernel(const bf16* __restrict__ a, const bf16* __restrict__ dh, bf16* __restrict__ da,
+                                                       long n8) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n8) return;
+    const Vec8<bf16> v = Vec8<bf16>::load(a + i * 8), g = Vec8<bf16>::load(dh + i * 8);
+    Vec8<bf16> o;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) o.set(k, g.get(k) * gelu_d(v.get(k)));
+    o.store(da + i * 8);
+}
+
+// x [B][F][T] fp32 -> rows [B*nf*nt][256] bf16, row = (b, pf, pt) (the order of conv_out.flatten(2)), col = kh*16 + kw
+__global__ __launch_bounds__(256) void patch_unfold_kernel(const float* __restrict__ x, bf16* __restrict__ out, int B, int F, int T,
+                                                           int nf, int nt, int fs, int ts) {
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;          // over rows * 32 (8 columns each)
+    const long rows = (long)B * nf * nt;
+    if (idx >= rows * 32) return;
+    const int c8 = (int)(idx & 31);
+    const long row = idx >> 5;
+    const int pt = (int)(row % nt), pf = (int)((row / nt) % nf), b = (int)(row / ((long)nt * nf));
+    const int kh = c8 >> 1, kw = (c8 & 1) * 8;
+    const float* src = x + ((long)b * F + pf * fs + kh) * T + pt * ts + kw;
+    Vec8<bf16> o;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) o.set(k, src[k]);
+    o.store(out + row * 256 + c8 * 8);
+}
+
+// out[r][c] = src[r % period][c]: the learned position embedding tiled over the batch (start value of the residual stream)
+__global__ __launch_bounds__(256) void tile_rows_kernel(const float* __restrict__ src, float* __restrict__ out, long rows, int period,
+                                                        int C4) {
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= rows * C4) return;
+    const long r = idx / C4;
+    const int c = (int)(idx % C4);
+    reinterpret_cast<f32x4*>(out)[idx] = reinterpret_cast<const f32x4*>(src)[(r % period) * C4 + c];
+}
+
+__global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                    float* __restrict__ v, long n, float lr, float b1, float b2, float eps, float wd,
+                                                    float gscale, const long long* __restrict__ step) {
+    const float t = (float)step[0];
+    const float bc1 = 1.f - powf(b1, t), bc2s = sqrtf(1.f - powf(b2, t));
+    const float step_size = lr / bc1;
+    for (long i = ((long)blockIdx.x * 256 + threadIdx.x) * 4; i < n; i += (long)gridDim.x * 1024) {
+        if (i + 4 <= n) {
+            f32x4 pv = *reinterpret_cast<f32x4*>(p + i), mv = *reinterpret_cast<f32x4*>(m + i), vv = *reinterpret_cast<f32x4*>(v + i);
+            const f32x4 gv = *reinterpret_cast<const f32x4*>(g + i);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float gg = gv[k] * gscale;
+                pv[k] *= 1.f - lr * wd;
+                mv[k] = b1 * mv[k] + (1.f - b1) * gg;
+                vv[k] = b2 * vv[k] + (1.f - b2) * gg * gg;
+                pv[k] -= step_size * mv[k] / (sqrtf(vv[k]) / bc2s + eps);
+            }
+            *reinterpret_cast<f32x4*>(p + i) = pv;
+            *reinterpret_cast<f32x4*>(m + i) = mv;
+            *reinterpret_cast<f32x4*>(v + i) = vv;
+        } else {
+            for (long j = i; j < n; ++j) {
+                const float gg = g[j] * gscale;
+                float pj = p[j] * (1.f - lr * wd);
+                m[j] = b1 * m[j] + (1.f - b1) * gg;
+                v[j] = b2 * v[j] + (1.f - b2) * gg * gg;
+                p[j] = pj - step_size * m[j] / (sqrtf(v[j]) / bc2s + eps);
+            }
+        }
+    }
+}
+
+}  // namespace
+
+#define S_(stream) static_cast<hipStream_t>(stream)
+
+extern "C" int audiossl_layernorm_fwd(const float* x, const float* gamma, const float* beta, void* y, float* mean, float* rstd, int M,
+                                      int C, float eps, void* stream) {
+    ASSL_REQUIRE(x && gamma && beta && y && mean && rstd && M > 0 && C > 0 && (C % 64) == 0 && C <= 64 * LN_MAX);
+    hipLaunchKernelGGL(layernorm_fwd_kernel, dim3(ceil_div(M, 4)), dim3(256), 0, S_(stream), x, gamma, beta, static_cast<bf16*>(y),
+                       mean, rstd, M, C, eps);
+    ASSL_LAUNCH_CHECK();
+}
+
+extern "C" int audiossl_layernorm_bwd(const float* dy, const float* x, const float* mean, const float* rstd, const float* gamma,
+                                      float* dres, float* dgamma, float* dbeta, int M, int C, void* stream) {
+    ASSL_REQUIRE(dy && x && mean && rstd && gamma && dres && dgamma && dbeta && M > 0 && (C % 64) == 0 && C <= 64 * LN_MAX);
+    hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(ceil_div(M, LN_ROWS)), dim3(256), 0, S_(stream), dy, x, mean, rstd, gamma, dres,
+                       dgamma, dbeta, M, C);
+    ASSL_LAUNCH_CHECK();
+}
+
+extern "C" int audiossl_gelu_fwd(const void* a, void* h, long n, void* stream) {
+    ASSL_REQUIRE(a && h && n > 0 && (n % 8) == 0);
+    hipLaunchKernelGGL(gelu_fwd_kernel, dim3(ceil_div(n / 8, 256)), dim3(256), 0, S_(stream), static_cast<const bf16*>(a),
+                       static_cast<bf16*>(h), n / 8);
+    ASSL_LAUNCH_CHECK();
+}
+
+extern "C" int audiossl_gelu_bwd(const void* a, const void* dh, void* da, long n, void* stream) {
+    ASSL_REQUIRE(a && dh && da && n > 0 && (n % 8) == 0);
+    hipLaunchKernelGGL(gelu_bwd_kernel, dim3(ceil_div(n / 8, 256)), dim3(256), 0, S_(stream), static_cast<const bf16*>(a),
+                       static_cast<const bf16*>(dh), static_cast<bf16*>(da), n / 8);
+    ASSL_LAUNCH_CHECK();
+}
+
+extern "C" int audiossl_patch_unfold(const float* x, void* out, int B, int F, int T, int fstride, int tstride, void* stream) {
+    ASSL_REQUIRE(x && out && B > 0 && F >= 16 && T >= 16 && fstride > 0 && tstride > 0);
+    const int nf = (F - 16) / fstride + 1, nt = (T - 16) / tstride + 1;
+    const long total = (long)B * nf * nt * 32;
+    hipLaunchKernelGGL(patch_unfold_kernel, dim3(ceil_div(total, 256)), dim3(256), 0, S_(stream), x, static_cast<bf16*>(out), B, F, T,
+                       nf, nt, fstride, tstride);
+    ASSL_LAUNCH_CHECK();
+}
+
+extern "C" int audiossl_tile_rows(const float* src, float* out, long rows, int period, int C, void* stream) {
+    ASSL_REQUIRE(src && out && rows > 0 && period > 0 && C > 0 && (C % 4) == 0);
+    if (!ASSL_ALIGNED16(src) || !ASSL_ALIGNED16(out)) return ASSL_EALIGN;
+    hipLaunchKernelGGL(tile_rows_kernel, dim3(ceil_div(rows * (C / 4), 256)), dim3(256), 0, S_(stream), src, out, rows, period, C / 4);
+    ASSL_LAUNCH_CHECK();
+}
+
+extern "C" int audiossl_adamw(float* p, const float* g, float* m, float* v, long n, float lr, float beta1, float beta2, float eps,
+                              float weight_decay, float grad_scale, const long long* step, void* stream) {
+    ASSL_REQUIRE(p && g && m && v && step && n > 0);
+    if (!ASSL_ALIGNED16(p) || !ASSL_ALIGNED16(g) || !ASSL_ALIGNED16(m) || !ASSL_ALIGNED16(v)) return ASSL_EALIGN;
+    const int grid = (int)min((long)2048, (n + 1023) / 1024);
+    hipLaunchKernelGGL(adamw_kernel, dim3(grid), dim3(256), 0, S_(stream), p, g, m, v, n, lr, beta1, beta2, eps, weight_decay,
+                       grad_scale, step);
+    ASSL_LAUNCH_CHECK();
+}

@@ -57,9 +57,9 @@ def _ksplit(M, Nn, K, target=512):
 
 
 def gemm(dtype, ta, tb, M, Nn, K, A, lda, B, ldb, C, ldc, alpha=1.0, bias=None, relu=0, keep=None, ldk=0, keep_scale=1.0,
-         gate=None, ldg=0, out_f32=0, atomic=0, ksplit=1):
+         gate=None, ldg=0, out_f32=0, atomic=0, ksplit=1, resid=None, ldr=0):
     N.call("gemm", dtype, ta, tb, M, Nn, K, float(alpha), A, lda, B, ldb, C, ldc, bias, relu, keep, ldk, float(keep_scale),
-           gate, ldg, out_f32, atomic, ksplit)
+           gate, ldg, out_f32, atomic, ksplit, resid, ldr)
 
 
 def linear_fwd(dtype, X, W, M, Nout, K, bias=None, relu=0, keep=None, keep_scale=1.0, out=None, out_f32=0):

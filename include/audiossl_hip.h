@@ -127,10 +127,12 @@ int audiossl_conv3x3_wgrad(const void* dY, const void* X, float* dWp, int N, int
  *   trans_a = 0: A is [M][K] (lda)   trans_a = 1: A is [K][M] (lda)
  *   trans_b = 0: B is [N][K] (ldb)   trans_b = 1: B is [K][N] (ldb)     (torch Linear weights are [N][K])
  * Epilogue, in order: + bias[N]; ReLU; * keep[M][ldk] * keep_scale (dropout); zero where gate[M][ldg] <= 0;
+ * + resid[M][ldr] (fp32, out-of-place residual connection of the transformer blocks; ksplit 1, not atomic);
  * store as dtype, or fp32 (out_f32), or fp32 atomicAdd (atomic; required when ksplit > 1). */
 int audiossl_gemm(int dtype, int trans_a, int trans_b, int M, int N, int K, float alpha, const void* A, long lda,
                   const void* B, long ldb, void* C, long ldc, const float* bias, int relu, const uint8_t* keep, long ldk,
-                  float keep_scale, const void* gate, long ldg, int out_f32, int atomic, int ksplit, void* stream);
+                  float keep_scale, const void* gate, long ldg, int out_f32, int atomic, int ksplit, const float* resid,
+                  long ldr, void* stream);
 
 /* ---- encoder tail: delores_s/upstream_encoder.py:26-28 ---------------------------------------------------- */
 int audiossl_maxmean_fwd(int dtype, int out_f32, const void* H, void* y, uint8_t* arg, int N, int Tt, int D, void* stream);
@@ -203,6 +205,31 @@ int audiossl_ce_rows(int dtype, const float* logits, const long long* target, in
  * fp32 [M][C]; bwd: gx = y * (gy - sum_c gy*y). */
 int audiossl_softmax_rows_fwd(const float* x, float* y, int M, int C, void* stream);
 int audiossl_softmax_rows_bwd(const float* y, const float* gy, float* gx, int M, int C, void* stream);
+
+/* ---- K18 AST / MAST transformer encoder (BASELINE config 4, "AST-base 12x768"): the ViT timm builds for ASTModel,
+ * extras/mast_new/mast/models/ast_work.py:70-81, 101, 183-230; optimiser extras/mast_new/mast/moco_model.py:373-379 ----
+ * attn_fwd: qkv bf16 [B*S][3*H*64] (q | k | v column blocks, head h at columns h*64) -> out bf16 [B*S][H*64] =
+ *           softmax(scale * q k^T) v per (clip, head), lse fp32 [B*H][S] kept for the backward.  S <= 128.
+ * attn_bwd: dout bf16 [B*S][H*64] -> dqkv bf16 [B*S][3*H*64].
+ * layernorm_fwd: x fp32 [M][C] -> y bf16, mean / rstd fp32 [M] (C % 64 == 0, C <= 1024).
+ * layernorm_bwd: dres fp32 [M][C] += dx (the residual-stream gradient accumulates in place); dgamma, dbeta += .
+ * gelu_fwd / gelu_bwd: exact GELU on bf16, da = dh * gelu'(a).
+ * patch_unfold: x fp32 [B][F][T] -> bf16 [B*nf*nt][256], 16x16 patches, strides (fstride, tstride), row = (b, pf, pt).
+ * tile_rows: out[r] = src[r % period] (position embedding tiled over the batch).
+ * adamw: torch.optim.AdamW on a flat buffer; `step` = device int64 holding the 1-based step count. */
+int audiossl_attn_fwd(const void* qkv, void* out, float* lse, int B, int S, int H, float scale, void* stream);
+int audiossl_attn_bwd(const void* qkv, const void* dout, const float* lse, void* dqkv, int B, int S, int H, float scale,
+                      void* stream);
+int audiossl_layernorm_fwd(const float* x, const float* gamma, const float* beta, void* y, float* mean, float* rstd, int M,
+                           int C, float eps, void* stream);
+int audiossl_layernorm_bwd(const float* dy, const float* x, const float* mean, const float* rstd, const float* gamma,
+                           float* dres, float* dgamma, float* dbeta, int M, int C, void* stream);
+int audiossl_gelu_fwd(const void* a, void* h, long n, void* stream);
+int audiossl_gelu_bwd(const void* a, const void* dh, void* da, long n, void* stream);
+int audiossl_patch_unfold(const float* x, void* out, int B, int F, int T, int fstride, int tstride, void* stream);
+int audiossl_tile_rows(const float* src, float* out, long rows, int period, int C, void* stream);
+int audiossl_adamw(float* p, const float* g, float* m, float* v, long n, float lr, float beta1, float beta2, float eps,
+                   float weight_decay, float grad_scale, const long long* step, void* stream);
 
 /* ---- LARS: extras/delores-s/multi_proc.py:4-43, on the flat parameter buffer ---------------------------------------
  * seg: n_seg x {int64 offset, int64 numel, int32 flags (bit0 weight decay, bit1 trust ratio), int32 pad} (device);

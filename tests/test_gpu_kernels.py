@@ -48,14 +48,14 @@ def test_gemm_modes(N, dtype, mode, shape):
     ref = (Aq.T if ta else Aq).double() @ (Bq if tb else Bq.T).double()
     C = torch.full((M, Nn), float("nan"), device="cuda", dtype=torch.float32)
     N.call("gemm", dtype, ta, tb, M, Nn, K, 1.0, Ad, Ad.shape[1], Bd, Bd.shape[1], C, Nn, None, 0, None, 0, 1.0,
-           None, 0, 1, 0, 1)
+           None, 0, 1, 0, 1, None, 0)
     torch.cuda.synchronize()
     assert torch.isfinite(C).all()
     assert rel_l2(C.cpu(), ref) < 1e-5                         # fp32 accumulate of exactly-represented operands
     # split-K + atomic accumulation on top of a non-zero C
     C2 = torch.ones(M, Nn, device="cuda", dtype=torch.float32)
     N.call("gemm", dtype, ta, tb, M, Nn, K, 0.5, Ad, Ad.shape[1], Bd, Bd.shape[1], C2, Nn, None, 0, None, 0, 1.0,
-           None, 0, 1, 1, 3)
+           None, 0, 1, 1, 3, None, 0)
     torch.cuda.synchronize()
     assert rel_l2(C2.cpu(), 1.0 + 0.5 * ref) < 1e-5
 
@@ -70,7 +70,7 @@ def test_gemm_epilogue(N, dtype):
     keep = dev((fill.uniform01((M, Nn), 24) >= 0.3).astype(np.uint8))
     gate = dev(fill.uniform((M, Nn), 25)).to(td)
     out = torch.empty(M, Nn, device="cuda", dtype=td)
-    N.call("gemm", dtype, 0, 0, M, Nn, K, 1.0, A, K, W, K, out, Nn, bias, 1, keep, Nn, 1.0 / 0.7, gate, Nn, 0, 0, 1)
+    N.call("gemm", dtype, 0, 0, M, Nn, K, 1.0, A, K, W, K, out, Nn, bias, 1, keep, Nn, 1.0 / 0.7, gate, Nn, 0, 0, 1, None, 0)
     torch.cuda.synchronize()
     ref = torch.relu(A.float() @ W.float().T + bias) * keep.float() / 0.7 * (gate.float() > 0)
     assert rel_l2(out.float().cpu(), ref.cpu()) < (1e-5 if dtype == 0 else 4e-3)
@@ -79,11 +79,11 @@ def test_gemm_epilogue(N, dtype):
 def test_gemm_rejects_bad_arguments(N):
     a = torch.zeros(16, 16, device="cuda")
     with pytest.raises(RuntimeError, match="EINVAL"):
-        N.call("gemm", 0, 0, 0, 16, 16, 12, 1.0, a, 16, a, 16, a, 16, None, 0, None, 0, 1.0, None, 0, 1, 0, 1)   # K % 8
+        N.call("gemm", 0, 0, 0, 16, 16, 12, 1.0, a, 16, a, 16, a, 16, None, 0, None, 0, 1.0, None, 0, 1, 0, 1, None, 0)   # K % 8
     with pytest.raises(RuntimeError, match="EALIGN"):
-        N.call("gemm", 0, 0, 0, 16, 16, 8, 1.0, a, 12, a, 16, a, 16, None, 0, None, 0, 1.0, None, 0, 1, 0, 1)    # lda % 8
+        N.call("gemm", 0, 0, 0, 16, 16, 8, 1.0, a, 12, a, 16, a, 16, None, 0, None, 0, 1.0, None, 0, 1, 0, 1, None, 0)    # lda % 8
     with pytest.raises(RuntimeError, match="device tensors"):
-        N.call("gemm", 0, 0, 0, 16, 16, 16, 1.0, a.cpu(), 16, a, 16, a, 16, None, 0, None, 0, 1.0, None, 0, 1, 0, 1)
+        N.call("gemm", 0, 0, 0, 16, 16, 16, 1.0, a.cpu(), 16, a, 16, a, 16, None, 0, None, 0, 1.0, None, 0, 1, 0, 1, None, 0)
 
 
 # ------------------------------------------------------------------------------------------------ log-mel

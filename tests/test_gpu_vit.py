@@ -1,0 +1,123 @@
+"""GPU: the transformer kernels of the AST / MAST encoder (attention, LayerNorm, GELU, patch unfold, AdamW) through the C ABI
+against plain PyTorch fp32 references of the same ops on the same seeded inputs.  Tolerances are those of bf16 MFMA operands
+with fp32 accumulation: outputs rel-L2 <= 1e-2, gradients rel-L2 <= 2e-2."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import fill
+from helpers import rel_l2
+
+pytestmark = pytest.mark.gpu
+
+
+def _t(shape, salt, lo=-1.0, hi=1.0):
+    return torch.from_numpy(fill.uniform(shape, salt, lo, hi))
+
+
+@pytest.mark.parametrize("B,S,H", [(2, 108, 12), (3, 128, 2), (1, 37, 4), (2, 1, 1)])
+def test_attention_forward_backward(B, S, H):
+    from src import _native as N
+    C = H * 64
+    qkv = _t((B * S, 3 * C), 100 + S, -1.5, 1.5).cuda().bfloat16()
+    dout = _t((B * S, C), 200 + S).cuda().bfloat16()
+    out = torch.empty(B * S, C, dtype=torch.bfloat16, device="cuda")
+    lse = torch.empty(B * H, S, dtype=torch.float32, device="cuda")
+    dqkv = torch.full((B * S, 3 * C), float("nan"), dtype=torch.bfloat16, device="cuda")
+    scale = 1.0 / math.sqrt(64)
+    N.call("attn_fwd", qkv, out, lse, B, S, H, scale)
+    N.call("attn_bwd", qkv, dout, lse, dqkv, B, S, H, scale)
+    torch.cuda.synchronize()
+    x = qkv.float().cpu().requires_grad_(True)
+    q, k, v = (x[:, i * C:(i + 1) * C].view(B, S, H, 64).permute(0, 2, 1, 3) for i in range(3))
+    s = (q @ k.transpose(-1, -2)) * scale
+    ref = (torch.softmax(s, dim=-1) @ v).permute(0, 2, 1, 3).reshape(B * S, C)
+    ref.backward(dout.float().cpu())
+    assert rel_l2(out.float().cpu(), ref.detach()) < 1e-2
+    np.testing.assert_allclose(lse.cpu().numpy(), torch.logsumexp(s, dim=-1).reshape(B * H, S).detach().numpy(), rtol=2e-3, atol=2e-3)
+    for i, name in enumerate("qkv"):
+        assert rel_l2(dqkv[:, i * C:(i + 1) * C].float().cpu(), x.grad[:, i * C:(i + 1) * C]) < 2e-2, name
+
+
+def test_attention_rejects_long_sequences():
+    from src import _native as N
+    z = torch.zeros(8, dtype=torch.bfloat16, device="cuda")
+    with pytest.raises(RuntimeError, match="EINVAL"):
+        N.call("attn_fwd", z, z, torch.zeros(8, device="cuda"), 1, 129, 1, 0.125)
+
+
+@pytest.mark.parametrize("M,C", [(216, 768), (5, 64), (130, 1024)])
+def test_layernorm_forward_backward(M, C):
+    from src import _native as N
+    x = (_t((M, C), 300 + M, -2, 2) + 0.5).cuda()
+    g = _t((C,), 301, 0.5, 1.5).cuda()
+    b = _t((C,), 302, -0.2, 0.2).cuda()
+    dy = _t((M, C), 303).cuda()
+    y = torch.empty(M, C, dtype=torch.bfloat16, device="cuda")
+    mean, rstd = torch.empty(M, device="cuda"), torch.empty(M, device="cuda")
+    N.call("layernorm_fwd", x, g, b, y, mean, rstd, M, C, 1e-6)
+    base = _t((M, C), 304).cuda()                       # the residual-stream gradient the LN gradient is added to
+    dres = base.clone()
+    dg, db = torch.zeros(C, device="cuda"), torch.zeros(C, device="cuda")
+    N.call("layernorm_bwd", dy, x, mean, rstd, g, dres, dg, db, M, C)
+    torch.cuda.synchronize()
+    xr, gr, br = x.cpu().requires_grad_(True), g.cpu().requires_grad_(True), b.cpu().requires_grad_(True)
+    ref = torch.nn.functional.layer_norm(xr, (C,), gr, br, 1e-6)
+    ref.backward(dy.cpu())
+    assert rel_l2(y.float().cpu(), ref.detach()) < 5e-3                       # bf16 output rounding
+    np.testing.assert_allclose(mean.cpu().numpy(), xr.detach().mean(1).numpy(), rtol=1e-5, atol=1e-6)
+    assert rel_l2((dres - base).cpu(), xr.grad) < 1e-5
+    assert rel_l2(dg.cpu(), gr.grad) < 1e-5 and rel_l2(db.cpu(), br.grad) < 1e-5
+
+
+def test_gelu_forward_backward():
+    from src import _native as N
+    n = 8 * 1000
+    a = _t((n,), 400, -4, 4).cuda().bfloat16()
+    dh = _t((n,), 401).cuda().bfloat16()
+    h, da = torch.empty_like(a), torch.empty_like(a)
+    N.call("gelu_fwd", a, h, n)
+    N.call("gelu_bwd", a, dh, da, n)
+    torch.cuda.synchronize()
+    ar = a.float().cpu().requires_grad_(True)
+    ref = torch.nn.functional.gelu(ar)
+    ref.backward(dh.float().cpu())
+    assert rel_l2(h.float().cpu(), ref.detach()) < 5e-3
+    assert rel_l2(da.float().cpu(), ar.grad) < 5e-3
+
+
+@pytest.mark.parametrize("F,T,fs,ts", [(128, 101, 10, 10), (64, 96, 16, 16)])
+def test_patch_unfold_matches_conv2d(F, T, fs, ts):
+    from src import _native as N
+    B = 3
+    x = _t((B, 1, F, T), 500 + F).cuda()
+    nf, nt = (F - 16) // fs + 1, (T - 16) // ts + 1
+    rows = torch.empty(B * nf * nt, 256, dtype=torch.bfloat16, device="cuda")
+    N.call("patch_unfold", x, rows, B, F, T, fs, ts)
+    torch.cuda.synchronize()
+    w = _t((32, 1, 16, 16), 501)
+    ref = torch.nn.functional.conv2d(x.cpu().bfloat16().float(), w, stride=(fs, ts)).flatten(2).transpose(1, 2).reshape(B * nf * nt, 32)
+    got = rows.float().cpu() @ w.view(32, 256).T
+    assert (nf, nt) == ((12, 9) if F == 128 else (4, 6))
+    np.testing.assert_allclose(got.numpy(), ref.numpy(), rtol=1e-4, atol=1e-4)
+
+
+def test_adamw_matches_torch():
+    from src import _native as N
+    n = 4 * 1000 + 3
+    p0, grads = _t((n,), 600), [_t((n,), 601 + i, -0.1, 0.1) for i in range(3)]
+    ref_p = p0.clone().requires_grad_(True)
+    opt = torch.optim.AdamW([ref_p], lr=3e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.05)
+    pad = (-n) % 4
+    p = torch.nn.functional.pad(p0, (0, pad)).cuda()
+    m, v = torch.zeros_like(p), torch.zeros_like(p)
+    step = torch.zeros(1, dtype=torch.int64, device="cuda")
+    for g in grads:
+        ref_p.grad = g.clone()
+        opt.step()
+        step.add_(1)
+        N.call("adamw", p, torch.nn.functional.pad(g, (0, pad)).cuda(), m, v, n, 3e-4, 0.9, 0.999, 1e-8, 0.05, 1.0, step)
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(p[:n].cpu().numpy(), ref_p.detach().numpy(), rtol=2e-5, atol=1e-7)
