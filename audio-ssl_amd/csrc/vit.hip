@@ -134,14 +134,19 @@ __global__ __launch_bounds__(256) void patch_unfold_kernel(const float* __restri
     o.store(out + row * 256 + c8 * 8);
 }
 
-// out[r][c] = src[r % period][c]: the learned position embedding tiled over the batch (start value of the residual stream)
+// out[r][c] = scale * src[(r / group) % period][c]
+//   group 1, period N : the learned position embedding tiled over the batch (start value of the residual stream)
+//   group N, period B : backward of the mean over tokens (every token row gets dpooled / N)
 __global__ __launch_bounds__(256) void tile_rows_kernel(const float* __restrict__ src, float* __restrict__ out, long rows, int period,
-                                                        int C4) {
+                                                        int group, float scale, int C4) {
     const long idx = (long)blockIdx.x * 256 + threadIdx.x;
     if (idx >= rows * C4) return;
     const long r = idx / C4;
     const int c = (int)(idx % C4);
-    reinterpret_cast<f32x4*>(out)[idx] = reinterpret_cast<const f32x4*>(src)[(r % period) * C4 + c];
+    f32x4 v = reinterpret_cast<const f32x4*>(src)[((r / group) % period) * C4 + c];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) v[k] *= scale;
+    reinterpret_cast<f32x4*>(out)[idx] = v;
 }
 
 __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
@@ -220,10 +225,10 @@ extern "C" int audiossl_patch_unfold(const float* x, void* out, int B, int F, in
     ASSL_LAUNCH_CHECK();
 }
 
-extern "C" int audiossl_tile_rows(const float* src, float* out, long rows, int period, int C, void* stream) {
-    ASSL_REQUIRE(src && out && rows > 0 && period > 0 && C > 0 && (C % 4) == 0);
+extern "C" int audiossl_tile_rows(const float* src, float* out, long rows, int period, int group, float scale, int C, void* stream) {
+    ASSL_REQUIRE(src && out && rows > 0 && period > 0 && group > 0 && C > 0 && (C % 4) == 0);
     if (!ASSL_ALIGNED16(src) || !ASSL_ALIGNED16(out)) return ASSL_EALIGN;
-    hipLaunchKernelGGL(tile_rows_kernel, dim3(ceil_div(rows * (C / 4), 256)), dim3(256), 0, S_(stream), src, out, rows, period, C / 4);
+    hipLaunchKernelGGL(tile_rows_kernel, dim3(ceil_div(rows * (C / 4), 256)), dim3(256), 0, S_(stream), src, out, rows, period, group, scale, C / 4);
     ASSL_LAUNCH_CHECK();
 }
 

@@ -215,7 +215,8 @@ int audiossl_softmax_rows_bwd(const float* y, const float* gy, float* gx, int M,
  * layernorm_bwd: dres fp32 [M][C] += dx (the residual-stream gradient accumulates in place); dgamma, dbeta += .
  * gelu_fwd / gelu_bwd: exact GELU on bf16, da = dh * gelu'(a).
  * patch_unfold: x fp32 [B][F][T] -> bf16 [B*nf*nt][256], 16x16 patches, strides (fstride, tstride), row = (b, pf, pt).
- * tile_rows: out[r] = src[r % period] (position embedding tiled over the batch).
+ * tile_rows: out[r] = scale * src[(r / group) % period]: position embedding tiled over the batch (group 1, period N), and
+ *            the backward of the mean over tokens (group N, period B, scale 1/N).
  * adamw: torch.optim.AdamW on a flat buffer; `step` = device int64 holding the 1-based step count. */
 int audiossl_attn_fwd(const void* qkv, void* out, float* lse, int B, int S, int H, float scale, void* stream);
 int audiossl_attn_bwd(const void* qkv, const void* dout, const float* lse, void* dqkv, int B, int S, int H, float scale,
@@ -227,7 +228,7 @@ int audiossl_layernorm_bwd(const float* dy, const float* x, const float* mean, c
 int audiossl_gelu_fwd(const void* a, void* h, long n, void* stream);
 int audiossl_gelu_bwd(const void* a, const void* dh, void* da, long n, void* stream);
 int audiossl_patch_unfold(const float* x, void* out, int B, int F, int T, int fstride, int tstride, void* stream);
-int audiossl_tile_rows(const float* src, float* out, long rows, int period, int C, void* stream);
+int audiossl_tile_rows(const float* src, float* out, long rows, int period, int group, float scale, int C, void* stream);
 int audiossl_adamw(float* p, const float* g, float* m, float* v, long n, float lr, float beta1, float beta2, float eps,
                    float weight_decay, float grad_scale, const long long* step, void* stream);
 

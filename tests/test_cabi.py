@@ -25,10 +25,10 @@ def test_header_declares_and_library_exports_every_entry_point():
 def test_argument_validation_happens_before_any_launch():
     lib = N.lib()
     # null pointers / bad shapes -> AUDIOSSL_EINVAL (-1), misaligned leading dimension -> AUDIOSSL_EALIGN (-3)
-    assert lib.audiossl_gemm(1, 0, 0, 16, 16, 16, 1.0, None, 16, None, 16, None, 16, None, 0, None, 0, 1.0, None, 0, 0, 0, 1, None) == -1
-    assert lib.audiossl_gemm(1, 0, 0, 16, 16, 12, 1.0, 256, 16, 256, 16, 256, 16, None, 0, None, 0, 1.0, None, 0, 0, 0, 1, None) == -1
-    assert lib.audiossl_gemm(1, 0, 0, 16, 16, 16, 1.0, 256, 12, 256, 16, 256, 16, None, 0, None, 0, 1.0, None, 0, 0, 0, 1, None) == -3
-    assert lib.audiossl_gemm(1, 0, 0, 16, 16, 16, 1.0, 256, 16, 256, 16, 256, 16, None, 0, None, 0, 1.0, None, 0, 0, 0, 2, None) == -1  # split-K needs atomic
+    assert lib.audiossl_gemm(1, 0, 0, 16, 16, 16, 1.0, None, 16, None, 16, None, 16, None, 0, None, 0, 1.0, None, 0, 0, 0, 1, None, 0, None) == -1
+    assert lib.audiossl_gemm(1, 0, 0, 16, 16, 12, 1.0, 256, 16, 256, 16, 256, 16, None, 0, None, 0, 1.0, None, 0, 0, 0, 1, None, 0, None) == -1
+    assert lib.audiossl_gemm(1, 0, 0, 16, 16, 16, 1.0, 256, 12, 256, 16, 256, 16, None, 0, None, 0, 1.0, None, 0, 0, 0, 1, None, 0, None) == -3
+    assert lib.audiossl_gemm(1, 0, 0, 16, 16, 16, 1.0, 256, 16, 256, 16, 256, 16, None, 0, None, 0, 1.0, None, 0, 0, 0, 2, None, 0, None) == -1  # split-K needs atomic
     assert lib.audiossl_logmel_fwd(256, 256, 1, 16000, 101, 512, 160, 64, 45, 256, 256, 256, 256, 0.0, 0.0, 1, None) == -1   # n_fft != 1024
     assert lib.audiossl_logmel_fwd(256, 256, 1, 16000, 100, 1024, 160, 64, 45, 256, 256, 256, 256, 0.0, 0.0, 1, None) == -1  # T mismatch
     assert lib.audiossl_colstats(1, 256, 1, 10, 60, 64, 1, 256, 256, None) == -1        # C % 64

@@ -121,3 +121,40 @@ def test_adamw_matches_torch():
         N.call("adamw", p, torch.nn.functional.pad(g, (0, pad)).cuda(), m, v, n, 3e-4, 0.9, 0.999, 1e-8, 0.05, 1.0, step)
     torch.cuda.synchronize()
     np.testing.assert_allclose(p[:n].cpu().numpy(), ref_p.detach().numpy(), rtol=2e-5, atol=1e-7)
+
+
+# ------------------------------------------------------------------------------------------------ whole encoder
+@pytest.mark.parametrize("depth,B,F,T", [(2, 4, 128, 101), (12, 2, 128, 101), (2, 8, 64, 96)])
+def test_ast_encoder_forward_backward_vs_oracle(depth, B, F, T):
+    """ASTModel (HIP launch sequence) against the CPU restatement: embedding and EVERY parameter gradient."""
+    from oracle import vit as OV
+    from helpers import views
+    from src.encoder import ASTModel
+    kw = dict(label_dim=256, fstride=10, tstride=10, input_fdim=F, input_tdim=T, depth=depth)
+    ref = OV.ASTModel(**kw)
+    fill.fill_state_dict_(ref, seed=40 + depth)
+    with torch.no_grad():
+        ref.v.pos_embed.copy_(_t(tuple(ref.v.pos_embed.shape), 41, -0.05, 0.05))
+    m = ASTModel(**kw)
+    assert [k for k, _ in m.named_parameters()] == [k for k, _ in ref.named_parameters()]
+    m.load_state_dict(ref.state_dict())
+    m = m.cuda().train()
+    x = torch.cat([views(B, T, 700 + i)[:, :, :min(F, 64)] for i in range((F + 63) // 64)], dim=2)[:, :, :F].contiguous()
+    assert x.shape == (B, 1, F, T)
+    dout = _t((B, 256), 702, -1, 1)
+    out_ref = ref(x)
+    out_ref.backward(dout)
+    out = m(x.cuda())
+    out.backward(dout.cuda())
+    torch.cuda.synchronize()
+    assert rel_l2(out.detach().float().cpu(), out_ref.detach()) < 2e-2
+    worst = 0.0
+    for (n, p), (_, pr) in zip(m.named_parameters(), ref.named_parameters()):
+        e = rel_l2(p.grad.float().cpu(), pr.grad)
+        worst = max(worst, e)
+        assert e < 6e-2, (n, e)
+    assert worst > 0.0
+    # inference path (no autograd) gives the same embedding
+    with torch.no_grad():
+        out2 = m(x.cuda())
+    assert rel_l2(out2.float().cpu(), out.detach().float().cpu()) < 1e-6
