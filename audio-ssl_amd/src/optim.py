@@ -85,3 +85,36 @@ class HipLARS(torch.optim.Optimizer):
         for fg in self.flat_groups:
             for p in fg.params:
                 p.grad = None
+
+
+class HipAdamW(torch.optim.Optimizer):
+    """torch.optim.AdamW (`extras/mast_new/mast/moco_model.py:373-379`) as one launch per flat parameter group.  The step
+    count lives in device memory and is advanced by a device op, so the optimiser step can sit inside a captured hipGraph."""
+
+    def __init__(self, flat_groups, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2, grad_scale=1.0):
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
+        self.flat_groups = list(flat_groups)
+        self.grad_scale = grad_scale
+        self.grad_scale_tensor = None
+        self.step_count = None
+        self.steps = 0
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        g0 = self.param_groups[0]
+        for fg in self.flat_groups:
+            if getattr(fg, "exp_avg", None) is None:
+                fg.exp_avg = torch.zeros_like(fg.data)
+                fg.exp_avg_sq = torch.zeros_like(fg.data)
+            if self.step_count is None or self.step_count.device != fg.data.device:
+                self.step_count = torch.zeros(1, dtype=torch.int64, device=fg.data.device)
+        self.step_count.add_(1)
+        for fg in self.flat_groups:
+            N.call("adamw", fg.data, fg.grad, fg.exp_avg, fg.exp_avg_sq, fg.numel, float(g0["lr"]), float(g0["betas"][0]),
+                   float(g0["betas"][1]), float(g0["eps"]), float(g0["weight_decay"]), float(self.grad_scale), self.step_count)
+        self.steps += 1
+
+    def zero_grad(self, set_to_none=True):
+        for fg in self.flat_groups:
+            for p in fg.params:
+                p.grad = None

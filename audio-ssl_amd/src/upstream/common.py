@@ -194,7 +194,7 @@ class GraphedStep:
         if self.calls <= self.eager_steps:
             return self._eager(img_1, img_2)
         key = (tuple(img_1.shape), tuple(img_2.shape), img_1.dtype, img_2.dtype, self._hyper(), self.expert.training,
-               self.expert.flat.data.data_ptr())
+               self.expert.flat.data.data_ptr(), getattr(self.expert, "graph_key", tuple)())
         if self.use_phases:
             # data parallel: one graph per collective-free phase, RCCL calls in between
             if self.phases is None or key != self.key:

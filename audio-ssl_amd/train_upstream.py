@@ -47,6 +47,7 @@ class HipTrainer:
         return self.world
 
     use_ddp = property(lambda self: self.world > 1)
+    current_epoch = property(lambda self: self.epoch)
     use_ddp2 = False
 
     def _init_dist(self):

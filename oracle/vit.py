@@ -63,3 +63,44 @@ class ASTModel(nn.Module):
         if self.final_norm:
             x = self.v.norm(x)
         return self.fc(x.mean(1))
+
+
+def adjust_moco_momentum(epoch, epochs=200, base=0.99):
+    """`extras/mast_new/mast/utils.py:55-57`"""
+    return 1. - 0.5 * (1. + math.cos(math.pi * epoch / epochs)) * (1. - base)
+
+
+class SSMastExpert(nn.Module):
+    """`Moco_v2` of `extras/mast_new/mast/moco_model.py:60-379`, single process: symmetric InfoNCE with a queue, the key
+    encoder updated by EMA (cosine momentum schedule, evaluated at epoch + 1) inside EACH of the two forward calls."""
+
+    def __init__(self, emb_dim=256, num_negatives=65536, softmax_temperature=0.07, **ast_kwargs):
+        super().__init__()
+        self.encoder_q = ASTModel(label_dim=emb_dim, **ast_kwargs)
+        self.encoder_k = ASTModel(label_dim=emb_dim, **ast_kwargs)
+        for pq, pk in zip(self.encoder_q.parameters(), self.encoder_k.parameters()):
+            pk.data.copy_(pq.data)
+            pk.requires_grad = False
+        self.register_buffer("queue", F.normalize(torch.randn(emb_dim, num_negatives), dim=0))
+        self.register_buffer("queue_ptr", torch.zeros(1, dtype=torch.long))
+        self.T, self.K = softmax_temperature, num_negatives
+
+    def one_direction(self, img_q, img_k, epoch):
+        q = F.normalize(self.encoder_q(img_q), dim=1)
+        with torch.no_grad():
+            em = adjust_moco_momentum(epoch + 1)
+            for pq, pk in zip(self.encoder_q.parameters(), self.encoder_k.parameters()):
+                pk.data = pk.data * em + pq.data * (1. - em)
+            k = F.normalize(self.encoder_k(img_k), dim=1)
+        l_pos = torch.einsum('nc,nc->n', [q, k]).unsqueeze(-1)
+        l_neg = torch.einsum('nc,ck->nk', [q, self.queue.clone().detach()])
+        logits = torch.cat([l_pos, l_neg], dim=1) / self.T
+        with torch.no_grad():
+            ptr, b = int(self.queue_ptr), k.shape[0]
+            assert self.K % b == 0
+            self.queue[:, ptr:ptr + b] = k.T
+            self.queue_ptr[0] = (ptr + b) % self.K
+        return F.cross_entropy(logits.float(), torch.zeros(logits.shape[0], dtype=torch.long))
+
+    def training_loss(self, img_1, img_2, epoch=0):
+        return self.one_direction(img_1, img_2, epoch) + self.one_direction(img_2, img_1, epoch)

@@ -158,3 +158,86 @@ def test_ast_encoder_forward_backward_vs_oracle(depth, B, F, T):
     with torch.no_grad():
         out2 = m(x.cuda())
     assert rel_l2(out2.float().cpu(), out.detach().float().cpu()) < 1e-6
+
+
+# ------------------------------------------------------------------------------------------------ SS-MAST expert
+MAST_CFG = {"run": {"batch_size": 8, "precision": "bf16"},
+            "pretrain": {"base_encoder": {"type": "MAST", "output_dim": 768, "depth": 2, "num_heads": 12, "fstride": 10, "tstride": 10,
+                                          "return_all_layers": False},
+                         "normalization": "mean_var",
+                         "input": {"type": "raw_wav", "sampling_rate": 16000, "length_wave": 1.0, "n_mels": 128}}}
+
+
+def _mel128(B, T, salt):
+    from helpers import views
+    return torch.cat([views(B, T, salt), views(B, T, salt + 5000)], dim=2).contiguous()          # [B, 1, 128, T]
+
+
+def test_ssmast_step_vs_oracle():
+    """Symmetric MoCo on the transformer: both cross-entropies, every gradient of the step, queue, EMA of the key encoder."""
+    import copy
+    from oracle import vit as OV
+    from helpers import closed_queue
+    from src.upstream.ssmast.upstream_expert import Upstream_Expert, adjust_moco_momentum
+    B, T, K = 8, 101, 64
+    ref = OV.SSMastExpert(emb_dim=256, num_negatives=K, input_fdim=128, input_tdim=T, depth=2)
+    fill.fill_state_dict_(ref, seed=50)
+    with torch.no_grad():
+        ref.encoder_q.v.pos_embed.copy_(_t(tuple(ref.encoder_q.v.pos_embed.shape), 51, -0.05, 0.05))
+        for pq, pk in zip(ref.encoder_q.parameters(), ref.encoder_k.parameters()):
+            pk.copy_(pq)
+        ref.queue.copy_(closed_queue(256, K))
+    ex = Upstream_Expert(copy.deepcopy(MAST_CFG), num_negatives=K)
+    ex.load_state_dict(ref.state_dict())
+    ex = ex.cuda().train()
+    a, b = _mel128(B, T, 9700), _mel128(B, T, 9701)
+    loss_ref = ref.training_loss(a, b, epoch=3)
+    loss_ref.backward()
+    ex.current_epoch = 3
+    opt = ex.configure_optimizers()
+    wk0 = ex.encoder_k.fc.weight.detach().clone()
+    opt.zero_grad()
+    loss = ex.training_step((a.cuda(), b.cuda()), 0)
+    loss.backward()
+    torch.cuda.synchronize()
+    assert abs(float(loss) - float(loss_ref)) < 2e-2 * float(loss_ref)
+    for (n, p), (_, pr) in zip(ex.encoder_q.named_parameters(), ref.encoder_q.named_parameters()):
+        assert rel_l2(p.grad.float().cpu(), pr.grad) < 8e-2, n
+    assert int(ex.queue_ptr[0]) == int(ref.queue_ptr[0]) == (2 * B) % K
+    assert rel_l2(ex.queue.cpu(), ref.queue) < 2e-2
+    # key encoder: two EMA updates with m(epoch + 1), no gradient
+    m = adjust_moco_momentum(4)
+    assert 0.99 < m < 1.0
+    want = wk0.cpu() * m * m + ex.encoder_q.fc.weight.detach().cpu() * (1 - m) * (1 + m)
+    np.testing.assert_allclose(ex.encoder_k.fc.weight.detach().cpu().numpy(), want.numpy(), rtol=1e-5, atol=1e-7)
+    assert rel_l2(ex.encoder_k.fc.weight.detach().cpu(), ref.encoder_k.fc.weight.detach()) < 1e-5
+    w0 = ex.encoder_q.fc.weight.detach().clone()
+    opt.step()                                                              # AdamW over the flat buffer
+    assert int(opt.step_count[0]) == 1 and not torch.equal(ex.encoder_q.fc.weight.detach(), w0)
+    assert float((ex.encoder_q.fc.weight.detach() - w0).abs().max()) <= 3e-4 * 1.001 + 1e-9      # |first Adam update| <= lr
+
+
+def test_ssmast_graph_replay_matches_eager():
+    """Graph-replayed steps (AdamW step counter, queue pointer and EMA inside the graph) against an eagerly stepped twin."""
+    import copy
+    from src.upstream.ssmast.upstream_expert import Upstream_Expert
+    twins = []
+    for _ in range(2):
+        torch.manual_seed(0)
+        twins.append(Upstream_Expert(copy.deepcopy(MAST_CFG), num_negatives=64).cuda().train())
+    eager, graphed = twins
+    opt_e, opt_g = eager.configure_optimizers(), graphed.configure_optimizers()
+    step = graphed.graphed_step(opt_g, eager_steps=1)
+    le, lg = [], []
+    for s in range(4):
+        a, b = _mel128(8, 101, 9800 + 2 * s).cuda(), _mel128(8, 101, 9801 + 2 * s).cuda()
+        opt_e.zero_grad()
+        loss = eager.training_step((a, b), s)
+        loss.backward()
+        opt_e.step()
+        le.append(float(loss))
+        lg.append(float(step(a, b)))
+    assert step.replays == 3 and all(np.isfinite(lg))
+    np.testing.assert_allclose(lg, le, rtol=2e-2)
+    assert int(opt_g.step_count[0]) == int(opt_e.step_count[0]) == 4
+    assert int(graphed.queue_ptr[0]) == int(eager.queue_ptr[0]) == (4 * 16) % 64
