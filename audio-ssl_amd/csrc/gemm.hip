@@ -12,6 +12,7 @@
 // Fragment K-order: lane half h owns k in [8h, 8h+8) of every 16-wide k-step for both operands; for
 // bf16 that is the hardware map of 32x32x16, for f32 the 8 k's are fed to 8 successive 32x32x2 MFMAs
 // (any bijection k->(step,half) is valid as long as A and B agree).
+#include <cstdlib>
 #include "common.h"
 
 namespace {
@@ -56,6 +57,59 @@ template <> struct Mma<float> {
         for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.hi[s], b.hi[s], acc, 0, 0, 0);
     }
 };
+
+// Epilogue through LDS.  The accumulators of a wave (64 x 64, C/D map of the 32x32 MFMA: col = lane & 31,
+// row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) are parked in a wave-private fp32 tile, then written out row by row with
+// lane = column: every optional term (bias, ReLU, dropout mask, gate, residual) is a coalesced load in a short runtime loop.
+// The fully unrolled per-element version this replaces was ~35 KB of straight-line code executed once per workgroup - the
+// instruction fetch alone cost ~14 us per launch (a one-tile, one-k-step GEMM took 16.7 us; tools/gemm_floor.py).
+constexpr int EPI_PITCH = 65;                                    // floats; odd pitch: conflict-free row reads
+constexpr size_t EPI_LDS = sizeof(float) * 4 * 64 * EPI_PITCH;   // 66,560 B, fits inside every variant's staging LDS
+
+template <typename T>
+__device__ __forceinline__ void epilogue_lds(const GemmArgs& g, f32x16 (&acc)[2][2], char* smem, int row0, int col0, int lane,
+                                             int wave) {
+    __syncthreads();                                             // every wave is done with the staging buffers
+    float* ct = reinterpret_cast<float*>(smem) + wave * 64 * EPI_PITCH;
+    const int half = lane >> 5, l31 = lane & 31;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                ct[(i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half) * EPI_PITCH + j * 32 + l31] = acc[i][j][r];
+    const int col = col0 + lane;
+    if (col >= g.N) return;
+    const float bias = g.bias ? g.bias[col] : 0.f;
+    const float floor_ = g.relu ? 0.f : -3.4e38f;
+    const T* gate = static_cast<const T*>(g.gate);
+    const int rows = min(64, g.M - row0);
+    // 8 rows per trip: the LDS reads and the optional global loads of a trip are independent, so their latencies overlap
+    // (one row per trip serialised ~150 cycles of LDS + store issue per row: 4 us of a 14 us single-tile launch)
+    for (int r0 = 0; r0 < rows; r0 += 8) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = ct[min(r0 + u, 63) * EPI_PITCH + lane];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const long row = row0 + min(r0 + u, rows - 1);
+            float x = fmaxf(g.alpha * v[u] + bias, floor_);
+            if (g.keep) x = g.keep[row * g.ldk + col] ? x * g.keep_scale : 0.f;
+            if (gate) x = to_f32(gate[row * g.ldg + col]) > 0.f ? x : 0.f;
+            if (g.resid) x += g.resid[row * g.ldr + col];
+            v[u] = x;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            if (r0 + u >= rows) break;
+            const long o = (long)(row0 + r0 + u) * g.ldc + col;
+            if (g.atomic)       atomicAdd(static_cast<float*>(g.C) + o, v[u]);
+            else if (g.out_f32) static_cast<float*>(g.C)[o] = v[u];
+            else                static_cast<T*>(g.C)[o] = from_f32<T>(v[u]);
+        }
+    }
+}
 
 // One operand's staging: 128 rows x 32 k per step, two Vec8 per thread.
 template <typename T, bool TRANS, int BK_>
@@ -196,35 +250,12 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
         cur ^= 1;
     }
 
-    // ---- epilogue: C/D map of 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
-    const T* gate = static_cast<const T*>(g.gate);
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int col = bn + wn + j * 32 + (lane & 31);
-            if (col >= g.N) continue;
-            const float bias = g.bias ? g.bias[col] : 0.f;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = bm + wm + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                if (row >= g.M) continue;
-                float v = g.alpha * acc[i][j][r] + bias;
-                if (g.relu) v = fmaxf(v, 0.f);
-                if (g.keep) v = g.keep[(long)row * g.ldk + col] ? v * g.keep_scale : 0.f;
-                if (gate) v = to_f32(gate[(long)row * g.ldg + col]) > 0.f ? v : 0.f;
-                if (g.resid) v += g.resid[(long)row * g.ldr + col];
-                const long o = (long)row * g.ldc + col;
-                if (g.atomic)       atomicAdd(static_cast<float*>(g.C) + o, v);
-                else if (g.out_f32) static_cast<float*>(g.C)[o] = v;
-                else                static_cast<T*>(g.C)[o] = from_f32<T>(v);
-            }
-        }
+    epilogue_lds<T>(g, acc, smem, bm + wm, bn + wn, lane, wave);
 }
 
 template <typename T, bool TA, bool TB, int BK>
 int launch(const GemmArgs& g, hipStream_t s) {
-    const size_t lds = sizeof(T) * 2 * (Stage<T, TA, BK>::LDS_ELEMS + Stage<T, TB, BK>::LDS_ELEMS);
+    const size_t lds = max(sizeof(T) * 2 * (Stage<T, TA, BK>::LDS_ELEMS + Stage<T, TB, BK>::LDS_ELEMS), EPI_LDS);
     static bool attr_set = false;
     if (!attr_set) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<T, TA, TB, BK>),
@@ -233,6 +264,128 @@ int launch(const GemmArgs& g, hipStream_t s) {
     }
     const int tiles = ceil_div(g.M, BM) * ceil_div(g.N, BN);
     hipLaunchKernelGGL((gemm_kernel<T, TA, TB, BK>), dim3(tiles, 1, g.ksplit), dim3(256), lds, s, g);
+    ASSL_LAUNCH_CHECK();
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// NT bf16 with direct-to-LDS staging (`global_load_lds_dwordx4`) and a 4-deep ring: the pipelined variant for the shapes
+// where one register stage cannot hide the load latency (M = 512..6144 Linear layers of the step: ~1.4 us per 64-deep
+// k-step against 0.2 us of MFMA work) and for the large transformer GEMMs.
+//   * an LDS-DMA instruction writes wave-uniform base + lane * 16 B, so the stage image is the plain [128 rows][64 k]
+//     tile (128-byte rows, no padding); bank conflicts of the fragment reads are removed by an XOR swizzle of the 16-byte
+//     chunk index, chunk ^= (row >> 1) & 7, applied to the SOURCE address of the DMA and to the ds_read address;
+//   * up to three stages stay in flight across the (raw) barrier: counted s_waitcnt vmcnt(N), never 0 in steady state;
+//   * rows past M / N are clamped to the last row (their results are never stored); K must be a multiple of 64.
+constexpr int GBK = 64;
+constexpr int GSTAGES = 4;
+constexpr int GOP_BYTES = 128 * GBK * 2;                 // one operand of one stage: 16 KB
+constexpr int GSTAGE_BYTES = 2 * GOP_BYTES;
+
+__device__ __forceinline__ void glds16(const bf16* src, char* dst) {
+    typedef __attribute__((address_space(1))) const void* gptr_t;
+    typedef __attribute__((address_space(3))) void* lptr_t;
+    __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)dst, 16, 0, 0);
+}
+
+__global__ __launch_bounds__(256) void gemm_nt_glds_kernel(GemmArgs g) {
+    extern __shared__ __attribute__((aligned(1024))) char smem[];
+    const int tiles_n = (g.N + BN - 1) / BN;
+    // blocks that share an XCD (ids congruent mod 8) get consecutive tiles: they share A row panels / B column panels in L2
+    const int nwg = gridDim.x, xcd = blockIdx.x & 7, q8 = nwg >> 3, r8 = nwg & 7;
+    const int wg = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (blockIdx.x >> 3);
+    const int bm = (wg / tiles_n) * BM, bn = (wg % tiles_n) * BN;
+    const int ksteps = g.K / GBK;
+    const int per = (ksteps + g.ksplit - 1) / g.ksplit;
+    const int ks0 = blockIdx.z * per, ks1 = min(ksteps, ks0 + per);
+    if (ks0 >= ks1) return;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
+
+    const bf16* Ap[4];
+    const bf16* Bp[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int rl = wave * 32 + i * 8 + (lane >> 3);
+        const int sc = (lane & 7) ^ ((rl >> 1) & 7);
+        Ap[i] = static_cast<const bf16*>(g.A) + (long)min(bm + rl, g.M - 1) * g.lda + sc * 8 + (long)ks0 * GBK;
+        Bp[i] = static_cast<const bf16*>(g.B) + (long)min(bn + rl, g.N - 1) * g.ldb + sc * 8 + (long)ks0 * GBK;
+    }
+    char* const wbase = smem + (wave * 32) * 128;        // this wave's first row inside an operand image
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int nk = ks1 - ks0;
+    auto issue = [&](int st) {
+        char* d = wbase + (st % GSTAGES) * GSTAGE_BYTES;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) glds16(Ap[i] + (long)st * GBK, d + i * 8 * 128);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) glds16(Bp[i] + (long)st * GBK, d + GOP_BYTES + i * 8 * 128);
+    };
+    for (int st = 0; st < GSTAGES - 1 && st < nk; ++st) issue(st);
+
+    // fragment addressing: row r, logical 16-byte chunk cc -> physical chunk cc ^ ((r >> 1) & 7)
+    const int half = lane >> 5, l31 = lane & 31;
+    int offA[2], offB[2], swA[2], swB[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int ra = wm + i * 32 + l31, rb = wn + i * 32 + l31;
+        offA[i] = ra * 128; swA[i] = (ra >> 1) & 7;
+        offB[i] = GOP_BYTES + rb * 128; swB[i] = (rb >> 1) & 7;
+    }
+    for (int it = 0; it < nk; ++it) {
+        const int ahead = min(nk - 1 - it, GSTAGES - 2);
+        if (ahead >= 2)      asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+        else if (ahead == 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                    // stage `it` visible to every wave; slot of stage it-1 free again
+        if (it + GSTAGES - 1 < nk) issue(it + GSTAGES - 1);
+        const char* sb = smem + (it % GSTAGES) * GSTAGE_BYTES;
+        // fragment reads run one k-step ahead of the MFMAs that consume them (one wave per SIMD: nobody else hides the
+        // ~120-cycle LDS latency)
+        Vec8<bf16> fa[2][2], fb[2][2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            fa[0][i] = Vec8<bf16>::load(reinterpret_cast<const bf16*>(sb + offA[i] + ((half ^ swA[i]) << 4)));
+            fb[0][i] = Vec8<bf16>::load(reinterpret_cast<const bf16*>(sb + offB[i] + ((half ^ swB[i]) << 4)));
+        }
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            const int cur = kk & 1, nxt = cur ^ 1;
+            if (kk < 3) {
+                const int cc = (kk + 1) * 2 + half;
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    fa[nxt][i] = Vec8<bf16>::load(reinterpret_cast<const bf16*>(sb + offA[i] + ((cc ^ swA[i]) << 4)));
+                    fb[nxt][i] = Vec8<bf16>::load(reinterpret_cast<const bf16*>(sb + offB[i] + ((cc ^ swB[i]) << 4)));
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) Mma<bf16>::run(acc[i][j], fa[cur][i], fb[cur][j]);
+        }
+    }
+
+    epilogue_lds<bf16>(g, acc, smem, bm + wm, bn + wn, lane, wave);
+}
+
+int launch_nt_glds(const GemmArgs& g, hipStream_t s) {
+    constexpr size_t lds = (size_t)GSTAGES * GSTAGE_BYTES;
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_glds_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)lds) != hipSuccess) return ASSL_ELAUNCH;
+        attr_set = true;
+    }
+    const int tiles = ceil_div(g.M, BM) * ceil_div(g.N, BN);
+    hipLaunchKernelGGL(gemm_nt_glds_kernel, dim3(tiles, 1, g.ksplit), dim3(256), lds, s, g);
     ASSL_LAUNCH_CHECK();
 }
 
@@ -268,6 +421,10 @@ extern "C" int audiossl_gemm(int dtype, int trans_a, int trans_b, int M, int N, 
                (dtype == 0) ? 1 : out_f32, atomic, ksplit, resid, ldr, (unsigned)a_ext, (unsigned)b_ext};
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (dtype == 0) return dispatch<float, 32>(g, trans_a, trans_b, s);
+    static const bool use_glds = getenv("AUDIOSSL_GEMM_GLDS") ? atoi(getenv("AUDIOSSL_GEMM_GLDS")) != 0 : true;
     const long blocks = (long)ceil_div(M, BM) * ceil_div(N, BN) * ksplit;
+    // the 4-deep direct-to-LDS ring (one workgroup per CU) wins while the grid is at most two waves of workgroups; beyond
+    // that two co-resident workgroups of the register-staged kernel overlap each other better (tools/gemm_floor.py)
+    if (use_glds && !trans_a && !trans_b && K % GBK == 0 && blocks <= 512) return launch_nt_glds(g, s);
     return blocks <= 256 && K >= 512 ? dispatch<bf16, 128>(g, trans_a, trans_b, s) : dispatch<bf16, 64>(g, trans_a, trans_b, s);
 }
