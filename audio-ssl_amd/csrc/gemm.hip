@@ -21,7 +21,6 @@ constexpr int BM = 128, BN = 128;
 // K-step per launch: bf16 64 when the grid fills the chip several times over (73 KB of LDS -> 2 workgroups / CU), 128 when
 // there is at most one workgroup per CU anyway (the loop is then latency-bound per step: fewer, fatter steps win;
 // measured 40 -> 26 us on 1024x2048x2048).  fp32 (validation path): 32.
-constexpr int TR_PITCH = 128 + 32;    // elements; [k][row] image: 80-dword rows keep ds_read_b64_tr_b16 conflict-free
 
 struct GemmArgs {
     const void* A; const void* B; void* C;
@@ -66,14 +65,15 @@ template <> struct Mma<float> {
 constexpr int EPI_PITCH = 65;                                    // floats; odd pitch: conflict-free row reads
 constexpr size_t EPI_LDS = sizeof(float) * 4 * 64 * EPI_PITCH;   // 66,560 B, fits inside every variant's staging LDS
 
-template <typename T>
-__device__ __forceinline__ void epilogue_lds(const GemmArgs& g, f32x16 (&acc)[2][2], char* smem, int row0, int col0, int lane,
+// MI = 32-row MFMA blocks per wave in M (wave tile = 32*MI x 64)
+template <typename T, int MI>
+__device__ __forceinline__ void epilogue_lds(const GemmArgs& g, f32x16 (&acc)[MI][2], char* smem, int row0, int col0, int lane,
                                              int wave) {
     __syncthreads();                                             // every wave is done with the staging buffers
     float* ct = reinterpret_cast<float*>(smem) + wave * 64 * EPI_PITCH;
     const int half = lane >> 5, l31 = lane & 31;
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < MI; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -84,7 +84,7 @@ __device__ __forceinline__ void epilogue_lds(const GemmArgs& g, f32x16 (&acc)[2]
     const float bias = g.bias ? g.bias[col] : 0.f;
     const float floor_ = g.relu ? 0.f : -3.4e38f;
     const T* gate = static_cast<const T*>(g.gate);
-    const int rows = min(64, g.M - row0);
+    const int rows = min(32 * MI, g.M - row0);
     // 8 rows per trip: the LDS reads and the optional global loads of a trip are independent, so their latencies overlap
     // (one row per trip serialised ~150 cycles of LDS + store issue per row: 4 us of a 14 us single-tile launch)
     for (int r0 = 0; r0 < rows; r0 += 8) {
@@ -112,11 +112,13 @@ __device__ __forceinline__ void epilogue_lds(const GemmArgs& g, f32x16 (&acc)[2]
 }
 
 // One operand's staging: 128 rows x 32 k per step, two Vec8 per thread.
-template <typename T, bool TRANS, int BK_>
+template <typename T, bool TRANS, int BK_, int ROWS = 128>
 struct Stage {
     static constexpr int BK = BK_;
     static constexpr int NT_PITCH = BK + 8;          // elements; [row][k] image, conflict-free 16-byte row reads
-    static constexpr int NV = BM * BK / 8 / 256;     // 8-element vectors per thread and step
+    static constexpr int TR_PITCH = ROWS + 32;       // elements; [k][row] image: 4 consecutive k-rows fall on distinct 32-byte bank groups
+    static constexpr int VR = ROWS / 8;              // vectors per k-row of the [k][row] image
+    static constexpr int NV = ROWS * BK / 8 / 256;   // 8-element vectors per thread and step
     static constexpr int VPR = BK / 8;               // vectors per row of the [row][k] image
     Vec8<T> r[NV];
     // Branch-free staging loads: a raw buffer load per 16 bytes, out-of-range vectors get an offset past the
@@ -141,7 +143,7 @@ struct Stage {
             int row, k;
             long idx;
             if (!TRANS) { row = row0 + v / VPR; k = k0 + (v % VPR) * 8; idx = (long)row * ld + k; }
-            else        { k = k0 + (v >> 4); row = row0 + (v & 15) * 8; idx = (long)k * ld + row; }
+            else        { k = k0 + v / VR; row = row0 + (v % VR) * 8; idx = (long)k * ld + row; }
             const unsigned off = (row < rows && k < kend) ? (unsigned)(idx * (long)sizeof(T)) : 0xFFFFFFE0u;
             r[i] = select_load(rs, off, (T*)nullptr);
         }
@@ -154,7 +156,7 @@ struct Stage {
         for (int i = 0; i < NV; ++i) {
             const int v = t + i * 256;
             if (!TRANS) r[i].store(lds + (v / VPR) * NT_PITCH + (v % VPR) * 8);
-            else        r[i].store(lds + (v >> 4) * TR_PITCH + (v & 15) * 8);
+            else        r[i].store(lds + (v / VR) * TR_PITCH + (v % VR) * 8);
         }
     }
     // fragment of 32 rows starting at `row`, k-step `kk` (0 or 16) for this lane
@@ -182,19 +184,20 @@ struct Stage {
         f.v = bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
         return f;
     }
-    static constexpr int LDS_ELEMS = TRANS ? BK * TR_PITCH : BM * NT_PITCH;
+    static constexpr int LDS_ELEMS = TRANS ? BK * TR_PITCH : ROWS * NT_PITCH;
 };
 
-template <typename T, bool TA, bool TB, int BK>
+template <typename T, bool TA, bool TB, int BK, int MI>
 __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
-    using SA = Stage<T, TA, BK>;
-    using SB = Stage<T, TB, BK>;
+    constexpr int BMv = 64 * MI;                                 // 128 x 128 tile (MI = 2) or 64 x 128 (MI = 1: twice the
+    using SA = Stage<T, TA, BK, BMv>;                            // workgroups for grids that would leave CUs idle)
+    using SB = Stage<T, TB, BK, BN>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     T* const ldsA0 = reinterpret_cast<T*>(smem);                 // two A buffers, then two B buffers
     T* const ldsB0 = ldsA0 + 2 * SA::LDS_ELEMS;
 
     const int tiles_n = (g.N + BN - 1) / BN;
-    const int bm = (blockIdx.x / tiles_n) * BM, bn = (blockIdx.x % tiles_n) * BN;
+    const int bm = (blockIdx.x / tiles_n) * BMv, bn = (blockIdx.x % tiles_n) * BN;
     // split-K range, in whole BK steps
     const int ksteps = (g.K + BK - 1) / BK;
     const int per = (ksteps + g.ksplit - 1) / g.ksplit;
@@ -205,11 +208,11 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
     const __amdgpu_buffer_rsrc_t A = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(g.A), 0, g.a_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t B = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(g.B), 0, g.b_bytes, 0x00020000);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
+    const int wm = (wave >> 1) * 32 * MI, wn = (wave & 1) * 64;
 
-    f32x16 acc[2][2];
+    f32x16 acc[MI][2];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < MI; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -235,13 +238,13 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
         const T* lb = ldsB0 + cur * SB::LDS_ELEMS;
 #pragma unroll
         for (int kk = 0; kk < BK; kk += 16) {
-            Vec8<T> fa[2], fb[2];
+            Vec8<T> fa[MI], fb[2];
 #pragma unroll
-            for (int i = 0; i < 2; ++i) fa[i] = SA::frag(la, wm + i * 32, kk, lane);
+            for (int i = 0; i < MI; ++i) fa[i] = SA::frag(la, wm + i * 32, kk, lane);
 #pragma unroll
             for (int j = 0; j < 2; ++j) fb[j] = SB::frag(lb, wn + j * 32, kk, lane);
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+            for (int i = 0; i < MI; ++i)
 #pragma unroll
                 for (int j = 0; j < 2; ++j) Mma<T>::run(acc[i][j], fa[i], fb[j]);
         }
@@ -250,20 +253,20 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
         cur ^= 1;
     }
 
-    epilogue_lds<T>(g, acc, smem, bm + wm, bn + wn, lane, wave);
+    epilogue_lds<T, MI>(g, acc, smem, bm + wm, bn + wn, lane, wave);
 }
 
-template <typename T, bool TA, bool TB, int BK>
+template <typename T, bool TA, bool TB, int BK, int MI>
 int launch(const GemmArgs& g, hipStream_t s) {
-    const size_t lds = max(sizeof(T) * 2 * (Stage<T, TA, BK>::LDS_ELEMS + Stage<T, TB, BK>::LDS_ELEMS), EPI_LDS);
+    const size_t lds = max(sizeof(T) * 2 * (Stage<T, TA, BK, 64 * MI>::LDS_ELEMS + Stage<T, TB, BK, BN>::LDS_ELEMS), EPI_LDS);
     static bool attr_set = false;
     if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<T, TA, TB, BK>),
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<T, TA, TB, BK, MI>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return ASSL_ELAUNCH;
         attr_set = true;
     }
-    const int tiles = ceil_div(g.M, BM) * ceil_div(g.N, BN);
-    hipLaunchKernelGGL((gemm_kernel<T, TA, TB, BK>), dim3(tiles, 1, g.ksplit), dim3(256), lds, s, g);
+    const int tiles = ceil_div(g.M, 64 * MI) * ceil_div(g.N, BN);
+    hipLaunchKernelGGL((gemm_kernel<T, TA, TB, BK, MI>), dim3(tiles, 1, g.ksplit), dim3(256), lds, s, g);
     ASSL_LAUNCH_CHECK();
 }
 
@@ -373,7 +376,7 @@ __global__ __launch_bounds__(256) void gemm_nt_glds_kernel(GemmArgs g) {
         }
     }
 
-    epilogue_lds<bf16>(g, acc, smem, bm + wm, bn + wn, lane, wave);
+    epilogue_lds<bf16, 2>(g, acc, smem, bm + wm, bn + wn, lane, wave);
 }
 
 int launch_nt_glds(const GemmArgs& g, hipStream_t s) {
@@ -389,12 +392,12 @@ int launch_nt_glds(const GemmArgs& g, hipStream_t s) {
     ASSL_LAUNCH_CHECK();
 }
 
-template <typename T, int BK>
+template <typename T, int BK, int MI>
 int dispatch(const GemmArgs& g, int ta, int tb, hipStream_t s) {
-    if (!ta && !tb) return launch<T, false, false, BK>(g, s);
-    if (!ta && tb) return launch<T, false, true, BK>(g, s);
-    if (ta && tb) return launch<T, true, true, BK>(g, s);
-    return launch<T, true, false, BK>(g, s);
+    if (!ta && !tb) return launch<T, false, false, BK, MI>(g, s);
+    if (!ta && tb) return launch<T, false, true, BK, MI>(g, s);
+    if (ta && tb) return launch<T, true, true, BK, MI>(g, s);
+    return launch<T, true, false, BK, MI>(g, s);
 }
 
 }  // namespace
@@ -420,11 +423,16 @@ extern "C" int audiossl_gemm(int dtype, int trans_a, int trans_b, int M, int N, 
     GemmArgs g{A, B, C, M, N, K, lda, ldb, ldc, alpha, bias, relu, keep, ldk, keep_scale, gate, ldg,
                (dtype == 0) ? 1 : out_f32, atomic, ksplit, resid, ldr, (unsigned)a_ext, (unsigned)b_ext};
     hipStream_t s = static_cast<hipStream_t>(stream);
-    if (dtype == 0) return dispatch<float, 32>(g, trans_a, trans_b, s);
+    if (dtype == 0) return dispatch<float, 32, 2>(g, trans_a, trans_b, s);
     static const bool use_glds = getenv("AUDIOSSL_GEMM_GLDS") ? atoi(getenv("AUDIOSSL_GEMM_GLDS")) != 0 : true;
     const long blocks = (long)ceil_div(M, BM) * ceil_div(N, BN) * ksplit;
-    // the 4-deep direct-to-LDS ring (one workgroup per CU) wins while the grid is at most two waves of workgroups; beyond
+    // the 4-deep direct-to-LDS ring (one workgroup per CU) wins for one to two waves of workgroups (below that the 64-row
+    // tiles further down are faster still); beyond
     // that two co-resident workgroups of the register-staged kernel overlap each other better (tools/gemm_floor.py)
-    if (use_glds && !trans_a && !trans_b && K % GBK == 0 && blocks <= 512) return launch_nt_glds(g, s);
-    return blocks <= 256 && K >= 512 ? dispatch<bf16, 128>(g, trans_a, trans_b, s) : dispatch<bf16, 64>(g, trans_a, trans_b, s);
+    if (use_glds && !trans_a && !trans_b && K % GBK == 0 && blocks > 128 && blocks <= 512) return launch_nt_glds(g, s);
+    static const bool small_tiles = getenv("AUDIOSSL_GEMM_SMALL") ? atoi(getenv("AUDIOSSL_GEMM_SMALL")) != 0 : true;
+    // these shapes are latency-bound per workgroup (~0.5 us per 64-deep k-step whatever the tile): when 128 x 128 tiles
+    // would occupy at most half of the 256 CUs, halve the tile in M and run twice as many workgroups
+    if (small_tiles && blocks <= 128 && M > 64) return dispatch<bf16, 64, 1>(g, trans_a, trans_b, s);
+    return blocks <= 256 && K >= 512 ? dispatch<bf16, 128, 2>(g, trans_a, trans_b, s) : dispatch<bf16, 64, 2>(g, trans_a, trans_b, s);
 }

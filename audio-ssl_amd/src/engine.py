@@ -50,7 +50,7 @@ def _empty(shape, dtype, like=None, device=None):
     return torch.empty(shape, dtype=dtype, device=device if device is not None else like.device)
 
 
-def _ksplit(M, Nn, K, target=512):
+def _ksplit(M, Nn, K, target=256):
     tiles = ((M + 127) // 128) * ((Nn + 127) // 128)
     ks = max(1, min(target // max(tiles, 1), (K + 127) // 128))
     return int(ks)
