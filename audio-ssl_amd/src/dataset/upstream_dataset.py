@@ -59,6 +59,35 @@ class UpstreamFrontEnd:
         lms = extract_log_mel_spectrogram(waves, self.to_mel_spec)
         return self.tfms.augment_batch(lms, plan=plan)
 
+    # ---- one-batch-ahead pipelining: the front end of batch i+1 (log-mel, running norm, mixup, crops: ~0.4 ms of small
+    #      launches, the running-norm scan being a one-workgroup recurrence) runs on its own stream underneath the training
+    #      step of batch i.  All front-end state (RunningNorm, mixup ring) is only ever touched on that stream, in order.
+    _stream = None
+
+    def submit(self, waves, plan=None):
+        """Start the front end for `waves` on the front-end stream; -> ticket for `collect`.  Call it BEFORE launching the
+        training step it should overlap with (the front-end stream waits for what is already queued on the current one)."""
+        if not waves.is_cuda:
+            waves = waves.cuda(non_blocking=True)
+        if self._stream is None:
+            self._stream = torch.cuda.Stream(device=waves.device)
+        self._stream.wait_stream(torch.cuda.current_stream(waves.device))
+        with torch.cuda.stream(self._stream):
+            views = self(waves, plan)
+            ev = torch.cuda.Event()
+            ev.record()
+        waves.record_stream(self._stream)
+        return views, ev
+
+    def collect(self, ticket):
+        """-> (img_1, img_2) of a submitted batch, ordered before whatever is queued next on the current stream."""
+        views, ev = ticket
+        cur = torch.cuda.current_stream(views[0].device)
+        cur.wait_event(ev)
+        for v in views:
+            v.record_stream(cur)
+        return views
+
 
 class BaseDataset(Dataset):
     def __init__(self, config, args, data_csv, tfms, per_sample=False):

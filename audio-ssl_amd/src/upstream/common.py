@@ -169,7 +169,9 @@ class GraphedStep:
 
     def __init__(self, expert, optimizer, eager_steps=2, world=1, phases=False):
         self.expert, self.opt, self.eager_steps, self.world = expert, optimizer, eager_steps, world
-        self.use_phases = phases or world > 1
+        # experts whose step has several independent branches replay one graph per phase even on a single rank: ROCm's
+        # graph executor runs the branches of ONE graph back to back, separately launched graphs on separate streams overlap
+        self.use_phases = phases or world > 1 or getattr(expert, "prefer_phases", False)
         self.calls = 0
         self.graph = None
         self.phases = None                 # GraphPhases of the data-parallel variant

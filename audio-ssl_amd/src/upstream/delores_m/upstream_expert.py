@@ -27,6 +27,8 @@ def _world():
 
 
 class Upstream_Expert(MocoQueueMixin, FusedExpertMixin, UpstreamModule):
+    prefer_phases = False         # single rank: ONE graph measured faster than one graph per phase (4.1 vs 4.3 ms at B=512)
+
     def __init__(self, config, base_encoder, datamodule=None, emb_dim: int = 128, num_negatives: int = 65536,
                  encoder_momentum: float = 0.999, softmax_temperature: float = 0.07, learning_rate: float = 0.03,
                  momentum: float = 0.9, weight_decay: float = 1e-4, data_dir: str = './', batch_size: int = 256,
@@ -127,20 +129,24 @@ class Upstream_Expert(MocoQueueMixin, FusedExpertMixin, UpstreamModule):
         self._key_stream.join(dev)
         k.record_stream(main)
 
-        # ---- loss heads: the three Barlow heads are independent of each other and of the MoCo head (one side stream
-        #      each); InfoNCE against the queue runs on the main stream concurrently
-        def heads_phase():
-            here = torch.cuda.current_stream()
-            dys = [None, None, None]
-            for i, p in enumerate((self.p1, self.p2, self.p3)):
-                st = self._streams(dev)[i]
-                st.wait_stream(here)
-                with torch.cuda.stream(st):
-                    Wp = flat.shadow_dict(f"p{i + 1}.")
-                    dys[i] = E.barlow_forward_backward(p.param_dict(), G(f"p{i + 1}."), Ys[i], dt, p.lambd, p.scale_loss,
-                                                       loss[i + 1:i + 2], need_dy1=True, need_dy2=False,
-                                                       update_running=self.training, backward=need_grad,
-                                                       Wc=tuple(Wp[f"projector.{j}.weight"] for j in (0, 3, 6)))
+        # ---- loss heads: the three Barlow heads are independent of each other and of the MoCo head.  Each is its own
+        #      phase on its own stream (a single captured graph would serialise the four branches: ROCm's graph executor
+        #      ran them back to back, 2.1 ms instead of 0.5 ms - tools/timeline.py)
+        streams = self._streams(dev)
+        dys = [None, None, None]
+
+        def head_phase(i, p):
+            Wp = flat.shadow_dict(f"p{i + 1}.")
+            return E.barlow_forward_backward(p.param_dict(), G(f"p{i + 1}."), Ys[i], dt, p.lambd, p.scale_loss,
+                                             loss[i + 1:i + 2], need_dy1=True, need_dy2=False,
+                                             update_running=self.training, backward=need_grad,
+                                             Wc=tuple(Wp[f"projector.{j}.weight"] for j in (0, 3, 6)))
+        for i, p in enumerate((self.p1, self.p2, self.p3)):
+            streams[i].wait_stream(main)
+            with torch.cuda.stream(streams[i]):
+                dys[i] = R.phase(f"head{i + 1}", lambda i=i, p=p: head_phase(i, p))
+
+        def moco_phase():
             shadow = E.cast(dt, self.queue) if dt != N.F32 else self.queue
             dq, kn32 = E.moco_forward_backward(dt, q, k, self.queue, shadow, float(self.hparams.softmax_temperature),
                                                loss[0:1], backward=need_grad)
@@ -151,19 +157,24 @@ class Upstream_Expert(MocoQueueMixin, FusedExpertMixin, UpstreamModule):
                 E.colsum_add(dt, dq, B, wq.shape[0], Gq["fc.bias"])
                 dyq = E.linear_bwd_x(dt, dq, wq, B, wq.shape[0], wq.shape[1], out_f32=1)
                 dA2 = E.maxmean_backward(dt, dyq, argq, Hq)
-            for st in self._streams(dev):
-                here.wait_stream(st)
-            for d in dys:
-                if d is not None:
-                    d.record_stream(here)
-            return kn32, dA2, dys, loss.sum()
-        kn32, dA2, dys, total = R.phase("heads", heads_phase)
+            return kn32, dA2
+        kn32, dA2 = R.phase("moco", moco_phase)
         self._dequeue_and_enqueue(kn32, None)               # after the logits and dq GEMMs have read the queue
+        for st in streams:
+            main.wait_stream(st)
+        for d in dys:
+            if d is not None:
+                d.record_stream(main)
         if need_grad:
             self.reduce_begin("heads")                      # p1-p3 gradients complete: their all-reduce overlaps the encoder bwd
-            R.phase("encoder_bwd", lambda: E.encoder_backward(cq, G("encoder_q.encoder."), dA2=dA2, dx1=dys[0], dx2=dys[1],
-                                                              dx3=dys[2]))
+
+            def backward_phase():
+                E.encoder_backward(cq, G("encoder_q.encoder."), dA2=dA2, dx1=dys[0], dx2=dys[1], dx3=dys[2])
+                return loss.sum()
+            total = R.phase("encoder_bwd", backward_phase)
             self.reduce_begin("enc")
+        else:
+            total = loss.sum()
         if parts is not None:
             parts["losses"] = loss
         return total

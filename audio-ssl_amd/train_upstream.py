@@ -82,8 +82,17 @@ class HipTrainer:
             if sampler is not None:
                 sampler.set_epoch(epoch)
             t0, clips = time.time(), 0
-            for i, (waves, plan) in enumerate(loader):
-                img_1, img_2 = dm.front_end(waves.to(dev, non_blocking=True), plan)
+            batches = iter(loader)
+            nxt = next(batches, None)
+            ticket = None if nxt is None else dm.front_end.submit(nxt[0].to(dev, non_blocking=True), nxt[1])
+            i = -1
+            while nxt is not None:
+                i += 1
+                waves = nxt[0]
+                img_1, img_2 = dm.front_end.collect(ticket)
+                nxt = next(batches, None)               # the next batch's log-mel + augmentation runs under this step
+                if nxt is not None:
+                    ticket = dm.front_end.submit(nxt[0].to(dev, non_blocking=True), nxt[1])
                 if gstep is not None:
                     loss = gstep(img_1, img_2)
                 else:

@@ -165,8 +165,13 @@ def main():
     # data-parallel ranks replay one graph per collective-free phase with the RCCL calls in between.
     gstep = None if args.no_graph else model.graphed_step(opt, phases=args.graph_phases)
 
+    ticket = [front.submit(waves)]
+
     def step(i):
-        img_1, img_2 = front(waves)
+        # the front end of the NEXT batch is submitted (own stream) before this batch's training step is launched, so it
+        # runs underneath it; every call does exactly one front end and one training step
+        img_1, img_2 = front.collect(ticket[0])
+        ticket[0] = front.submit(waves)
         if gstep is not None:
             return gstep(img_1, img_2)
         opt.zero_grad()
@@ -203,7 +208,8 @@ def main():
         N.PROFILE = {"audiossl_gemm": []}
         prof_steps = min(args.steps, 5)
         for i in range(prof_steps):
-            img_1, img_2 = front(waves)
+            img_1, img_2 = front.collect(ticket[0])
+            ticket[0] = front.submit(waves)
             gstep._eager(img_1, img_2)
         torch.cuda.synchronize()
     else:

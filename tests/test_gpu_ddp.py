@@ -99,7 +99,7 @@ def test_two_rank_graph_phases_match_eager(which):
     from helpers import rel_l2
     e0, _ = _run(which, graph=False)
     g0, g1 = _run(which, graph=True)
-    want = ["encoder_bwd", "heads", "key", "query"] if which == "delores_m" else ["encoder_bwd", "forward"]
+    want = ["encoder_bwd", "head1", "head2", "head3", "key", "moco", "query"] if which == "delores_m" else ["encoder_bwd", "forward"]
     assert g0["graphs"] == (want, None) and g1["graphs"] == (want, None)
     for n in g0["w"]:
         np.testing.assert_array_equal(g0["w"][n], g1["w"][n], err_msg=n)
