@@ -47,7 +47,7 @@ def pmc_traffic(ta, tb):
         if "gemm_kernel" not in name or v["read_bytes_per_launch"] is None:
             continue
         m = re.search(r"gemm_kernelIDF16bLb(\d)ELb(\d)ELi\d+E", name)
-        key = (int(m.group(1)), int(m.group(2))) if m else ((1, 1) if re.search(r"E, true, \d+>", name) else None)
+        key = (int(m.group(1)), int(m.group(2))) if m else ((1, 1) if re.search(r"E, true, \d+(, \d+)?>", name) else None)
         if key == (ta, tb):
             tot += (v["read_bytes_per_launch"] + (v["write_bytes_per_launch"] or 0)) * v["launches"]
             n += v["launches"]
