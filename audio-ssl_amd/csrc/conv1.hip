@@ -11,11 +11,13 @@
 //   dW_c,tap = gamma rstd [ G_c,tap - dbeta_c/n S1_tap - dgamma_c/n * rstd (w_c . S2[:,tap] + (b_c-mean_c) S1_tap) ]
 // with G = sum over pooled pixels of (routed, ReLU-gated) gradient x tap value, so it is ONE more pass.
 // Layouts: image [N][F][T] fp32 (NCHW, C=1); pooled output [N][T/2][F/2][64] (time, mel, channel) in T_.
+#include <cstdlib>
 #include "common.h"
 
 namespace {
 
 constexpr int NTAP = 9, NMOM = 9 + 45;
+constexpr int MOM_REPL = 16;     // replicas of the moment accumulator (`mom` scratch = MOM_REPL * 54 doubles)
 
 __device__ __forceinline__ int tri(int a, int b) {   // index of pair (a<=b) in the packed upper triangle
     return a * 9 - a * (a - 1) / 2 + (b - a);
@@ -59,18 +61,28 @@ __global__ __launch_bounds__(256) void conv1_moments_kernel(const float* __restr
     if (threadIdx.x < NMOM) {
         const double v = (double)sh[0][threadIdx.x] + (double)sh[1][threadIdx.x] + (double)sh[2][threadIdx.x] +
                          (double)sh[3][threadIdx.x];
-        atomicAdd(&mom[threadIdx.x], v);
+        atomicAdd(&mom[(blockIdx.x & (MOM_REPL - 1)) * NMOM + threadIdx.x], v);     // replicated: same-address atomics serialise
     }
 }
 
 // 64 threads, one per output channel.
-__global__ void conv1_finalize_kernel(const double* __restrict__ mom, const float* __restrict__ w,
+__global__ void conv1_finalize_kernel(double* __restrict__ momr, const float* __restrict__ w,
                                       const float* __restrict__ bias, const float* __restrict__ gamma,
                                       const float* __restrict__ beta, float* running_mean, float* running_var,
                                       float momentum, float eps, double count, float* scale, float* shift,
                                       float* save_mean, float* save_rstd) {
     const int c = threadIdx.x;
     if (c >= 64) return;
+    // fold the replicas into mom[0..53] (kept for the backward), then every channel reads the totals
+    __shared__ double tot[NMOM];
+    if (c < NMOM) {
+        double t = 0.0;
+        for (int r = 0; r < MOM_REPL; ++r) t += momr[r * NMOM + c];
+        tot[c] = t;
+    }
+    __syncthreads();
+    if (c < NMOM) momr[c] = tot[c];
+    const double* mom = tot;
     double mean = 0.0, var = 0.0;
     for (int a = 0; a < 9; ++a) mean += (double)w[c * 9 + a] * mom[a];
     mean = mean / count;
@@ -257,6 +269,213 @@ __global__ __launch_bounds__(256) void conv1_bwd_kernel(const float* __restrict_
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// bf16 MFMA formulation of the stem (the fp32 VALU kernels above are the validation path; they are VALU-bound: 7.5 GFLOP of
+// fp32 FMAs per 512-clip step forward).  One wave owns 8 pooled mel rows of an (image, pooled time column) item = 32 conv
+// pixels = one 32-row MFMA tile, ordered row = 4 * pooled_pixel + window_position, so that in the C/D map
+// (row = (r & 3) + 8 * (r >> 2) + 4 * half) register r of a lane is window position r & 3 of pooled pixel 2 * (r >> 2) + half:
+// BatchNorm + ReLU + the 2x2 max are in-register per lane (= channel).  K = 9 taps padded to 16: lanes of the lower half
+// carry taps 0..7, the upper half tap 8 and zeros.
+__device__ __forceinline__ Vec8<bf16> stem_taps(const float* patch, int f, int dt, int half) {
+    Vec8<bf16> a;
+    if (half == 0) {
+        a.v[0] = (bf16)patch[(f + 0) * 4 + dt + 0]; a.v[1] = (bf16)patch[(f + 0) * 4 + dt + 1]; a.v[2] = (bf16)patch[(f + 0) * 4 + dt + 2];
+        a.v[3] = (bf16)patch[(f + 1) * 4 + dt + 0]; a.v[4] = (bf16)patch[(f + 1) * 4 + dt + 1]; a.v[5] = (bf16)patch[(f + 1) * 4 + dt + 2];
+        a.v[6] = (bf16)patch[(f + 2) * 4 + dt + 0]; a.v[7] = (bf16)patch[(f + 2) * 4 + dt + 1];
+    } else {
+        a = Vec8<bf16>::zero();
+        a.v[0] = (bf16)patch[(f + 2) * 4 + dt + 2];
+    }
+    return a;
+}
+// weights as the B operand: B[k = tap][n = channel], lane = channel 32 j + (lane & 31), k = 8 half + jj
+__device__ __forceinline__ Vec8<bf16> stem_weights(const float* w, int c, int half) {
+    Vec8<bf16> b = Vec8<bf16>::zero();
+    if (half == 0) {
+#pragma unroll
+        for (int jj = 0; jj < 8; ++jj) b.v[jj] = (bf16)w[c * 9 + jj];
+    } else {
+        b.v[0] = (bf16)w[c * 9 + 8];
+    }
+    return b;
+}
+
+__global__ __launch_bounds__(256) void conv1_fwd_mfma_kernel(const float* __restrict__ img, const float* __restrict__ w,
+                                                             const float* __restrict__ bias, const float* __restrict__ scale,
+                                                             const float* __restrict__ shift, bf16* __restrict__ out,
+                                                             int N, int F, int T) {
+    extern __shared__ __attribute__((aligned(16))) float patch[];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, half = lane >> 5, l31 = lane & 31;
+    const int To = T / 2, Fo = F / 2;
+    Vec8<bf16> wb[2];
+    float b[2], sc[2], sh[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int c = 32 * j + l31;
+        wb[j] = stem_weights(w, c, half);
+        b[j] = bias[c]; sc[j] = scale[c]; sh[j] = shift[c];
+    }
+    const int pp = l31 >> 2, df = (l31 >> 1) & 1, dt = l31 & 1;          // this lane's A row: pooled pixel pp, window (df, dt)
+    PatchRegs pre;
+    int item = blockIdx.x;
+    if (item < N * To) { pre.fetch(img, item / To, item % To, F, T); pre.put(patch, F); }
+    __syncthreads();
+    for (; item < N * To; item += gridDim.x) {
+        const int n = item / To, tp = item - n * To;
+        const int nxt = item + gridDim.x;
+        if (nxt < N * To) pre.fetch(img, nxt / To, nxt % To, F, T);
+        for (int tile = wv; tile * 8 < Fo; tile += 4) {
+            const int fp = min(tile * 8 + pp, Fo - 1);
+            const Vec8<bf16> a = stem_taps(patch, 2 * fp + df, dt, half);
+            bf16* o = out + (((long)n * To + tp) * Fo) * 64;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                f32x16 acc;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.v, wb[j].v, acc, 0, 0, 0);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    float m = 0.f;
+#pragma unroll
+                    for (int r3 = 0; r3 < 4; ++r3) m = fmaxf(m, sc[j] * (acc[4 * q + r3] + b[j]) + sh[j]);
+                    const int fpo = tile * 8 + 2 * q + half;
+                    if (fpo < Fo) o[(long)fpo * 64 + 32 * j + l31] = (bf16)m;
+                }
+            }
+        }
+        __syncthreads();
+        if (nxt < N * To) pre.put(patch, F);
+        __syncthreads();
+    }
+}
+
+// Backward with the same MFMA recompute (so the arg-max of the pooling window is the forward's) and the 9 tap sums
+// G[c][tap] = sum_pixels dz[pixel][c] * x_tap[pixel] as a second MFMA: A = x taps (row = tap, k = pixel), B = the routed
+// gradient straight out of the accumulator registers (lane = channel, k = pixel in the register order - the A operand reads
+// its pixels from the LDS patch in that same order).
+__global__ __launch_bounds__(256, 3) void conv1_bwd_mfma_kernel(const float* __restrict__ img, const float* __restrict__ w,
+                                                             const float* __restrict__ bias, const float* __restrict__ scale,
+                                                             const float* __restrict__ shift, const float* __restrict__ mean,
+                                                             const float* __restrict__ rstd, const float* __restrict__ dP,
+                                                             const float* __restrict__ dxl, float inv_To, float* __restrict__ accg,
+                                                             int N, int F, int T) {
+    extern __shared__ __attribute__((aligned(16))) float patch[];
+    __shared__ float red[4][64][11];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, half = lane >> 5, l31 = lane & 31;
+    const int To = T / 2, Fo = F / 2;
+    Vec8<bf16> wb[2];
+    float b[2], sc[2], sh[2], mu[2], rs[2], dbeta[2] = {0.f, 0.f}, dgamma[2] = {0.f, 0.f};
+    f32x16 G[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int c = 32 * j + l31;
+        wb[j] = stem_weights(w, c, half);
+        b[j] = bias[c]; sc[j] = scale[c]; sh[j] = shift[c]; mu[j] = mean[c]; rs[j] = rstd[c];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) G[j][r] = 0.f;
+    }
+    const int pp = l31 >> 2, df = (l31 >> 1) & 1, dt = l31 & 1;
+    const int tap = l31, kh = tap / 3, kw = tap - 3 * kh;               // A2 row of this lane (taps >= 9: zero rows)
+    // pooled gradients of this lane's 2 channels x 4 pooled pixels of one (item, tile)
+    auto fetch_gp = [&](int it, int tile, float (&gp)[2][4]) {
+        const int n = it / To, tp = it - n * To;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int fpo = tile * 8 + 2 * q + half;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                float g = 0.f;
+                if (fpo < Fo) {
+                    g = dP[(((long)n * To + tp) * Fo + fpo) * 64 + 32 * j + l31];
+                    if (dxl) g += dxl[(long)n * Fo * 64 + fpo * 64 + 32 * j + l31] * inv_To;
+                }
+                gp[j][q] = g;
+            }
+        }
+    };
+    PatchRegs pre;
+    int item = blockIdx.x;
+    float gp[2][4];
+    if (item < N * To) { pre.fetch(img, item / To, item % To, F, T); pre.put(patch, F); }
+    __syncthreads();
+    for (; item < N * To; item += gridDim.x) {
+        const int nxt = item + gridDim.x;
+        if (nxt < N * To) pre.fetch(img, nxt / To, nxt % To, F, T);
+        for (int tile = wv; tile * 8 < Fo; tile += 4) {
+            fetch_gp(item, tile, gp);
+            const int fp = min(tile * 8 + pp, Fo - 1);
+            const Vec8<bf16> a = stem_taps(patch, 2 * fp + df, dt, half);
+            // x taps as the A operand of the G product: element jj of k-step st is pixel 16 st + (jj & 3) + 8 (jj >> 2) + 4 half
+            // (hi + lo splitting of both operands was tried: the weight-gradient error of this flavour comes from pooling
+            // windows whose arg-max differs from the fp32 convolution's, not from the rounding of the tap sums)
+            Vec8<bf16> xh[2];
+#pragma unroll
+            for (int st = 0; st < 2; ++st) {
+                xh[st] = Vec8<bf16>::zero();
+                if (tap < 9) {
+#pragma unroll
+                    for (int jj = 0; jj < 8; ++jj) {
+                        const int pix = 16 * st + (jj & 3) + 8 * (jj >> 2) + 4 * half;
+                        const int fpx = min(tile * 8 + (pix >> 2), Fo - 1), wp = pix & 3;
+                        xh[st].v[jj] = (bf16)patch[(2 * fpx + (wp >> 1) + kh) * 4 + (wp & 1) + kw];
+                    }
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                f32x16 acc;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.v, wb[j].v, acc, 0, 0, 0);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    int best = 0;
+                    float ybest = acc[4 * q] + b[j];
+                    float m = sc[j] * ybest + sh[j];
+#pragma unroll
+                    for (int r3 = 1; r3 < 4; ++r3) {
+                        const float y = acc[4 * q + r3] + b[j], z = sc[j] * y + sh[j];
+                        if (z > m) { m = z; best = r3; ybest = y; }
+                    }
+                    const float da = m > 0.f ? gp[j][q] : 0.f;
+                    dbeta[j] += da;
+                    dgamma[j] += da * (ybest - mu[j]) * rs[j];
+#pragma unroll
+                    for (int r3 = 0; r3 < 4; ++r3) acc[4 * q + r3] = (r3 == best) ? da : 0.f;          // routed gradient dz
+                }
+#pragma unroll
+                for (int st = 0; st < 2; ++st) {
+                    Vec8<bf16> gh;
+#pragma unroll
+                    for (int jj = 0; jj < 8; ++jj) gh.v[jj] = (bf16)acc[8 * st + jj];
+                    G[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh[st].v, gh.v, G[j], 0, 0, 0);
+                }
+            }
+        }
+        __syncthreads();
+        if (nxt < N * To) pre.put(patch, F);
+        __syncthreads();
+    }
+    // G[j][r]: row (tap) = (r & 3) + 8 (r >> 2) + 4 half, column = channel 32 j + l31
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int c = 32 * j + l31;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int t = (r & 3) + 8 * (r >> 2) + 4 * half;
+            if (t < 9) red[wv][c][t] = G[j][r];
+        }
+        const float db = dbeta[j] + __shfl_xor(dbeta[j], 32, 64), dg = dgamma[j] + __shfl_xor(dgamma[j], 32, 64);
+        if (half == 0) { red[wv][c][9] = db; red[wv][c][10] = dg; }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 64 * 11; i += 256) {
+        const int c = i / 11, k = i - c * 11;
+        atomicAdd(&accg[(blockIdx.x & 31) * 704 + i], red[0][c][k] + red[1][c][k] + red[2][c][k] + red[3][c][k]);
+    }
+}
+
 __global__ void conv1_bwd_finalize_kernel(const float* __restrict__ acc, const double* __restrict__ mom,
                                           const float* __restrict__ w, const float* __restrict__ bias,
                                           const float* __restrict__ gamma, const float* __restrict__ mean,
@@ -293,9 +512,11 @@ extern "C" int audiossl_conv1_stats(const float* img, int N, int F, int T, const
     ASSL_REQUIRE(img && w && bias && gamma && beta && mom && scale && shift && save_mean && save_rstd);
     ASSL_REQUIRE(N > 0 && F >= 2 && T >= 2);
     hipStream_t s = static_cast<hipStream_t>(stream);
-    if (hipMemsetAsync(mom, 0, sizeof(double) * NMOM, s) != hipSuccess) return ASSL_ELAUNCH;
+    if (hipMemsetAsync(mom, 0, sizeof(double) * NMOM * MOM_REPL, s) != hipSuccess) return ASSL_ELAUNCH;
     const long total = (long)N * F * T;
-    const int grid = (int)min((long)2048, (total + 255) / 256);
+    // every workgroup ends with 54 fp64 atomics; on ONE set of 54 addresses they serialise at the memory side (2048
+    // workgroups: a 116 us launch) - MOM_REPL replicas of the accumulator, folded by the finalize kernel
+    const int grid = (int)min((long)1024, (total + 255) / 256);
     hipLaunchKernelGGL(conv1_moments_kernel, dim3(grid), dim3(256), 0, s, img, mom, N, F, T);
     hipLaunchKernelGGL(conv1_finalize_kernel, dim3(1), dim3(64), 0, s, mom, w, bias, gamma, beta, running_mean,
                        running_var, momentum, eps, (double)total, scale, shift, save_mean, save_rstd);
@@ -305,32 +526,40 @@ extern "C" int audiossl_conv1_stats(const float* img, int N, int F, int T, const
 extern "C" int audiossl_conv1_fwd(int dtype, const float* img, int N, int F, int T, const float* w, const float* bias,
                                   const float* scale, const float* shift, void* out, void* stream) {
     ASSL_REQUIRE(img && w && bias && scale && shift && out && N > 0 && F >= 2 && F <= 126 && T >= 2 && (F % 2) == 0);
-    ASSL_REQUIRE(dtype == 0 || dtype == 1);
+    ASSL_REQUIRE(dtype == 0 || dtype == 1 || dtype == 2);
     hipStream_t s = static_cast<hipStream_t>(stream);
     const int grid = min(N * (T / 2), 2048);
     const size_t lds = sizeof(float) * (F + 2) * 4;
     if (dtype == 0)
         hipLaunchKernelGGL(conv1_fwd_kernel<float>, dim3(grid), dim3(256), lds, s, img, w, bias, scale, shift,
                            static_cast<float*>(out), N, F, T);
-    else
+    else if (dtype == 2)
         hipLaunchKernelGGL(conv1_fwd_kernel<bf16>, dim3(grid), dim3(256), lds, s, img, w, bias, scale, shift,
+                           static_cast<bf16*>(out), N, F, T);
+    else
+        hipLaunchKernelGGL(conv1_fwd_mfma_kernel, dim3(grid), dim3(256), lds, s, img, w, bias, scale, shift,
                            static_cast<bf16*>(out), N, F, T);
     ASSL_LAUNCH_CHECK();
 }
 
 // acc: 32*64*11 floats of scratch (zeroed here).  dxl may be null.  Grad outputs are accumulated (+=).
-extern "C" int audiossl_conv1_bwd(int dtype, const float* img, int N, int F, int T, const float* w, const float* bias,
+extern "C" int audiossl_conv1_bwd(int dtype, int conv_dtype, const float* img, int N, int F, int T, const float* w, const float* bias,
                                   const float* gamma, const float* scale, const float* shift, const float* mean,
                                   const float* rstd, const double* mom, const void* dP, const void* dxl, float* acc,
                                   float* dW, float* dbias, float* dgamma, float* dbeta, void* stream) {
     ASSL_REQUIRE(img && w && bias && gamma && scale && shift && mean && rstd && mom && dP && acc && dW && dgamma && dbeta);
     ASSL_REQUIRE(N > 0 && F >= 2 && F <= 64 && T >= 2 && (F % 2) == 0 && (dtype == 0 || dtype == 1));
+    ASSL_REQUIRE(conv_dtype == 0 || (conv_dtype == 1 && dtype == 0));     // the MFMA recompute takes fp32 gradients
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (hipMemsetAsync(acc, 0, sizeof(float) * 32 * 64 * 11, s) != hipSuccess) return ASSL_ELAUNCH;
-    const int grid = min(N * (T / 2), 2048);
+    static const int bwd_grid = getenv("AUDIOSSL_CONV1_BWD_GRID") ? atoi(getenv("AUDIOSSL_CONV1_BWD_GRID")) : 2048;
+    const int grid = min(N * (T / 2), bwd_grid);
     const size_t lds = sizeof(float) * (F + 2) * 4;
     const float inv_To = 1.f / (float)(T / 2);
-    if (dtype == 0)
+    if (conv_dtype == 1)
+        hipLaunchKernelGGL(conv1_bwd_mfma_kernel, dim3(grid), dim3(256), lds, s, img, w, bias, scale, shift, mean, rstd,
+                           static_cast<const float*>(dP), static_cast<const float*>(dxl), inv_To, acc, N, F, T);
+    else if (dtype == 0)
         hipLaunchKernelGGL(conv1_bwd_kernel<float>, dim3(grid), dim3(256), lds, s, img, w, bias, scale, shift, mean, rstd,
                            static_cast<const float*>(dP), static_cast<const float*>(dxl), inv_To, acc, N, F, T);
     else

@@ -206,7 +206,7 @@ def encoder_forward(P, x, dtype, keep=None, p_drop=0.3, train=True, update_runni
     b1 = P["features_1.0.bias"]
     g1, be1 = P["features_1.1.weight"], P["features_1.1.bias"]
     if train:
-        c.mom1 = _empty((54,), torch.float64, like=x)
+        c.mom1 = _empty((16 * 54,), torch.float64, like=x)         # 16 replicas of the 54 tap moments; totals end up in [0:54]
         c.sc1, c.sh1, c.mean1, c.rstd1 = (_empty((64,), torch.float32, like=x) for _ in range(4))
         N.call("conv1_stats", img, Nimg, F, T, w1, b1, g1, be1, P["features_1.1.running_mean"] if update_running else None,
                P["features_1.1.running_var"] if update_running else None, BN_MOMENTUM, BN_EPS, c.mom1, c.sc1, c.sh1, c.mean1,
@@ -215,7 +215,9 @@ def encoder_forward(P, x, dtype, keep=None, p_drop=0.3, train=True, update_runni
         c.sc1, c.sh1 = _bn_eval(x, 64, g1, be1, P["features_1.1.running_mean"], P["features_1.1.running_var"])
     T1, F1 = T // 2, F // 2
     c.P1 = _empty((Nimg, T1, F1, 64), td, like=x)
-    N.call("conv1_fwd", dtype, img, Nimg, F, T, w1, b1, c.sc1, c.sh1, c.P1)
+    # bf16: the stem conv is a bf16 MFMA; bf16_hp keeps the fp32 VALU convolution (exact pooling arg-max) with bf16 output
+    c.stem_mfma = dtype == N.BF16 and not HP
+    N.call("conv1_fwd", dtype if (dtype == N.F32 or c.stem_mfma) else 2, img, Nimg, F, T, w1, b1, c.sc1, c.sh1, c.P1)
     col = _col_buffer(dtype, Nimg, T1, F1, x)
     bn2 = (P["features_2.1.weight"], P["features_2.1.bias"], P["features_2.1.running_mean"], P["features_2.1.running_var"])
     c.Y2, c.P2, c.st2, c.W2f, c.W2d = _conv_block_fwd(dtype, c.P1, Nimg, T1, F1, P["features_2.0.weight"],
@@ -319,7 +321,7 @@ def encoder_backward(c, G, dA2=None, dH2=None, dx1=None, dx2=None, dx3=None):
                           G["features_2.1.weight"], G["features_2.1.bias"], True, col, keep)
     acc = _empty((32 * 64 * 11,), torch.float32, like=c.H2)
     P = c.P
-    N.call("conv1_bwd", GD, c.img, Nimg, c.F, c.T, P["features_1.0.weight"].reshape(64, 9), P["features_1.0.bias"],
+    N.call("conv1_bwd", GD, int(c.stem_mfma), c.img, Nimg, c.F, c.T, P["features_1.0.weight"].reshape(64, 9), P["features_1.0.bias"],
            P["features_1.1.weight"], c.sc1, c.sh1, c.mean1, c.rstd1, c.mom1, dP1, dx1, acc,
            G["features_1.0.weight"].view(64, 9), G["features_1.0.bias"], G["features_1.1.weight"], G["features_1.1.bias"])
     WGRAD.join(dev)            # dA2 / dA1 / dY* stay referenced until the side stream is ordered before us

@@ -75,17 +75,21 @@ int audiossl_aug_plan_host(uint32_t* np_key, int* np_pos, uint32_t* py_key, int*
 int audiossl_mask_fill(float* x, const int* tab, int n_img, int max_masks, int F, int T, int zero_fill, void* stream);
 
 /* ---- K6 stem: src/encoder/audiontt.py:46-50 (features_1) ------------------------------------------------
- * conv1_stats: batch statistics of Conv2d(1,64,3,p=1) output from 54 tap moments (`mom`, fp64 scratch, kept for
- *   the backward); updates running stats; writes scale = gamma*rstd, shift = beta - mean*scale, mean, rstd.
+ * conv1_stats: batch statistics of Conv2d(1,64,3,p=1) output from 54 tap moments (`mom`: 16 x 54 doubles of scratch, the
+ *   totals are left in mom[0..53] for the backward); updates running stats; writes scale = gamma*rstd, shift = beta - mean*scale, mean, rstd.
  * conv1_fwd : img [N][F][T] f32 -> pooled [N][T/2][F/2][64] (dtype), conv recomputed, nothing else stored.
  * conv1_bwd : dP (+ dxl [N][F/2*64] / (T/2), may be NULL) -> dW [64][9], dgamma, dbeta (dbias == 0); acc = 32*704
- *             floats of scratch. */
+ *             floats of scratch.
+ * dtype 0: fp32 VALU convolution, fp32 output (validation path); dtype 2 (forward only): the same convolution, bf16 output
+ * (`bf16_hp`).  dtype 1 (forward) / conv_dtype 1 (backward, fp32 gradients): the conv
+ * is a bf16 MFMA (taps x weights, K = 9 padded to 16) and so are the nine tap sums of the weight gradient; forward and
+ * backward must use the same flavour so the pooling arg-max agrees. */
 int audiossl_conv1_stats(const float* img, int N, int F, int T, const float* w, const float* bias, const float* gamma,
                          const float* beta, float* running_mean, float* running_var, float momentum, float eps,
                          double* mom, float* scale, float* shift, float* save_mean, float* save_rstd, void* stream);
 int audiossl_conv1_fwd(int dtype, const float* img, int N, int F, int T, const float* w, const float* bias,
                        const float* scale, const float* shift, void* out, void* stream);
-int audiossl_conv1_bwd(int dtype, const float* img, int N, int F, int T, const float* w, const float* bias,
+int audiossl_conv1_bwd(int dtype, int conv_dtype, const float* img, int N, int F, int T, const float* w, const float* bias,
                        const float* gamma, const float* scale, const float* shift, const float* mean, const float* rstd,
                        const double* mom, const void* dP, const void* dxl, float* acc, float* dW, float* dbias,
                        float* dgamma, float* dbeta, void* stream);
