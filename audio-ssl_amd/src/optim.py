@@ -12,6 +12,7 @@ class HipSGD(torch.optim.Optimizer):
         self.grad_scale = grad_scale
         self.grad_scale_tensor = None      # optional device scalar multiplied in (loss.backward(g))
         self.steps = 0
+        self._early = {}                   # id(flat group) -> first element already stepped by step_tail() this step
 
     @torch.no_grad()
     def step(self, closure=None):
@@ -20,9 +21,30 @@ class HipSGD(torch.optim.Optimizer):
             first = fg.momentum is None
             if first:
                 fg.momentum = torch.empty_like(fg.data)
-            N.call("sgd_momentum", fg.data, fg.grad, fg.momentum, fg.numel, float(g0["lr"]), float(g0["momentum"]),
-                   float(g0["weight_decay"]), int(first), float(self.grad_scale), self.grad_scale_tensor)
+            lo, hi = 0, fg.numel
+            done = self._early.pop(id(fg), None)
+            if done is not None:                      # [done, numel) was already stepped by step_tail() during this step
+                hi = done
+            if hi > lo:
+                N.call("sgd_momentum", fg.data[lo:hi], fg.grad[lo:hi], fg.momentum[lo:hi], hi - lo, float(g0["lr"]),
+                       float(g0["momentum"]), float(g0["weight_decay"]), int(first), float(self.grad_scale), self.grad_scale_tensor)
         self.steps += 1
+
+    @torch.no_grad()
+    def step_tail(self, fg, start):
+        """Step the slice [start, numel) of one flat group now, on the current stream; the next step() covers the rest.
+        Used by the fused experts to update the loss-head parameters (83 % of delores_m's buffer) as soon as their
+        gradients are final, underneath the encoder backward, instead of in the serial tail of the step."""
+        if fg.momentum is None or start >= fg.numel or start % 64:
+            return False
+        g0 = self.param_groups[0]
+        N.call("sgd_momentum", fg.data[start:], fg.grad[start:], fg.momentum[start:], fg.numel - start, float(g0["lr"]),
+               float(g0["momentum"]), float(g0["weight_decay"]), 0, float(self.grad_scale), self.grad_scale_tensor)
+        return True
+
+    def mark_early(self, fg, start):
+        """Host-side bookkeeping for step_tail (kept separate: a replayed graph re-issues the launch, not this)."""
+        self._early[id(fg)] = start
 
     def zero_grad(self, set_to_none=True):
         for fg in self.flat_groups:

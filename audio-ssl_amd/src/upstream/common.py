@@ -175,6 +175,8 @@ class GraphedStep:
         self.calls = 0
         self.graph = None
         self.phases = None                 # GraphPhases of the data-parallel variant
+        import inspect
+        self._takes_optimizer = "optimizer" in inspect.signature(expert.fused_loss).parameters
         self.key = None
         self.replays = 0
 
@@ -183,8 +185,11 @@ class GraphedStep:
         return tuple((k, g[k]) for k in sorted(g) if k != "params" and isinstance(g[k], (int, float)))
 
     def _eager(self, img_1, img_2, runner=None):
-        loss = self.expert.fused_loss(img_1, img_2, True) if runner is None else \
-            self.expert.fused_loss(img_1, img_2, True, runner=runner)
+        kw = {} if runner is None else {"runner": runner}
+        if self._takes_optimizer:
+            kw["optimizer"] = self.opt                 # lets the expert step finished parameter segments early
+        self.opt.grad_scale_tensor = None
+        loss = self.expert.fused_loss(img_1, img_2, True, **kw)
         self.expert.all_reduce_grads()             # no-op on one rank
         self.opt.grad_scale_tensor = None
         self.opt.step()

@@ -68,7 +68,7 @@ class Upstream_Expert(MocoQueueMixin, FusedExpertMixin, UpstreamModule):
         return named
 
     # ------------------------------------------------------------------ fused step
-    def fused_loss(self, img_q, img_k, need_grad=True, parts=None, runner=None):
+    def fused_loss(self, img_q, img_k, need_grad=True, parts=None, runner=None, optimizer=None):
         """Forward + backward of the whole step.  The work is written as collective-free *phases* (query encoder, key
         encoder, loss heads, encoder backward) handed to `runner`: the default runs them in place; the data-parallel
         graph step captures each one into a hipGraph (common.GraphPhases).  Collectives sit between the phases."""
@@ -165,13 +165,26 @@ class Upstream_Expert(MocoQueueMixin, FusedExpertMixin, UpstreamModule):
         for d in dys:
             if d is not None:
                 d.record_stream(main)
+        early = None
         if need_grad:
             self.reduce_begin("heads")                      # p1-p3 gradients complete: their all-reduce overlaps the encoder bwd
+            if optimizer is not None and not ddp and hasattr(optimizer, "step_tail"):
+                # single rank: the head parameters can be updated right now, on a side stream under the encoder backward
+                # (nothing reads the fp32 head weights or their gradients again in this step)
+                early = streams[0]
+                early.wait_stream(main)
+                with torch.cuda.stream(early):
+                    if R.phase("sgd_heads", lambda: optimizer.step_tail(flat, self.head_offset())):
+                        optimizer.mark_early(flat, self.head_offset())
+                    else:
+                        early = None
 
             def backward_phase():
                 E.encoder_backward(cq, G("encoder_q.encoder."), dA2=dA2, dx1=dys[0], dx2=dys[1], dx3=dys[2])
                 return loss.sum()
             total = R.phase("encoder_bwd", backward_phase)
+            if early is not None:
+                main.wait_stream(early)
             self.reduce_begin("enc")
         else:
             total = loss.sum()
