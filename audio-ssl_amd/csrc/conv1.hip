@@ -354,19 +354,33 @@ __global__ __launch_bounds__(256) void conv1_fwd_mfma_kernel(const float* __rest
 // G[c][tap] = sum_pixels dz[pixel][c] * x_tap[pixel] as a second MFMA: A = x taps (row = tap, k = pixel), B = the routed
 // gradient straight out of the accumulator registers (lane = channel, k = pixel in the register order - the A operand reads
 // its pixels from the LDS patch in that same order).
+template <bool SLAB>
 __global__ __launch_bounds__(256, 3) void conv1_bwd_mfma_kernel(const float* __restrict__ img, const float* __restrict__ w,
                                                              const float* __restrict__ bias, const float* __restrict__ scale,
                                                              const float* __restrict__ shift, const float* __restrict__ mean,
                                                              const float* __restrict__ rstd, const float* __restrict__ dP,
                                                              const float* __restrict__ dxl, float inv_To, float* __restrict__ accg,
                                                              int N, int F, int T) {
-    extern __shared__ __attribute__((aligned(16))) float patch[];
+    // SLAB (n_mels = 64): the item's 8 KB slab of pooled gradients [32 rows][64 ch] fp32 is DMA'd straight into LDS
+    // (global_load_lds, no registers) one item ahead - with three workgroups per CU the per-lane loads it replaces left
+    // ~0.6 TB/s of reads in flight.  Dynamic LDS: two slabs, then the input patch.
+    extern __shared__ __attribute__((aligned(1024))) float dyn[];
+    float* const patch = dyn + (SLAB ? 2 * 2048 : 0);
     __shared__ float red[4][64][11];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, half = lane >> 5, l31 = lane & 31;
     const int To = T / 2, Fo = F / 2;
     Vec8<bf16> wb[2];
     float b[2], sc[2], sh[2], mu[2], rs[2], dbeta[2] = {0.f, 0.f}, dgamma[2] = {0.f, 0.f};
     f32x16 G[2];
+    auto slab_dma = [&](int it, int slot) {
+        typedef __attribute__((address_space(1))) const void* gptr_t;
+        typedef __attribute__((address_space(3))) void* lptr_t;
+        const float* src = dP + (long)it * Fo * 64;                       // (n, tp) items are contiguous [Fo][64] slabs
+#pragma unroll
+        for (int k = 0; k < 2; ++k)
+            __builtin_amdgcn_global_load_lds((gptr_t)(src + (k * 4 + wv) * 256 + lane * 4),
+                                             (lptr_t)(dyn + slot * 2048 + (k * 4 + wv) * 256), 16, 0, 0);
+    };
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         const int c = 32 * j + l31;
@@ -378,7 +392,20 @@ __global__ __launch_bounds__(256, 3) void conv1_bwd_mfma_kernel(const float* __r
     const int pp = l31 >> 2, df = (l31 >> 1) & 1, dt = l31 & 1;
     const int tap = l31, kh = tap / 3, kw = tap - 3 * kh;               // A2 row of this lane (taps >= 9: zero rows)
     // pooled gradients of this lane's 2 channels x 4 pooled pixels of one (item, tile)
-    auto fetch_gp = [&](int it, int tile, float (&gp)[2][4]) {
+    // dxl term (gradient of the layer-mean output, [N][Fo*64], shared by all time columns) of one (item, tile)
+    const float* dxp = dxl ? dxl : dP;                                  // no branch in the loop: a null dxl reads (and ignores) dP
+    const float dxs = dxl ? inv_To : 0.f;
+    auto fetch_dxl = [&](int it, int tile, float (&gx)[2][4]) {
+        const int n = it / To;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int fpo = min(tile * 8 + 2 * q + half, Fo - 1);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) gx[j][q] = dxp[(long)n * Fo * 64 + fpo * 64 + 32 * j + l31];    // raw: scaled at use
+        }
+    };
+    // pooled gradients of this lane's 2 channels x 4 pooled pixels of one (item, tile)
+    auto fetch_gp = [&](int it, int tile, int slot, const float (&gx)[2][4], float (&gp)[2][4]) {
         const int n = it / To, tp = it - n * To;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
@@ -386,24 +413,34 @@ __global__ __launch_bounds__(256, 3) void conv1_bwd_mfma_kernel(const float* __r
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
                 float g = 0.f;
-                if (fpo < Fo) {
-                    g = dP[(((long)n * To + tp) * Fo + fpo) * 64 + 32 * j + l31];
-                    if (dxl) g += dxl[(long)n * Fo * 64 + fpo * 64 + 32 * j + l31] * inv_To;
-                }
+                if (fpo < Fo)
+                    g = (SLAB ? dyn[slot * 2048 + fpo * 64 + 32 * j + l31]
+                              : dP[(((long)n * To + tp) * Fo + fpo) * 64 + 32 * j + l31]) + gx[j][q] * dxs;
                 gp[j][q] = g;
             }
         }
     };
     PatchRegs pre;
     int item = blockIdx.x;
-    float gp[2][4];
-    if (item < N * To) { pre.fetch(img, item / To, item % To, F, T); pre.put(patch, F); }
-    __syncthreads();
-    for (; item < N * To; item += gridDim.x) {
+    float gp[2][4], gx[2][4], gxn[2][4];
+    if (item < N * To) {
+        pre.fetch(img, item / To, item % To, F, T);
+        pre.put(patch, F);
+        if (SLAB) { fetch_dxl(item, wv, gx); slab_dma(item, 0); }
+    }
+    __syncthreads();                                                    // (drains the first slab's DMA as well)
+    int slot = 0;
+    for (; item < N * To; item += gridDim.x, slot ^= 1) {
         const int nxt = item + gridDim.x;
-        if (nxt < N * To) pre.fetch(img, nxt / To, nxt % To, F, T);
+        if (nxt < N * To) {
+            // everything for the NEXT item is requested here and consumed after the barrier that ends this one: no
+            // register-destination load is waited for in between (hipcc drains vmcnt to 0 for those, DMA included)
+            pre.fetch(img, nxt / To, nxt % To, F, T);
+            if (SLAB) { fetch_dxl(nxt, wv, gxn); slab_dma(nxt, slot ^ 1); }
+        }
         for (int tile = wv; tile * 8 < Fo; tile += 4) {
-            fetch_gp(item, tile, gp);
+            if (!SLAB) fetch_dxl(item, tile, gx);
+            fetch_gp(item, tile, slot, gx, gp);
             const int fp = min(tile * 8 + pp, Fo - 1);
             const Vec8<bf16> a = stem_taps(patch, 2 * fp + df, dt, half);
             // x taps as the A operand of the G product: element jj of k-step st is pixel 16 st + (jj & 3) + 8 (jj >> 2) + 4 half
@@ -455,6 +492,12 @@ __global__ __launch_bounds__(256, 3) void conv1_bwd_mfma_kernel(const float* __r
         }
         __syncthreads();
         if (nxt < N * To) pre.put(patch, F);
+        if (SLAB) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) gx[j][q] = gxn[j][q];
+        }
         __syncthreads();
     }
     // G[j][r]: row (tap) = (r & 3) + 8 (r >> 2) + 4 half, column = channel 32 j + l31
@@ -556,8 +599,11 @@ extern "C" int audiossl_conv1_bwd(int dtype, int conv_dtype, const float* img, i
     const int grid = min(N * (T / 2), bwd_grid);
     const size_t lds = sizeof(float) * (F + 2) * 4;
     const float inv_To = 1.f / (float)(T / 2);
-    if (conv_dtype == 1)
-        hipLaunchKernelGGL(conv1_bwd_mfma_kernel, dim3(grid), dim3(256), lds, s, img, w, bias, scale, shift, mean, rstd,
+    if (conv_dtype == 1 && F == 64)
+        hipLaunchKernelGGL(conv1_bwd_mfma_kernel<true>, dim3(grid), dim3(256), lds + 2 * 2048 * sizeof(float), s, img, w, bias, scale,
+                           shift, mean, rstd, static_cast<const float*>(dP), static_cast<const float*>(dxl), inv_To, acc, N, F, T);
+    else if (conv_dtype == 1)
+        hipLaunchKernelGGL(conv1_bwd_mfma_kernel<false>, dim3(grid), dim3(256), lds, s, img, w, bias, scale, shift, mean, rstd,
                            static_cast<const float*>(dP), static_cast<const float*>(dxl), inv_To, acc, N, F, T);
     else if (dtype == 0)
         hipLaunchKernelGGL(conv1_bwd_kernel<float>, dim3(grid), dim3(256), lds, s, img, w, bias, scale, shift, mean, rstd,
