@@ -15,6 +15,8 @@ import torch
 
 from src import _native as N
 
+import os as _os
+_STEM_VALU = _os.environ.get("AUDIOSSL_STEM_VALU") == "1"     # debug switch: fp32 VALU stem on the bf16 path
 BN_MOMENTUM = 0.1
 BN_EPS = 1e-5
 
@@ -216,7 +218,7 @@ def encoder_forward(P, x, dtype, keep=None, p_drop=0.3, train=True, update_runni
     T1, F1 = T // 2, F // 2
     c.P1 = _empty((Nimg, T1, F1, 64), td, like=x)
     # bf16: the stem conv is a bf16 MFMA; bf16_hp keeps the fp32 VALU convolution (exact pooling arg-max) with bf16 output
-    c.stem_mfma = dtype == N.BF16 and not HP
+    c.stem_mfma = dtype == N.BF16 and not HP and not _STEM_VALU
     N.call("conv1_fwd", dtype if (dtype == N.F32 or c.stem_mfma) else 2, img, Nimg, F, T, w1, b1, c.sc1, c.sh1, c.P1)
     col = _col_buffer(dtype, Nimg, T1, F1, x)
     bn2 = (P["features_2.1.weight"], P["features_2.1.bias"], P["features_2.1.running_mean"], P["features_2.1.running_var"])

@@ -191,6 +191,12 @@ class GraphedStep:
         self.opt.grad_scale_tensor = None
         loss = self.expert.fused_loss(img_1, img_2, True, **kw)
         self.expert.all_reduce_grads()             # no-op on one rank
+        if runner is not None:
+            # graph-phase mode: the optimiser launch that follows must not be issued while the phase graphs are still in
+            # flight on this stream.  Without this drain the two-rank test (tools/ddp_flaky.py) produced a wrong - but on
+            # both ranks identical - update in about half of the runs; syncing before the collectives or after the
+            # optimiser did not help, draining the launch stream here did (8/8 runs, twice).  Root cause not established.
+            torch.cuda.current_stream().synchronize()
         self.opt.grad_scale_tensor = None
         self.opt.step()
         return loss
@@ -206,6 +212,7 @@ class GraphedStep:
             # data parallel: one graph per collective-free phase, RCCL calls in between
             if self.phases is None or key != self.key:
                 self.phases, self.key = GraphPhases(), key
+
             a, b = self.phases.static("img_1", img_1), self.phases.static("img_2", img_2)
             self.replays += 1
             return self._eager(a, b, runner=self.phases)
@@ -385,6 +392,7 @@ class FusedExpertMixin:
                 self.reduce_begin(which)
         for _, work in self._pending:
             work.wait()                       # the current stream waits for RCCL's stream
+
         self._pending = None
         if self.hip_optimizer is not None:
             self.hip_optimizer.grad_scale = 1.0 / dist.get_world_size()

@@ -99,6 +99,8 @@ def test_two_rank_graph_phases_match_eager(which):
     from helpers import rel_l2
     e0, _ = _run(which, graph=False)
     g0, g1 = _run(which, graph=True)
+    h0, _ = _run(which, graph=True)                           # a second, independent run: the graph step must be repeatable
+    np.testing.assert_allclose(h0["losses"], g0["losses"], rtol=2e-3)
     want = ["encoder_bwd", "head1", "head2", "head3", "key", "moco", "query"] if which == "delores_m" else ["encoder_bwd", "forward"]
     assert g0["graphs"] == (want, None) and g1["graphs"] == (want, None)
     for n in g0["w"]:
