@@ -290,10 +290,10 @@ extern "C" int audiossl_colstats(int dtype, const void* x, int groups, long M, i
     hipStream_t s = static_cast<hipStream_t>(stream);
     const size_t nb = sizeof(double) * C * groups;
     if (want_sq && sumsq == sum + (size_t)C * groups) {            // contiguous scratch: one memset node
-        if (hipMemsetAsync(sum, 0, 2 * nb, s) != hipSuccess) return ASSL_ELAUNCH;
+        ASSL_ZERO(sum, 2 * nb, s);
     } else {
-        if (hipMemsetAsync(sum, 0, nb, s) != hipSuccess) return ASSL_ELAUNCH;
-        if (want_sq && hipMemsetAsync(sumsq, 0, nb, s) != hipSuccess) return ASSL_ELAUNCH;
+        ASSL_ZERO(sum, nb, s);
+        if (want_sq) ASSL_ZERO(sumsq, nb, s);
     }
     const int slabs = C / 64;
     long it = (M * slabs * groups + 32L * 2048 - 1) / (32L * 2048);  // aim for ~2048 blocks in total, 1..128 iterations each
@@ -357,7 +357,7 @@ extern "C" int audiossl_bn_relu_pool_bwd(int dtype, int ydtype, int gdtype, cons
     ASSL_REQUIRE(N > 0 && Ti >= 2 && Fi >= 2 && (Fi % 2) == 0 && (dtype == 0 || dtype == 1) && (gdtype == 0 || gdtype == dtype));
     ASSL_REQUIRE(ydtype == 0 || ydtype == dtype);
     hipStream_t s = static_cast<hipStream_t>(stream);
-    if (hipMemsetAsync(stat, 0, sizeof(float) * 128 * 33, s) != hipSuccess) return ASSL_ELAUNCH;
+    ASSL_ZERO(stat, sizeof(float) * 128 * 33, s);
     const long total = (long)N * ((Ti + 1) / 2) * (Fi / 2) * 8;
     const int grid = ceil_div(total, 256);
     const float inv_To = 1.f / (float)(Ti / 2);

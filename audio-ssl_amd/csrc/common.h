@@ -11,6 +11,13 @@
 
 #define ASSL_REQUIRE(cond) do { if (!(cond)) return ASSL_EINVAL; } while (0)
 #define ASSL_ALIGNED16(p) ((((uintptr_t)(p)) & 15) == 0)
+// Scratch zeroing.  Entry points that accumulate into caller-provided scratch zero it themselves - unless the caller has
+// declared (audiossl_set_prezeroed) that every scratch pointer it passes is already zero: the fused training step takes all
+// of them from one arena cleared by a single memset, which removes ~30 tiny memset nodes from the step's graph.
+extern int g_assl_prezeroed;
+#define ASSL_ZERO(ptr, bytes, s) \
+    do { if (!g_assl_prezeroed && hipMemsetAsync((ptr), 0, (bytes), (s)) != hipSuccess) return ASSL_ELAUNCH; } while (0)
+
 #define ASSL_LAUNCH_CHECK() do { if (hipGetLastError() != hipSuccess) return ASSL_ELAUNCH; return ASSL_OK; } while (0)
 
 typedef __bf16 bf16;

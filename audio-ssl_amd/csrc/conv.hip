@@ -288,10 +288,10 @@ extern "C" int audiossl_conv3x3_fwd(const void* X, const void* W, const float* b
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (sum) {
         if (sumsq == sum + 64) {
-            if (hipMemsetAsync(sum, 0, sizeof(double) * 128, s) != hipSuccess) return ASSL_ELAUNCH;
+            ASSL_ZERO(sum, sizeof(double) * 128, s);
         } else {
-            if (hipMemsetAsync(sum, 0, sizeof(double) * 64, s) != hipSuccess) return ASSL_ELAUNCH;
-            if (hipMemsetAsync(sumsq, 0, sizeof(double) * 64, s) != hipSuccess) return ASSL_ELAUNCH;
+            ASSL_ZERO(sum, sizeof(double) * 64, s);
+            ASSL_ZERO(sumsq, sizeof(double) * 64, s);
         }
     }
     const int rows = N * Ti, TT = 256 / Fi, tiles = (rows + TT - 1) / TT;

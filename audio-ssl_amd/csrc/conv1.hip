@@ -555,7 +555,7 @@ extern "C" int audiossl_conv1_stats(const float* img, int N, int F, int T, const
     ASSL_REQUIRE(img && w && bias && gamma && beta && mom && scale && shift && save_mean && save_rstd);
     ASSL_REQUIRE(N > 0 && F >= 2 && T >= 2);
     hipStream_t s = static_cast<hipStream_t>(stream);
-    if (hipMemsetAsync(mom, 0, sizeof(double) * NMOM * MOM_REPL, s) != hipSuccess) return ASSL_ELAUNCH;
+    ASSL_ZERO(mom, sizeof(double) * NMOM * MOM_REPL, s);
     const long total = (long)N * F * T;
     // every workgroup ends with 54 fp64 atomics; on ONE set of 54 addresses they serialise at the memory side (2048
     // workgroups: a 116 us launch) - MOM_REPL replicas of the accumulator, folded by the finalize kernel
@@ -594,7 +594,7 @@ extern "C" int audiossl_conv1_bwd(int dtype, int conv_dtype, const float* img, i
     ASSL_REQUIRE(N > 0 && F >= 2 && F <= 64 && T >= 2 && (F % 2) == 0 && (dtype == 0 || dtype == 1));
     ASSL_REQUIRE(conv_dtype == 0 || (conv_dtype == 1 && dtype == 0));     // the MFMA recompute takes fp32 gradients
     hipStream_t s = static_cast<hipStream_t>(stream);
-    if (hipMemsetAsync(acc, 0, sizeof(float) * 32 * 64 * 11, s) != hipSuccess) return ASSL_ELAUNCH;
+    ASSL_ZERO(acc, sizeof(float) * 32 * 64 * 11, s);
     static const int bwd_grid = getenv("AUDIOSSL_CONV1_BWD_GRID") ? atoi(getenv("AUDIOSSL_CONV1_BWD_GRID")) : 2048;
     const int grid = min(N * (T / 2), bwd_grid);
     const size_t lds = sizeof(float) * (F + 2) * 4;

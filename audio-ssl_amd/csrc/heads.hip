@@ -362,6 +362,9 @@ __global__ __launch_bounds__(256) void dropout_mask_kernel(uint8_t* __restrict__
 
 }  // namespace
 
+int g_assl_prezeroed = 0;
+extern "C" int audiossl_set_prezeroed(int on) { g_assl_prezeroed = on ? 1 : 0; return ASSL_OK; }
+
 #define S_(stream) static_cast<hipStream_t>(stream)
 #define GRID1(n) dim3((unsigned)(((long)(n) + 255) / 256))
 
@@ -406,7 +409,7 @@ extern "C" int audiossl_colbn_bwd(int dtype, int adtype, int gdtype, const void*
     ASSL_REQUIRE(a && dh && scale && shift && mean && rstd && tmp && da && groups > 0 && M > 0 && C > 0 && (C % 8) == 0);
     ASSL_REQUIRE((dtype == 0 || dtype == 1) && (C % 64) == 0 && (gdtype == 0 || gdtype == dtype) && (adtype == 0 || adtype == dtype));
     hipStream_t s = S_(stream);
-    if (hipMemsetAsync(tmp, 0, sizeof(double) * 2 * C * groups, s) != hipSuccess) return ASSL_ELAUNCH;
+    ASSL_ZERO(tmp, sizeof(double) * 2 * C * groups, s);
     const int rpb = M >= 4096 ? 256 : 64;
     dim3 grid(ceil_div(M, rpb), C / 64, groups);
     const long total = groups * M * C / 8;

@@ -52,6 +52,55 @@ def _empty(shape, dtype, like=None, device=None):
     return torch.empty(shape, dtype=dtype, device=device if device is not None else like.device)
 
 
+class ZeroArena:
+    """Zero-initialised scratch for one fused training step.  The entry points that accumulate into caller-provided scratch
+    (column / tap statistics, split-K targets, atomically reduced partials) each used to clear it with their own memset:
+    ~30 tiny nodes per step, which cost more on the launch side of a graph replay (~15 us of host time per node) than on
+    the GPU.  Inside `with ARENA.step(device):` every such buffer is a slice of one persistent buffer cleared by ONE memset,
+    and the library is told to skip its own (`audiossl_set_prezeroed`)."""
+
+    def __init__(self, nbytes=8 << 20):
+        self.nbytes, self.buf, self.off, self.active = nbytes, None, 0, False
+
+    def step(self, device):
+        arena = self
+
+        class _Ctx:
+            def __enter__(self_):
+                if arena.buf is None or arena.buf.device != device:
+                    arena.buf = torch.empty(arena.nbytes, dtype=torch.uint8, device=device)
+                arena.off, arena.active = 0, True
+                arena.buf.zero_()
+                N.call_host("set_prezeroed", 1)
+
+            def __exit__(self_, *exc):
+                arena.active = False
+                N.call_host("set_prezeroed", 0)
+                return False
+        return _Ctx()
+
+    def zeros(self, shape, dtype, like=None, device=None):
+        """A zeroed tensor: an arena slice inside a step, `torch.zeros` otherwise (or when the arena is exhausted)."""
+        dev = device if device is not None else like.device
+        if self.active and self.buf.device == dev:
+            n = 1
+            for d in (shape if isinstance(shape, (tuple, list)) else (shape,)):
+                n *= int(d)
+            nb = n * torch.empty((), dtype=dtype).element_size()
+            if self.off + nb <= self.nbytes:
+                t = self.buf[self.off:self.off + nb].view(dtype).view(shape)
+                self.off += (nb + 255) // 256 * 256
+                return t
+        return torch.zeros(shape, dtype=dtype, device=dev)
+
+    def scratch(self, shape, dtype, like):
+        """Scratch that the callee clears itself unless it has been told the caller did: zeroed inside a step, raw outside."""
+        return self.zeros(shape, dtype, like=like) if self.active else _empty(shape, dtype, like=like)
+
+
+ARENA = ZeroArena()
+
+
 def _ksplit(M, Nn, K, target=256):
     tiles = ((M + 127) // 128) * ((Nn + 127) // 128)
     ks = max(1, min(target // max(tiles, 1), (K + 127) // 128))
@@ -113,7 +162,7 @@ def pooled_dtype(dtype):
 
 def colsum_add(dtype, X, M, C, dst, tmp=None):
     """dst[C] += column sums of X [M,C]"""
-    tmp = tmp if tmp is not None else _empty((C,), torch.float64, like=X)
+    tmp = tmp if tmp is not None else ARENA.scratch((C,), torch.float64, X)
     N.call("colstats", dtype, X, 1, M, C, C, 0, tmp, None)
     N.call("add_d2f", tmp, dst, C)
 
@@ -135,7 +184,7 @@ class EncoderCtx:
 
 def _bn_train(dtype, Y, M, C, gamma, beta, rm, rv, update_running, groups=1):
     """Batch statistics of Y [groups][M][C] -> per-group (scale, shift, mean, rstd), each [groups*C]."""
-    sq = _empty((2, groups * C), torch.float64, like=Y)
+    sq = ARENA.scratch((2, groups * C), torch.float64, Y)
     N.call("colstats", dtype, Y, groups, M, C, C, 1, sq[0], sq[1])
     st = _empty((4, groups * C), torch.float32, like=Y)
     N.call("bn_finalize", sq[0], sq[1], groups, float(M), C, gamma, beta, rm if update_running else None,
@@ -160,7 +209,7 @@ def _conv_block_fwd(dtype, Pin, Nimg, Ti, Fi, W, bias, bn, train, update_running
     Y = _empty((M, 64), N.torch_dtype(ad), like=Pin)          # BatchNorm input: fp32 on the fp32 and bf16_hp paths
     gamma, beta, rm, rv = bn
     fused = dtype == N.BF16 and Fi in (16, 32)
-    sq = _empty((2, 64), torch.float64, like=Pin) if (fused and train) else None
+    sq = ARENA.scratch((2, 64), torch.float64, Pin) if (fused and train) else None
     if fused:
         N.call("conv3x3_fwd", Pin, Wf, bias, Y, int(ad == N.F32), None if sq is None else sq[0], None if sq is None else sq[1],
                Nimg, Ti, Fi)
@@ -208,7 +257,7 @@ def encoder_forward(P, x, dtype, keep=None, p_drop=0.3, train=True, update_runni
     b1 = P["features_1.0.bias"]
     g1, be1 = P["features_1.1.weight"], P["features_1.1.bias"]
     if train:
-        c.mom1 = _empty((16 * 54,), torch.float64, like=x)         # 16 replicas of the 54 tap moments; totals end up in [0:54]
+        c.mom1 = ARENA.scratch((16 * 54,), torch.float64, x)         # 16 replicas of the 54 tap moments; totals end up in [0:54]
         c.sc1, c.sh1, c.mean1, c.rstd1 = (_empty((64,), torch.float32, like=x) for _ in range(4))
         N.call("conv1_stats", img, Nimg, F, T, w1, b1, g1, be1, P["features_1.1.running_mean"] if update_running else None,
                P["features_1.1.running_var"] if update_running else None, BN_MOMENTUM, BN_EPS, c.mom1, c.sc1, c.sh1, c.mean1,
@@ -260,19 +309,19 @@ def _conv_block_bwd(dtype, Y, dP, dxl, st, Nimg, Ti, Fi, Pin, Wd, G_w, G_gamma, 
     scale, shift, mean, rstd = st
     M = Nimg * Ti * Fi
     dY = torch.empty((M, 64), dtype=td, device=Y.device)
-    stat = _empty((33 * 128,), torch.float32, like=Y)
+    stat = ARENA.scratch((33 * 128,), torch.float32, Y)
     N.call("bn_relu_pool_bwd", dtype, N.F32 if Y.dtype == torch.float32 else dtype, GD, Y, dP, dxl, scale, shift, mean, rstd, stat, dY, G_gamma, G_beta, Nimg, Ti, Fi)
     # wgrad: dWp[co][tap*64+ci] = sum_pix dY[pix][co] * Pin[pix + off(tap)][ci]
     fused = dtype == N.BF16 and Fi in (16, 32)
     if fused:
         def wg():
-            dWp = torch.zeros(64, 576, dtype=torch.float32, device=Y.device)
+            dWp = ARENA.zeros((64, 576), torch.float32, device=Y.device)
             N.call("conv3x3_wgrad", dY, Pin, dWp, Nimg, Ti, Fi)
             N.call("unpack_conv_dw", dWp, G_w)
             return dWp
         keep.append((dY, WGRAD.run(Y.device, wg)))             # off the critical path
     else:
-        dWp = torch.zeros(64, 576, dtype=torch.float32, device=Y.device)
+        dWp = ARENA.zeros((64, 576), torch.float32, device=Y.device)
         N.call("im2col3x3", dtype, Pin, col, Nimg, Ti, Fi)
         gemm(dtype, 1, 1, 64, 576, M, dY, 64, col, 576, dWp, 576, out_f32=1, atomic=1, ksplit=_ksplit(64, 576, M, 1024))
         N.call("unpack_conv_dw", dWp, G_w)
@@ -321,7 +370,7 @@ def encoder_backward(c, G, dA2=None, dH2=None, dx1=None, dx2=None, dx3=None):
                           G["features_3.1.weight"], G["features_3.1.bias"], True, col, keep)
     dP1 = _conv_block_bwd(dtype, c.Y2, dP2, dx2, c.st2, Nimg, T1, F1, c.P1, c.W2d, G["features_2.0.weight"],
                           G["features_2.1.weight"], G["features_2.1.bias"], True, col, keep)
-    acc = _empty((32 * 64 * 11,), torch.float32, like=c.H2)
+    acc = ARENA.scratch((32 * 64 * 11,), torch.float32, c.H2)
     P = c.P
     N.call("conv1_bwd", GD, int(c.stem_mfma), c.img, Nimg, c.F, c.T, P["features_1.0.weight"].reshape(64, 9), P["features_1.0.bias"],
            P["features_1.1.weight"], c.sc1, c.sh1, c.mean1, c.rstd1, c.mom1, dP1, dx1, acc,
@@ -408,19 +457,20 @@ def projector_backward(c, PP, G, dzn, dy_rows=None):
     dtype, B, D, kin, groups = c.dtype, c.B, c.D, c.kin, c.groups
     M = groups * B
     td = N.torch_dtype(dtype)
-    tmp = _empty((2 * groups * D,), torch.float64, like=dzn)
+    def tmp():                                   # one fresh (zeroed) statistics scratch per BatchNorm backward
+        return ARENA.scratch((2 * groups * D,), torch.float64, dzn)
     dz = _empty((M, D), td, like=c.zn)
     # gradients entering a BatchNorm backward (dzn, dh2, dh1) are fp32 GEMM outputs; its outputs (dz, da2, da1) are
     # MFMA operands only and are stored in the activation dtype
-    N.call("colbn_bwd", dtype, c.ad, GD, c.z, dzn, *c.st0, 0, groups, B, D, tmp, dz, None, None)
+    N.call("colbn_bwd", dtype, c.ad, GD, c.z, dzn, *c.st0, 0, groups, B, D, tmp(), dz, None, None)
     linear_bwd_w(dtype, dz, c.h2, G["projector.6.weight"], M, D, D)
     dh2 = linear_bwd_x(dtype, dz, c.W[2], M, D, D, out_f32=1)
     da2 = _empty((M, D), td, like=c.zn)
-    N.call("colbn_bwd", dtype, c.ad, GD, c.a2, dh2, *c.st2, 1, groups, B, D, tmp, da2, G["projector.4.weight"], G["projector.4.bias"])
+    N.call("colbn_bwd", dtype, c.ad, GD, c.a2, dh2, *c.st2, 1, groups, B, D, tmp(), da2, G["projector.4.weight"], G["projector.4.bias"])
     linear_bwd_w(dtype, da2, c.h1, G["projector.3.weight"], M, D, D)
     dh1 = linear_bwd_x(dtype, da2, c.W[1], M, D, D, out_f32=1)
     da1 = _empty((M, D), td, like=c.zn)
-    N.call("colbn_bwd", dtype, c.ad, GD, c.a1, dh1, *c.st1, 1, groups, B, D, tmp, da1, G["projector.1.weight"], G["projector.1.bias"])
+    N.call("colbn_bwd", dtype, c.ad, GD, c.a1, dh1, *c.st1, 1, groups, B, D, tmp(), da1, G["projector.1.weight"], G["projector.1.bias"])
     linear_bwd_w(dtype, da1, c.y_hi, G["projector.0.weight"], M, D, kin)
     if c.y_lo is not None:
         linear_bwd_w(dtype, da1, c.y_lo, G["projector.0.weight"], M, D, kin)
@@ -480,7 +530,7 @@ def moco_forward_backward(dtype, q, k, queue, queue_shadow, temperature, loss_ou
     Pm = _empty((B, K), td, like=q)
     dlpos = _empty((B,), torch.float32, like=q)
     N.call("moco_ce_bwd", dtype, lpos, lneg, lse, B, K, 1.0 / (B * temperature), Pm, dlpos)
-    dqn = torch.zeros(B, dim, dtype=torch.float32, device=q.device)
+    dqn = ARENA.zeros((B, dim), torch.float32, device=q.device)
     gemm(dtype, 0, 0, B, dim, K, Pm, K, queue_shadow, K, dqn, dim, out_f32=1, atomic=1, ksplit=_ksplit(B, dim, K, 256))
     dq = _empty((B, dim), td, like=q)
     N.call("l2norm_bwd", dtype, dqn, dlpos, kn32, qn32, qinv, B, dim, dq)

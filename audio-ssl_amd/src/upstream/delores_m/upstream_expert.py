@@ -69,6 +69,10 @@ class Upstream_Expert(MocoQueueMixin, FusedExpertMixin, UpstreamModule):
 
     # ------------------------------------------------------------------ fused step
     def fused_loss(self, img_q, img_k, need_grad=True, parts=None, runner=None, optimizer=None):
+        with E.ARENA.step(img_q.device):          # every zero-initialised scratch of the step: one arena, one memset
+            return self._fused_loss(img_q, img_k, need_grad, parts, runner, optimizer)
+
+    def _fused_loss(self, img_q, img_k, need_grad, parts, runner, optimizer):
         """Forward + backward of the whole step.  The work is written as collective-free *phases* (query encoder, key
         encoder, loss heads, encoder backward) handed to `runner`: the default runs them in place; the data-parallel
         graph step captures each one into a hipGraph (common.GraphPhases).  Collectives sit between the phases."""

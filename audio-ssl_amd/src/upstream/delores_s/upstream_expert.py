@@ -46,6 +46,10 @@ class Upstream_Expert(FusedExpertMixin, UpstreamModule):
 
     # ------------------------------------------------------------------ fused step
     def fused_loss(self, img_1, img_2, need_grad=True, runner=None):
+        with E.ARENA.step(img_1.device):          # every zero-initialised scratch of the step: one arena, one memset
+            return self._fused_loss(img_1, img_2, need_grad, runner)
+
+    def _fused_loss(self, img_1, img_2, need_grad, runner):
         """Forward + backward of the step as two collective-free phases (see common.GraphPhases): both views through the
         encoder + the Barlow head, then the encoder backward; the gradient all-reduces start between / after them."""
         R = runner or EAGER

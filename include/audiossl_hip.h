@@ -170,6 +170,10 @@ int audiossl_enqueue(int dtype, const float* keys, int B, int D, int K, int ptr,
                      void* stream);
 int audiossl_ema_update(float* pk, const float* pq, long n, float m, void* stream);
 
+/* Host-side switch: 1 = every scratch pointer handed to the entry points below is already zero (the caller cleared its whole
+ * scratch arena with one memset), so they skip their own hipMemsetAsync; 0 (default) = they zero their scratch themselves. */
+int audiossl_set_prezeroed(int on);
+
 /* ---- K17 optimiser + plumbing: delores_s/upstream_expert.py:236-243 (torch.optim.SGD) ---------------------- */
 int audiossl_sgd_momentum(float* p, const float* g, float* buf, long n, float lr, float momentum, float weight_decay,
                           int first, float grad_scale, const float* grad_scale_dev, void* stream);
