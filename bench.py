@@ -135,11 +135,13 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", 0))
     if world != args.gpus and world == 1 and args.gpus > 1:
         raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
+    if os.environ.get("AUDIOSSL_SHARE_GPU") == "1":                # rehearsal of the N > 1 path on a one-GPU box: every rank on
+        local = 0                                                  # cuda:0, gloo transport (RCCL refuses two ranks per device)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world)
+        dist.init_process_group(os.environ.get("AUDIOSSL_DIST_BACKEND", "nccl"), rank=rank, world_size=world)
 
     from src import _native as N
     from src.augmentations import AugmentationModule
