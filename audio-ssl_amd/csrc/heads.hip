@@ -150,6 +150,15 @@ __global__ __launch_bounds__(256) void colbn_bwd_apply_kernel(const TA* __restri
     }
     const Vec8<TA> va = Vec8<TA>::load(a + idx * 8);
     const Vec8<TG> vg = Vec8<TG>::load(dh + idx * 8);
+    // the eight per-column constants as vector loads (they were 6 scalar loads per element)
+    const Vec8<float> vsc = Vec8<float>::load(scale + c8 * 8), vsh = Vec8<float>::load(shift + c8 * 8);
+    const Vec8<float> vmu = Vec8<float>::load(mean + c8 * 8), vrs = Vec8<float>::load(rstd + c8 * 8);
+    double dsg[8], dsx[8];
+#pragma unroll
+    for (int i = 0; i < 8; i += 2) {
+        const double2 p = *reinterpret_cast<const double2*>(sg + c8 * 8 + i), q = *reinterpret_cast<const double2*>(sgx + c8 * 8 + i);
+        dsg[i] = p.x; dsg[i + 1] = p.y; dsx[i] = q.x; dsx[i + 1] = q.y;
+    }
     Vec8<T_> o;
     const float invM = 1.f / (float)M;
 #pragma unroll
@@ -157,10 +166,10 @@ __global__ __launch_bounds__(256) void colbn_bwd_apply_kernel(const TA* __restri
         const int c = c8 * 8 + i;
         const float x = va.get(i);
         float g = vg.get(i);
-        if (relu && !(scale[c] * x + shift[c] > 0.f)) g = 0.f;
-        const float xhat = (x - mean[c]) * rstd[c];
-        const float mg = (float)sg[c] * invM, mgx = (float)sgx[c] * invM;
-        o.set(i, scale[c] * (g - mg - xhat * mgx));
+        if (relu && !(vsc.get(i) * x + vsh.get(i) > 0.f)) g = 0.f;
+        const float xhat = (x - vmu.get(i)) * vrs.get(i);
+        const float mg = (float)dsg[i] * invM, mgx = (float)dsx[i] * invM;
+        o.set(i, vsc.get(i) * (g - mg - xhat * mgx));
         if (row == 0 && dgamma) { atomicAdd(&dgamma[c], (float)sgx[c]); atomicAdd(&dbeta[c], (float)sg[c]); }
     }
     o.store(da + idx * 8);
@@ -177,13 +186,19 @@ template <typename T_>
 __global__ __launch_bounds__(256) void barlow_loss_kernel(const float* __restrict__ c, int D, float coef, float dscale,
                                                           T_* __restrict__ dc, float* __restrict__ loss_out) {
     __shared__ float sh[16];
-    const long total = (long)D * D;
+    const int total8 = D * (D / 8);                     // 8 consecutive columns of one row per thread and trip (D % 8 == 0)
     float acc = 0.f;
-    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
-        const int i = (int)(idx / D), j = (int)(idx - (long)i * D);
-        const float v = c[idx] - (i == j ? 1.f : 0.f);
-        acc += v * v;
-        dc[idx] = from_f32<T_>(dscale * v);
+    for (int v = blockIdx.x * 256 + threadIdx.x; v < total8; v += gridDim.x * 256) {
+        const int i = v / (D / 8), j0 = (v - i * (D / 8)) * 8;
+        const Vec8<float> x = Vec8<float>::load(c + (long)v * 8);
+        Vec8<T_> o;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const float d = x.get(k) - (i == j0 + k ? 1.f : 0.f);
+            acc += d * d;
+            o.set(k, dscale * d);
+        }
+        o.store(dc + (long)v * 8);
     }
     acc = block_sum(acc, sh);
     if (threadIdx.x == 0) atomicAdd(loss_out, coef * acc);
@@ -436,8 +451,9 @@ extern "C" int audiossl_add_d2f(const double* src, float* dst, int n, void* stre
 
 extern "C" int audiossl_barlow_loss(int dtype, const float* c, int D, float coef, float dscale, void* dc, float* loss_out,
                                     void* stream) {
-    ASSL_REQUIRE(c && dc && loss_out && D > 0 && (dtype == 0 || dtype == 1));
-    const int grid = min(2048, ceil_div((long)D * D, 256));
+    ASSL_REQUIRE(c && dc && loss_out && D > 0 && (D % 8) == 0 && D <= 16384 && (dtype == 0 || dtype == 1));
+    if (!ASSL_ALIGNED16(c) || !ASSL_ALIGNED16(dc)) return ASSL_EALIGN;
+    const int grid = min(512, ceil_div((long)D * (D / 8), 256));
     if (dtype == 0) hipLaunchKernelGGL(barlow_loss_kernel<float>, dim3(grid), dim3(256), 0, S_(stream), c, D, coef, dscale, (float*)dc, loss_out);
     else            hipLaunchKernelGGL(barlow_loss_kernel<bf16>, dim3(grid), dim3(256), 0, S_(stream), c, D, coef, dscale, (bf16*)dc, loss_out);
     ASSL_LAUNCH_CHECK();
