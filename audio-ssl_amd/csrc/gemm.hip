@@ -188,11 +188,10 @@ struct Stage {
 };
 
 template <typename T, bool TA, bool TB, int BK, int MI>
-__global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
+__device__ __forceinline__ void gemm_body(const GemmArgs& g, char* smem) {
     constexpr int BMv = 64 * MI;                                 // 128 x 128 tile (MI = 2) or 64 x 128 (MI = 1: twice the
     using SA = Stage<T, TA, BK, BMv>;                            // workgroups for grids that would leave CUs idle)
     using SB = Stage<T, TB, BK, BN>;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
     T* const ldsA0 = reinterpret_cast<T*>(smem);                 // two A buffers, then two B buffers
     T* const ldsB0 = ldsA0 + 2 * SA::LDS_ELEMS;
 
@@ -254,6 +253,40 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
     }
 
     epilogue_lds<T, MI>(g, acc, smem, bm + wm, bn + wn, lane, wave);
+}
+
+template <typename T, bool TA, bool TB, int BK, int MI>
+__global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    gemm_body<T, TA, TB, BK, MI>(g, smem);
+}
+
+// Several independent problems of one kind in ONE launch (blockIdx.y = problem): the three Barlow heads of delores_m run
+// the same chain of GEMMs on different operands; issued as separate launches on separate streams they were serialised by
+// the hardware-queue mapping of the graph executor (1.6 ms of a 3.3 ms step), and each launch filled half the chip at best.
+constexpr int MAX_MULTI = 4;
+struct GemmMulti { GemmArgs p[MAX_MULTI]; };
+
+template <typename T, bool TA, bool TB, int BK, int MI>
+__global__ __launch_bounds__(256) void gemm_multi_kernel(GemmMulti gm) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const GemmArgs& g = gm.p[blockIdx.y];
+    const int tiles = ((g.M + 64 * MI - 1) / (64 * MI)) * ((g.N + BN - 1) / BN);
+    if ((int)blockIdx.x >= tiles) return;
+    gemm_body<T, TA, TB, BK, MI>(g, smem);
+}
+
+template <typename T, bool TA, bool TB, int BK, int MI>
+int launch_multi(const GemmMulti& gm, int count, int max_tiles, int ksplit, hipStream_t s) {
+    const size_t lds = max(sizeof(T) * 2 * (Stage<T, TA, BK, 64 * MI>::LDS_ELEMS + Stage<T, TB, BK, BN>::LDS_ELEMS), EPI_LDS);
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_multi_kernel<T, TA, TB, BK, MI>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return ASSL_ELAUNCH;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((gemm_multi_kernel<T, TA, TB, BK, MI>), dim3(max_tiles, count, ksplit), dim3(256), lds, s, gm);
+    ASSL_LAUNCH_CHECK();
 }
 
 template <typename T, bool TA, bool TB, int BK, int MI>
@@ -401,6 +434,42 @@ int dispatch(const GemmArgs& g, int ta, int tb, hipStream_t s) {
 }
 
 }  // namespace
+
+extern "C" int audiossl_gemm_multi(int count, int trans_a, int trans_b, int M, int N, const int* K, float alpha,
+                                   const void* const* A, const long* lda, const void* const* B, const long* ldb,
+                                   void* const* C, long ldc, int out_f32, int atomic, int ksplit, void* stream) {
+    ASSL_REQUIRE(count >= 1 && count <= MAX_MULTI && K && A && B && C && lda && ldb && M > 0 && N > 0 && ksplit >= 1);
+    ASSL_REQUIRE(!atomic || out_f32);
+    ASSL_REQUIRE(ksplit == 1 || atomic);
+    GemmMulti gm;
+    int kmin = 1 << 30;
+    for (int i = 0; i < count; ++i) {
+        ASSL_REQUIRE(A[i] && B[i] && C[i] && K[i] > 0);
+        ASSL_REQUIRE((trans_a ? M : K[i]) % 8 == 0 && (trans_b ? N : K[i]) % 8 == 0);
+        if (!ASSL_ALIGNED16(A[i]) || !ASSL_ALIGNED16(B[i]) || lda[i] % 8 || ldb[i] % 8) return ASSL_EALIGN;
+        const long a_ext = (trans_a ? ((long)(K[i] - 1) * lda[i] + M) : ((long)(M - 1) * lda[i] + K[i])) * 2;
+        const long b_ext = (trans_b ? ((long)(K[i] - 1) * ldb[i] + N) : ((long)(N - 1) * ldb[i] + K[i])) * 2;
+        ASSL_REQUIRE(a_ext < 0xFFFFFF00L && b_ext < 0xFFFFFF00L);
+        gm.p[i] = GemmArgs{A[i], B[i], C[i], M, N, K[i], lda[i], ldb[i], ldc, alpha, nullptr, 0, nullptr, 0, 1.f, nullptr, 0,
+                           out_f32, atomic, ksplit, nullptr, 0, (unsigned)a_ext, (unsigned)b_ext};
+        kmin = min(kmin, K[i]);
+    }
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const long blocks = (long)ceil_div(M, BM) * ceil_div(N, BN) * ksplit * count;
+    const bool small = blocks <= 128 && M > 64;
+    const int max_tiles = ceil_div(M, small ? 64 : BM) * ceil_div(N, BN);
+#define MULTI(BK_, MI_)                                                                                   \
+    do {                                                                                                  \
+        if (!trans_a && !trans_b) return launch_multi<bf16, false, false, BK_, MI_>(gm, count, max_tiles, ksplit, s); \
+        if (!trans_a && trans_b) return launch_multi<bf16, false, true, BK_, MI_>(gm, count, max_tiles, ksplit, s);   \
+        if (trans_a && trans_b) return launch_multi<bf16, true, true, BK_, MI_>(gm, count, max_tiles, ksplit, s);     \
+        return launch_multi<bf16, true, false, BK_, MI_>(gm, count, max_tiles, ksplit, s);                            \
+    } while (0)
+    if (small) MULTI(64, 1);
+    if (blocks <= 256 && kmin >= 512) MULTI(128, 2);
+    MULTI(64, 2);
+#undef MULTI
+}
 
 // dtype: 0 = fp32 operands (exact f32 MFMA), 1 = bf16 operands.  See include/audiossl_hip.h.
 extern "C" int audiossl_gemm(int dtype, int trans_a, int trans_b, int M, int N, int K, float alpha,

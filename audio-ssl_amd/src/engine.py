@@ -507,6 +507,104 @@ def barlow_forward_backward(PP, G, Y, dtype, lambd, scale_loss, loss_out, need_d
     return projector_backward(c, PP, G, dzn, rows)
 
 
+# =============================================================================================== several Barlow heads at once
+def gemm_multi(ta, tb, M, Nn, Ks, As, ldas, Bs, ldbs, Cs, ldc, alpha=1.0, out_f32=0, atomic=0, ksplit=1):
+    """One launch for len(As) independent bf16 problems with common M, N, ldc, transposes and epilogue (audiossl_gemm_multi)."""
+    import ctypes
+    n = len(As)
+    for t in list(As) + list(Bs) + list(Cs):
+        if not t.is_cuda or not t.is_contiguous():
+            raise RuntimeError("gemm_multi needs contiguous device tensors")
+    vp = lambda ts: (ctypes.c_void_p * n)(*[t.data_ptr() for t in ts])
+    li = lambda xs: (ctypes.c_long * n)(*[int(x) for x in xs])
+    K_, A_, B_, C_, la_, lb_ = (ctypes.c_int * n)(*[int(k) for k in Ks]), vp(As), vp(Bs), vp(Cs), li(ldas), li(ldbs)
+    adr = ctypes.addressof
+    N.call("gemm_multi", n, ta, tb, M, Nn, adr(K_), float(alpha), adr(A_), adr(la_), adr(B_), adr(lb_), adr(C_), ldc, out_f32,
+           atomic, ksplit)
+
+
+def barlow_heads_forward_backward(PPs, Gs, Ys, dtype, lambds, scale_losses, loss_outs, update_running=True, backward=True,
+                                  Wcs=None):
+    """`barlow_forward_backward` for several heads in lock-step: every GEMM of the chain is ONE multi-problem launch over the
+    heads (they differ only in the first layer's K), the small BatchNorm / loss kernels are issued per head in between.
+    Ys[h]: [2B, in_h] stacked views; returns dY_h [B, in_h] (gradient of view 1's input) per head, fp32.
+    Not used on the bf16_hp path (split first GEMM) nor with the cross-GPU correlation all-reduce."""
+    nh = len(Ys)
+    B = Ys[0].shape[0] // 2
+    M = 2 * B
+    td = N.torch_dtype(dtype)
+    dev = Ys[0].device
+    W = Wcs if Wcs is not None else [tuple(cast(dtype, PP[f"projector.{i}.weight"]) for i in (0, 3, 6)) for PP in PPs]
+    D = W[0][0].shape[0]
+    kins = [Y.shape[1] for Y in Ys]
+    ad = _ad(dtype)
+    o32 = int(ad == N.F32)
+    tad = torch.float32 if o32 else td
+    H = range(nh)
+
+    def bn(h, a, prefix, affine):
+        PP = PPs[h]
+        return _bn_train(ad, a, B, D, PP[prefix + ".weight"] if affine else None, PP[prefix + ".bias"] if affine else None,
+                         PP[prefix + ".running_mean"], PP[prefix + ".running_var"], update_running, 2)
+
+    def layer(xs, ws, ks, prefix, affine, relu):
+        a = [torch.empty(M, D, dtype=tad, device=dev) for _ in H]
+        gemm_multi(0, 0, M, D, ks, xs, ks, ws, ks, a, D, out_f32=o32)
+        st = [bn(h, a[h], prefix, affine) for h in H]
+        out = [torch.empty(M, D, dtype=td, device=dev) for _ in H]
+        for h in H:
+            N.call("colbn_fwd", dtype, ad, a[h], st[h][0], st[h][1], relu, out[h], 2, B, D)
+        return a, st, out
+    a1, st1, h1 = layer(Ys, [W[h][0] for h in H], kins, "projector.1", True, 1)
+    a2, st2, h2 = layer(h1, [W[h][1] for h in H], [D] * nh, "projector.4", True, 1)
+    z, st0, zn = layer(h2, [W[h][2] for h in H], [D] * nh, "bn", False, 0)
+    # correlation c_h = zn1^T zn2 / B, loss, dc
+    cm = [torch.empty(D, D, dtype=torch.float32, device=dev) for _ in H]
+    gemm_multi(1, 1, D, D, [B] * nh, [zn[h][:B] for h in H], [D] * nh, [zn[h][B:] for h in H], [D] * nh, cm, D,
+               alpha=1.0 / B, out_f32=1)
+    dc = [torch.empty(D, D, dtype=td, device=dev) for _ in H]
+    for h in H:
+        coef = (lambds[h] if lambds[h] else 1.0) * scale_losses[h]
+        N.call("barlow_loss", dtype, cm[h], D, coef, 2.0 * coef / B, dc[h], loss_outs[h])
+    if not backward:
+        return [None] * nh
+    dzn = [torch.empty(M, D, dtype=torch.float32, device=dev) for _ in H]
+    gemm_multi(0, 0, B, D, [D] * nh, [zn[h][B:] for h in H], [D] * nh, dc, [D] * nh, [dzn[h][:B] for h in H], D, out_f32=1)
+    gemm_multi(0, 1, B, D, [D] * nh, [zn[h][:B] for h in H], [D] * nh, dc, [D] * nh, [dzn[h][B:] for h in H], D, out_f32=1)
+
+    def bn_bwd(a, dh, st, relu, names):
+        out = [torch.empty(M, D, dtype=td, device=dev) for _ in H]
+        for h in H:
+            tmp = ARENA.scratch((2 * 2 * D,), torch.float64, dh[h])
+            N.call("colbn_bwd", dtype, ad, GD, a[h], dh[h], *st[h], relu, 2, B, D, tmp, out[h],
+                   Gs[h][names[0]] if names else None, Gs[h][names[1]] if names else None)
+        return out
+
+    def wgrad(dys, xs, name, ks):
+        dWs = [Gs[h][name] for h in H]
+        if len(set(ks)) == 1:
+            gemm_multi(1, 1, D, ks[0], [M] * nh, dys, [D] * nh, xs, ks, dWs, ks[0], out_f32=1, atomic=1,
+                       ksplit=_ksplit(D, ks[0], M, max(256 // nh, 1)))
+        else:                                           # first layer: the heads' input widths (= N of this GEMM) differ
+            for h in H:
+                linear_bwd_w(dtype, dys[h], xs[h], dWs[h], M, D, ks[h])
+
+    def dgrad(dys, ws, K, rows):
+        out = [torch.empty(rows, K, dtype=torch.float32, device=dev) for _ in H]
+        gemm_multi(0, 1, rows, K, [D] * nh, dys, [D] * nh, ws, [K] * nh, out, K, out_f32=1)
+        return out
+    dz = bn_bwd(z, dzn, st0, 0, None)
+    wgrad(dz, h2, "projector.6.weight", [D] * nh)
+    dh2 = dgrad(dz, [W[h][2] for h in H], D, M)
+    da2 = bn_bwd(a2, dh2, st2, 1, ("projector.4.weight", "projector.4.bias"))
+    wgrad(da2, h1, "projector.3.weight", [D] * nh)
+    dh1 = dgrad(da2, [W[h][1] for h in H], D, M)
+    da1 = bn_bwd(a1, dh1, st1, 1, ("projector.1.weight", "projector.1.bias"))
+    wgrad(da1, Ys, "projector.0.weight", kins)
+    # dY for view 1 only (rows [0, B)); widths differ per head
+    return [linear_bwd_x(dtype, da1[h], W[h][0], B, D, kins[h], out_f32=1) for h in H]
+
+
 # =============================================================================================== MoCo head
 def moco_forward_backward(dtype, q, k, queue, queue_shadow, temperature, loss_out, backward=True):
     """q, k: fp32 [B,dim] pre-normalisation embeddings (k carries no gradient).  queue fp32 [dim,K]; queue_shadow the

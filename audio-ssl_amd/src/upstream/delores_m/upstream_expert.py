@@ -53,6 +53,7 @@ class Upstream_Expert(MocoQueueMixin, FusedExpertMixin, UpstreamModule):
         prec = config.get("run", {}).get("precision")
         self.precision = {"fp32": N.F32, "bf16": N.BF16, "bf16_hp": N.BF16}.get(prec, default_precision())
         self.high_precision = prec == "bf16_hp"
+        self.grouped_heads = bool(config.get("run", {}).get("grouped_heads", False))
         self.encoder_q.encoder.precision = self.encoder_k.encoder.precision = self.precision
         self.flat_k = None
         self._key_stream = E.SideStream()
@@ -145,10 +146,26 @@ class Upstream_Expert(MocoQueueMixin, FusedExpertMixin, UpstreamModule):
                                              loss[i + 1:i + 2], need_dy1=True, need_dy2=False,
                                              update_running=self.training, backward=need_grad,
                                              Wc=tuple(Wp[f"projector.{j}.weight"] for j in (0, 3, 6)))
-        for i, p in enumerate((self.p1, self.p2, self.p3)):
-            streams[i].wait_stream(main)
-            with torch.cuda.stream(streams[i]):
-                dys[i] = R.phase(f"head{i + 1}", lambda i=i, p=p: head_phase(i, p))
+        heads = (self.p1, self.p2, self.p3)
+        if self.high_precision or dt == N.F32 or not self.grouped_heads:
+            for i, p in enumerate(heads):
+                streams[i].wait_stream(main)
+                with torch.cuda.stream(streams[i]):
+                    dys[i] = R.phase(f"head{i + 1}", lambda i=i, p=p: head_phase(i, p))
+        else:
+            # run.grouped_heads: the three chains in lock-step on ONE side stream, every GEMM a single multi-problem launch.
+            # Measured (tools/phase_times.py, B=512): one head chain 375 us alone, the three on three streams 1,050 us
+            # (concurrent queues do not overlap here: 1,430 us with 8 hardware queues), grouped 940 us in isolation - but the
+            # whole single-graph step came out slower (3.54 vs 3.27 ms), so the three-stream form stays the default.
+            def heads_phase():
+                Wps = [flat.shadow_dict(f"p{i + 1}.") for i in range(3)]
+                return E.barlow_heads_forward_backward(
+                    [p.param_dict() for p in heads], [G(f"p{i + 1}.") for i in range(3)], Ys, dt, [p.lambd for p in heads],
+                    [p.scale_loss for p in heads], [loss[i + 1:i + 2] for i in range(3)], update_running=self.training,
+                    backward=need_grad, Wcs=[tuple(Wp[f"projector.{j}.weight"] for j in (0, 3, 6)) for Wp in Wps])
+            streams[0].wait_stream(main)
+            with torch.cuda.stream(streams[0]):
+                dys = list(R.phase("heads", heads_phase))
 
         def moco_phase():
             shadow = E.cast(dt, self.queue) if dt != N.F32 else self.queue

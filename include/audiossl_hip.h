@@ -138,6 +138,13 @@ int audiossl_gemm(int dtype, int trans_a, int trans_b, int M, int N, int K, floa
                   float keep_scale, const void* gate, long ldg, int out_f32, int atomic, int ksplit, const float* resid,
                   long ldr, void* stream);
 
+/* `count` (<= 4) independent bf16 problems of one kind in one launch (the three Barlow heads of delores_m): same M, N, ldc,
+ * transposes and epilogue (alpha, fp32 / atomic output, split-K), per-problem K, operand pointers and leading dimensions.
+ * K, A, lda, B, ldb, C are HOST arrays of `count` entries. */
+int audiossl_gemm_multi(int count, int trans_a, int trans_b, int M, int N, const int* K, float alpha, const void* const* A,
+                        const long* lda, const void* const* B, const long* ldb, void* const* C, long ldc, int out_f32,
+                        int atomic, int ksplit, void* stream);
+
 /* ---- encoder tail: delores_s/upstream_encoder.py:26-28 ---------------------------------------------------- */
 int audiossl_maxmean_fwd(int dtype, int out_f32, const void* H, void* y, uint8_t* arg, int N, int Tt, int D, void* stream);
 int audiossl_maxmean_bwd(int dtype, int gdtype, const void* dy, const uint8_t* arg, const void* H, void* dA, int N, int Tt,

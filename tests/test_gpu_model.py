@@ -268,6 +268,37 @@ def test_slicer_steps_vs_reference_golden(golden, cfg_s, prec):
         np.testing.assert_allclose(sd["encoder_q.cluster_projector.2.weight"].cpu().numpy().ravel()[:256], g["wq_cluster"], rtol=5e-3, atol=3e-4)
 
 
+def test_delores_m_grouped_heads_match_per_head_path(cfg_m):
+    """run.grouped_heads (multi-problem GEMM launches over the three Barlow heads) against the default per-head chains:
+    same loss terms and gradients up to fp32 atomic order."""
+    from src.encoder import AudioNTT2020Task6
+    from src.upstream.delores_m.upstream_expert import Upstream_Expert
+    B, T, Tp, K = 16, 96, 12, 256
+    outs = []
+    for grouped in (False, True):
+        cfg = _cfg(cfg_m, "bf16")
+        cfg["run"]["grouped_heads"] = grouped
+        em = Upstream_Expert(cfg, base_encoder=AudioNTT2020Task6, num_negatives=K)
+        fill.fill_state_dict_(em, seed=11)
+        for pq, pk in zip(em.encoder_q.parameters(), em.encoder_k.parameters()):
+            pk.data.copy_(pq.data)
+        em.queue.copy_(closed_queue(128, K))
+        em = em.cuda().train()
+        assert em.grouped_heads == grouped
+        em.encoder_q.encoder.dropout_masks.queue = [drop_mask((B, Tp, 2048), 8902)]
+        em.encoder_k.encoder.dropout_masks.queue = [drop_mask((B, Tp, 2048), 8903)]
+        parts = {}
+        loss = em.fused_loss(views(B, T, 8900).cuda(), views(B, T, 8901).cuda(), True, parts)
+        em.flat.attach_grads()
+        torch.cuda.synchronize()
+        outs.append((parts["losses"].cpu().numpy(), {n: p.grad.float().cpu() for n, p in em.named_parameters() if p.grad is not None}))
+    (l0, g0), (l1, g1) = outs
+    np.testing.assert_allclose(l1, l0, rtol=1e-4)
+    assert set(g0) == set(g1)
+    for n in g0:
+        assert rel_l2(g1[n], g0[n]) < 2e-3, n
+
+
 # ------------------------------------------------------------------------------------------------ hipGraph replay
 @pytest.mark.parametrize("which", ["delores_m", "delores_s"])
 def test_graphed_step_matches_eager(cfg_m, cfg_s, which):
