@@ -101,10 +101,12 @@ class ZeroArena:
 ARENA = ZeroArena()
 
 
-def _ksplit(M, Nn, K, target=256):
+def _ksplit(M, Nn, K, target=512):
+    """Split-K factor of an accumulating (fp32 atomics) GEMM.  Splitting pays only while every workgroup keeps a long K loop
+    (>= 32 steps of 64) and the grid stays within two workgroups per CU: 2048x2048x6144 78 us at 2 vs 93 us unsplit, but
+    2048x2048x1024 28 us unsplit vs 37 / 62 us at 2 / 4 (tools/gemm_floor.py)."""
     tiles = ((M + 127) // 128) * ((Nn + 127) // 128)
-    ks = max(1, min(target // max(tiles, 1), (K + 127) // 128))
-    return int(ks)
+    return int(max(1, min(target // max(tiles, 1), (K // 64) // 32)))
 
 
 def gemm(dtype, ta, tb, M, Nn, K, A, lda, B, ldb, C, ldc, alpha=1.0, bias=None, relu=0, keep=None, ldk=0, keep_scale=1.0,

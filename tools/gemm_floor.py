@@ -41,3 +41,12 @@ C = torch.zeros(M, Nn, device="cuda", dtype=torch.float32)
 for ks, atomic in ((1, 0), (1, 1), (2, 1), (4, 1)):
     us = timeit(lambda: E.gemm(1, 1, 1, M, Nn, K, A, M, B, Nn, C, Nn, out_f32=1, atomic=atomic, ksplit=ks))
     print(f"ksplit={ks} atomic={atomic}   {us:.1f} us", flush=True)
+print("---- TN split-K variants for the long-K weight gradients of the encoder fc layers")
+for M, Nn, K in ((2048, 2048, 6144), (2048, 512, 6144), (2048, 2048, 1024), (2048, 1024, 1024), (2048, 512, 1024)):
+    A = torch.randn(K, M, device="cuda").bfloat16(); B = torch.randn(K, Nn, device="cuda").bfloat16()
+    C = torch.zeros(M, Nn, device="cuda", dtype=torch.float32)
+    row = []
+    for ks in (1, 2, 4, 8):
+        us = timeit(lambda: E.gemm(1, 1, 1, M, Nn, K, A, M, B, Nn, C, Nn, out_f32=1, atomic=1, ksplit=ks), 20)
+        row.append(f"ks={ks}: {us:6.1f}")
+    print(f"TN {M}x{Nn}x{K}  " + "  ".join(row) + f"   (_ksplit -> {E._ksplit(M, Nn, K)})", flush=True)
