@@ -17,6 +17,7 @@
 //   channels transposed per 16-lane group); the 64x576 fp32 result lives in registers (9 accumulators per wave) across
 //   all tiles of the workgroup and is added to global memory once (fp32 atomics, 128-byte runs).
 // Roofline (B=512, block 2): 60.4 GFLOP per pass; algorithmic HBM traffic 105 MB in + 105 MB out.
+#include <cstdlib>
 #include "common.h"
 
 namespace {
@@ -33,41 +34,45 @@ struct ConvArgs {
     int Ti, rows_total, tiles, out_f32;
 };
 
-template <int FI, int PITCH>
+template <int FI, int PITCH, int NTH = 256>
 struct Halo {
     static constexpr int TT = 256 / FI;                         // t-rows per tile
     static constexpr int COLS = FI + 2;
     static constexpr int ELEMS = (TT + 2) * COLS * PITCH;
-    static constexpr int NV = (TT + 2) * FI * 8 / 256;          // 16-byte vectors per thread
+    static constexpr int NV = ((TT + 2) * FI * 8 + NTH - 1) / NTH;   // 16-byte vectors per thread
+    static constexpr int NVEC = (TT + 2) * FI * 8;
     Vec8<bf16> r[NV];
     __device__ __forceinline__ void load(const bf16* __restrict__ X, int g0, int rows_total) {
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
-            const int v = threadIdx.x + i * 256;
+            const int v = threadIdx.x + i * NTH;
             const int row = v / (FI * 8), rem = v % (FI * 8);
             const int gr = g0 - 1 + row;
-            r[i] = (gr >= 0 && gr < rows_total) ? Vec8<bf16>::load(X + ((long)gr * FI) * CH + rem * 8) : Vec8<bf16>::zero();
+            r[i] = (v < NVEC && gr >= 0 && gr < rows_total) ? Vec8<bf16>::load(X + ((long)gr * FI) * CH + rem * 8) : Vec8<bf16>::zero();
         }
     }
     __device__ __forceinline__ void put(bf16* lds) const {
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
-            const int v = threadIdx.x + i * 256;
+            const int v = threadIdx.x + i * NTH;
             const int row = v / (FI * 8), rem = v % (FI * 8);
-            r[i].store(lds + (row * COLS + (rem >> 3) + 1) * PITCH + (rem & 7) * 8);
+            if (v < NVEC) r[i].store(lds + (row * COLS + (rem >> 3) + 1) * PITCH + (rem & 7) * 8);
         }
     }
     __device__ __forceinline__ static void zero_border(bf16* lds) {       // columns 0 and FI+1 of every row
-        for (int i = threadIdx.x; i < (TT + 2) * 2 * 8; i += 256) {
+        for (int i = threadIdx.x; i < (TT + 2) * 2 * 8; i += NTH) {
             const int row = i / 16, side = (i >> 3) & 1, c8 = i & 7;
             Vec8<bf16>::zero().store(lds + (row * COLS + side * (FI + 1)) * PITCH + c8 * 8);
         }
     }
 };
 
-template <int FI>
-__global__ __launch_bounds__(256, 1) void conv3x3_kernel(ConvArgs a) {
-    using H = Halo<FI, PIXP>;
+// NW = 8: 512 threads, one 32-pixel row-tile per wave: two waves per SIMD, so one wave's MFMAs cover the other's LDS reads
+// (with 4 waves the tile took ~15 us against 1.9 us of MFMA work).
+template <int FI, int NW>
+__global__ __launch_bounds__(64 * NW, 1) void conv3x3_kernel(ConvArgs a) {
+    using H = Halo<FI, PIXP, 64 * NW>;
+    constexpr int RT = 8 / NW;                                    // 32-pixel row-tiles per wave
     constexpr int TT = H::TT, COLS = H::COLS;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     bf16* const wl = reinterpret_cast<bf16*>(smem);               // [64][WPITCH]
@@ -76,7 +81,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_kernel(ConvArgs a) {
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int m = lane & 31, h = lane >> 5;
-    for (int v = threadIdx.x; v < CH * KTOT / 8; v += 256) {
+    for (int v = threadIdx.x; v < CH * KTOT / 8; v += 64 * NW) {
         const int row = v / (KTOT / 8), c = v % (KTOT / 8);
         Vec8<bf16>::load(a.W + row * KTOT + c * 8).store(wl + row * WPITCH + c * 8);
     }
@@ -94,11 +99,11 @@ __global__ __launch_bounds__(256, 1) void conv3x3_kernel(ConvArgs a) {
         if (next < a.tiles) halo.load(a.X, next * TT, a.rows_total);
 
         // per-lane geometry of the two 32-pixel row-tiles this wave owns
-        int tl[2], fcol[2];
-        bool ok[2][3];
+        int tl[RT], fcol[RT];
+        bool ok[RT][3];
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int rt = 2 * wave + i;
+        for (int i = 0; i < RT; ++i) {
+            const int rt = RT * wave + i;
             tl[i] = FI == 32 ? rt : 2 * rt + (m >> 4);
             fcol[i] = FI == 32 ? m : (m & 15);
             const int g = g0 + tl[i];
@@ -106,9 +111,9 @@ __global__ __launch_bounds__(256, 1) void conv3x3_kernel(ConvArgs a) {
 #pragma unroll
             for (int dt = 0; dt < 3; ++dt) ok[i][dt] = g < a.rows_total && ti + dt - 1 >= 0 && ti + dt - 1 < a.Ti;
         }
-        f32x16 acc[2][2];
+        f32x16 acc[RT][2];
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < RT; ++i)
 #pragma unroll
             for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -119,16 +124,16 @@ __global__ __launch_bounds__(256, 1) void conv3x3_kernel(ConvArgs a) {
             const int dt = tap % 3, df = tap / 3;                 // tap = kh*3 + kw: kh walks mel (f), kw walks time (t)
 #pragma unroll
             for (int cc = 0; cc < 4; ++cc) {
-                Vec8<bf16> fa[2], fb[2];
+                Vec8<bf16> fa[RT], fb[2];
 #pragma unroll
-                for (int i = 0; i < 2; ++i) {
+                for (int i = 0; i < RT; ++i) {
                     const bf16* p = hl + ((tl[i] + dt) * COLS + fcol[i] + df) * PIXP + cc * 16 + 8 * h;
                     fa[i] = ok[i][dt] ? Vec8<bf16>::load(p) : Vec8<bf16>::zero();
                 }
 #pragma unroll
                 for (int j = 0; j < 2; ++j) fb[j] = Vec8<bf16>::load(wl + (j * 32 + m) * WPITCH + tap * 64 + cc * 16 + 8 * h);
 #pragma unroll
-                for (int i = 0; i < 2; ++i)
+                for (int i = 0; i < RT; ++i)
 #pragma unroll
                     for (int j = 0; j < 2; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i].v, fb[j].v, acc[i][j], 0, 0, 0);
@@ -136,8 +141,8 @@ __global__ __launch_bounds__(256, 1) void conv3x3_kernel(ConvArgs a) {
         }
         // epilogue: C/D map col = lane&31 (channel), row = (r&3) + 8*(r>>2) + 4*h (pixel of the row-tile)
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int rt = 2 * wave + i;
+        for (int i = 0; i < RT; ++i) {
+            const int rt = RT * wave + i;
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
                 const int co = j * 32 + m;
@@ -171,8 +176,9 @@ __global__ __launch_bounds__(256, 1) void conv3x3_kernel(ConvArgs a) {
         __syncthreads();
         if (threadIdx.x < 128) {
             const int c = threadIdx.x >> 1, k = threadIdx.x & 1;
-            const double t = (double)red[(0 * 64 + c) * 2 + k] + (double)red[(1 * 64 + c) * 2 + k] +
-                             (double)red[(2 * 64 + c) * 2 + k] + (double)red[(3 * 64 + c) * 2 + k];
+            double t = 0.0;
+#pragma unroll
+            for (int w = 0; w < NW; ++w) t += (double)red[(w * 64 + c) * 2 + k];
             atomicAdd(k == 0 ? &a.sum[c] : &a.sumsq[c], t);
         }
     }
@@ -298,15 +304,17 @@ extern "C" int audiossl_conv3x3_fwd(const void* X, const void* W, const float* b
     ConvArgs a{static_cast<const bf16*>(X), static_cast<const bf16*>(W), bias, static_cast<bf16*>(Y), sum, sumsq, Ti, rows, tiles, out_f32};
     const int grid = tiles < 256 ? tiles : 256;
     static bool attr32 = false, attr16 = false;
-    if (Fi == 32) {
-        const size_t lds = sizeof(bf16) * (CH * WPITCH + Halo<32, PIXP>::ELEMS);
-        if (!attr32) { if (set_lds(conv3x3_kernel<32>, lds)) return ASSL_ELAUNCH; attr32 = true; }
-        hipLaunchKernelGGL(conv3x3_kernel<32>, dim3(grid), dim3(256), lds, s, a);
-    } else {
-        const size_t lds = sizeof(bf16) * (CH * WPITCH + Halo<16, PIXP>::ELEMS);
-        if (!attr16) { if (set_lds(conv3x3_kernel<16>, lds)) return ASSL_ELAUNCH; attr16 = true; }
-        hipLaunchKernelGGL(conv3x3_kernel<16>, dim3(grid), dim3(256), lds, s, a);
-    }
+    static const int nw = getenv("AUDIOSSL_CONV_WAVES") ? atoi(getenv("AUDIOSSL_CONV_WAVES")) : 8;
+    static bool attr[4] = {false, false, false, false};
+#define CONV_LAUNCH(FI_, NW_, SLOT)                                                                       \
+    do {                                                                                                  \
+        const size_t lds = sizeof(bf16) * (CH * WPITCH + Halo<FI_, PIXP>::ELEMS);                         \
+        if (!attr[SLOT]) { if (set_lds(conv3x3_kernel<FI_, NW_>, lds)) return ASSL_ELAUNCH; attr[SLOT] = true; } \
+        hipLaunchKernelGGL((conv3x3_kernel<FI_, NW_>), dim3(grid), dim3(64 * NW_), lds, s, a);           \
+    } while (0)
+    if (Fi == 32) { if (nw == 8) CONV_LAUNCH(32, 8, 0); else CONV_LAUNCH(32, 4, 1); }
+    else          { if (nw == 8) CONV_LAUNCH(16, 8, 2); else CONV_LAUNCH(16, 4, 3); }
+#undef CONV_LAUNCH
     ASSL_LAUNCH_CHECK();
 }
 
