@@ -188,16 +188,19 @@ struct WgradArgs {
     const bf16* dY; const bf16* X; float* dW; int Ti, rows_total, tiles;
 };
 
-template <int FI>
-__global__ __launch_bounds__(256, 1) void conv3x3_wgrad_kernel(WgradArgs a) {
-    using H = Halo<FI, PIXW>;
+// KG = 2: 8 waves; waves 4-7 take the second half of each tile's pixels (the contraction dimension) with their own 9
+// accumulators - two waves per SIMD overlap LDS reads and MFMAs; both halves end in the same fp32 atomics.
+template <int FI, int KG>
+__global__ __launch_bounds__(256 * KG, 1) void conv3x3_wgrad_kernel(WgradArgs a) {
+    using H = Halo<FI, PIXW, 256 * KG>;
     constexpr int TT = H::TT, COLS = H::COLS;
-    constexpr int NVY = 256 * 8 / 256;                            // 16-byte vectors of the dY tile per thread
+    constexpr int NTH = 256 * KG;
+    constexpr int NVY = 256 * 8 / NTH;                            // 16-byte vectors of the dY tile per thread
     extern __shared__ __attribute__((aligned(16))) char smem[];
     bf16* const yl = reinterpret_cast<bf16*>(smem);               // dY tile [256 pixels][PIXW]
     bf16* const hl = yl + 256 * PIXW;                             // X halo tile
 
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = (threadIdx.x >> 6) & 3, grp = threadIdx.x >> 8;
     const int h = lane >> 5, half = (lane >> 4) & 1, q = (lane & 15) >> 2, p = lane & 3;
     const int cot = wave & 1;                                     // channel-out tile of this wave
     const int n0 = (wave >> 1) * 9;                               // first of its 9 (tap, ci-half) column tiles
@@ -214,7 +217,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wgrad_kernel(WgradArgs a) {
     auto load_y = [&](int g0) {
 #pragma unroll
         for (int i = 0; i < NVY; ++i) {
-            const int v = threadIdx.x + i * 256;                 // pixel = v>>3, chunk = v&7
+            const int v = threadIdx.x + i * NTH;                 // pixel = v>>3, chunk = v&7
             const long pix = (long)g0 * FI + (v >> 3);
             ry[i] = pix < (long)a.rows_total * FI ? Vec8<bf16>::load(a.dY + pix * CH + (v & 7) * 8) : Vec8<bf16>::zero();
         }
@@ -222,7 +225,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wgrad_kernel(WgradArgs a) {
     auto put_y = [&]() {
 #pragma unroll
         for (int i = 0; i < NVY; ++i) {
-            const int v = threadIdx.x + i * 256;
+            const int v = threadIdx.x + i * NTH;
             ry[i].store(yl + (v >> 3) * PIXW + (v & 7) * 8);
         }
     };
@@ -236,7 +239,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wgrad_kernel(WgradArgs a) {
         if (next < a.tiles) { halo.load(a.X, next * TT, a.rows_total); load_y(next * TT); }
 
 #pragma unroll 1
-        for (int ks = 0; ks < 16; ++ks) {                         // 16 pixels per k-step, all inside one t-row
+        for (int ks = grp * (16 / KG); ks < (grp + 1) * (16 / KG); ++ks) {   // 16 pixels per k-step, all inside one t-row
             const int t_local = FI == 32 ? (ks >> 1) : ks;
             const int f0 = FI == 32 ? (ks & 1) * 16 : 0;
             const int g = g0 + t_local;
@@ -303,7 +306,6 @@ extern "C" int audiossl_conv3x3_fwd(const void* X, const void* W, const float* b
     const int rows = N * Ti, TT = 256 / Fi, tiles = (rows + TT - 1) / TT;
     ConvArgs a{static_cast<const bf16*>(X), static_cast<const bf16*>(W), bias, static_cast<bf16*>(Y), sum, sumsq, Ti, rows, tiles, out_f32};
     const int grid = tiles < 256 ? tiles : 256;
-    static bool attr32 = false, attr16 = false;
     static const int nw = getenv("AUDIOSSL_CONV_WAVES") ? atoi(getenv("AUDIOSSL_CONV_WAVES")) : 8;
     static bool attr[4] = {false, false, false, false};
 #define CONV_LAUNCH(FI_, NW_, SLOT)                                                                       \
@@ -326,15 +328,18 @@ extern "C" int audiossl_conv3x3_wgrad(const void* dY, const void* X, float* dWp,
     const int rows = N * Ti, TT = 256 / Fi, tiles = (rows + TT - 1) / TT;
     WgradArgs a{static_cast<const bf16*>(dY), static_cast<const bf16*>(X), dWp, Ti, rows, tiles};
     const int grid = tiles < 256 ? tiles : 256;
-    static bool attr32 = false, attr16 = false;
-    if (Fi == 32) {
-        const size_t lds = sizeof(bf16) * (256 * PIXW + Halo<32, PIXW>::ELEMS);
-        if (!attr32) { if (set_lds(conv3x3_wgrad_kernel<32>, lds)) return ASSL_ELAUNCH; attr32 = true; }
-        hipLaunchKernelGGL(conv3x3_wgrad_kernel<32>, dim3(grid), dim3(256), lds, s, a);
-    } else {
-        const size_t lds = sizeof(bf16) * (256 * PIXW + Halo<16, PIXW>::ELEMS);
-        if (!attr16) { if (set_lds(conv3x3_wgrad_kernel<16>, lds)) return ASSL_ELAUNCH; attr16 = true; }
-        hipLaunchKernelGGL(conv3x3_wgrad_kernel<16>, dim3(grid), dim3(256), lds, s, a);
-    }
+    // measured: the pixel split pays on the 32-pixel-wide layer (304 -> 275 us) and costs on the 16-wide one (112 -> 119 us)
+    static const int kg_env = getenv("AUDIOSSL_WGRAD_KG") ? atoi(getenv("AUDIOSSL_WGRAD_KG")) : 0;
+    const int kg = kg_env ? kg_env : (Fi == 32 ? 2 : 1);
+    static bool attr[4] = {false, false, false, false};
+#define WGRAD_LAUNCH(FI_, KG_, SLOT)                                                                      \
+    do {                                                                                                  \
+        const size_t lds = sizeof(bf16) * (256 * PIXW + Halo<FI_, PIXW>::ELEMS);                          \
+        if (!attr[SLOT]) { if (set_lds(conv3x3_wgrad_kernel<FI_, KG_>, lds)) return ASSL_ELAUNCH; attr[SLOT] = true; } \
+        hipLaunchKernelGGL((conv3x3_wgrad_kernel<FI_, KG_>), dim3(grid), dim3(256 * KG_), lds, s, a);    \
+    } while (0)
+    if (Fi == 32) { if (kg == 2) WGRAD_LAUNCH(32, 2, 0); else WGRAD_LAUNCH(32, 1, 1); }
+    else          { if (kg == 2) WGRAD_LAUNCH(16, 2, 2); else WGRAD_LAUNCH(16, 1, 3); }
+#undef WGRAD_LAUNCH
     ASSL_LAUNCH_CHECK();
 }
