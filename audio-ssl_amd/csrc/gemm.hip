@@ -40,6 +40,7 @@ struct GemmArgs {
     const float* resid;       // fp32 [M][ldr] added to the result (out-of-place residual connection) or null
     long ldr;
     unsigned a_bytes, b_bytes; // extents of A and B for the buffer descriptors (hardware bounds check)
+    int vec_epi;              // every epilogue operand allows 8-column vectors (set by epi_vectorisable)
 };
 
 template <typename T> struct Mma;
@@ -109,6 +110,82 @@ __device__ __forceinline__ void epilogue_lds(const GemmArgs& g, f32x16 (&acc)[MI
             else                static_cast<T*>(g.C)[o] = from_f32<T>(v[u]);
         }
     }
+}
+
+// The same with 8 consecutive columns per lane (8 rows x 64 columns per wave trip): 16-byte stores of bf16 results (two for
+// fp32), 8-byte keep-mask loads, 16-byte gate / residual loads.  The one-column-per-lane form above issues a 128-byte
+// store per row and wave - on the 6144 x 2048 Linear layers of the encoder the epilogue then took longer than the k-loop
+// (70 us at K = 512 against 113 us at K = 2048).  bf16 operands, non-atomic results, N % 8 == 0 and aligned operands only.
+template <int MI>
+__device__ __forceinline__ void epilogue_vec(const GemmArgs& g, f32x16 (&acc)[MI][2], char* smem, int row0, int col0, int lane,
+                                             int wave) {
+    __syncthreads();
+    float* ct = reinterpret_cast<float*>(smem) + wave * 64 * EPI_PITCH;
+    const int half = lane >> 5, l31 = lane & 31;
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                ct[(i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half) * EPI_PITCH + j * 32 + l31] = acc[i][j][r];
+    const int c8 = (lane & 7) * 8, rr = lane >> 3;
+    const int col = col0 + c8;
+    if (col >= g.N) return;
+    float bias[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) bias[u] = 0.f;
+    if (g.bias) {
+        const Vec8<float> b = Vec8<float>::load(g.bias + col);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) bias[u] = b.get(u);
+    }
+    const float floor_ = g.relu ? 0.f : -3.4e38f;
+    const bf16* gate = static_cast<const bf16*>(g.gate);
+#pragma unroll 2
+    for (int r0 = 0; r0 < 32 * MI; r0 += 8) {
+        const int rl = r0 + rr;
+        const long row = row0 + rl;
+        if (row >= g.M) continue;
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = fmaxf(g.alpha * ct[rl * EPI_PITCH + c8 + u] + bias[u], floor_);
+        if (g.keep) {
+            const unsigned long long k8 = *reinterpret_cast<const unsigned long long*>(g.keep + row * g.ldk + col);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = ((k8 >> (8 * u)) & 0xFFull) ? v[u] * g.keep_scale : 0.f;
+        }
+        if (gate) {
+            const Vec8<bf16> gt = Vec8<bf16>::load(gate + row * g.ldg + col);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = gt.get(u) > 0.f ? v[u] : 0.f;
+        }
+        if (g.resid) {
+            const Vec8<float> rs = Vec8<float>::load(g.resid + row * g.ldr + col);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] += rs.get(u);
+        }
+        const long o = row * g.ldc + col;
+        if (g.out_f32) {
+            Vec8<float> out;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) out.set(u, v[u]);
+            out.store(static_cast<float*>(g.C) + o);
+        } else {
+            Vec8<bf16> out;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) out.set(u, v[u]);
+            out.store(static_cast<bf16*>(g.C) + o);
+        }
+    }
+}
+
+template <typename T, int MI>
+__device__ __forceinline__ void epilogue(const GemmArgs& g, f32x16 (&acc)[MI][2], char* smem, int row0, int col0, int lane, int wave) {
+    if constexpr (sizeof(T) == 2) {
+        if (g.vec_epi) { epilogue_vec<MI>(g, acc, smem, row0, col0, lane, wave); return; }
+    }
+    epilogue_lds<T, MI>(g, acc, smem, row0, col0, lane, wave);
 }
 
 // One operand's staging: 128 rows x 32 k per step, two Vec8 per thread.
@@ -252,7 +329,7 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g, char* smem) {
         cur ^= 1;
     }
 
-    epilogue_lds<T, MI>(g, acc, smem, bm + wm, bn + wn, lane, wave);
+    epilogue<T, MI>(g, acc, smem, bm + wm, bn + wn, lane, wave);
 }
 
 template <typename T, bool TA, bool TB, int BK, int MI>
@@ -304,18 +381,18 @@ int launch(const GemmArgs& g, hipStream_t s) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-// NT bf16 with direct-to-LDS staging (`global_load_lds_dwordx4`) and a 4-deep ring: the pipelined variant for the shapes
-// where one register stage cannot hide the load latency (M = 512..6144 Linear layers of the step: ~1.4 us per 64-deep
-// k-step against 0.2 us of MFMA work) and for the large transformer GEMMs.
-//   * an LDS-DMA instruction writes wave-uniform base + lane * 16 B, so the stage image is the plain [128 rows][64 k]
-//     tile (128-byte rows, no padding); bank conflicts of the fragment reads are removed by an XOR swizzle of the 16-byte
-//     chunk index, chunk ^= (row >> 1) & 7, applied to the SOURCE address of the DMA and to the ds_read address;
-//   * up to three stages stay in flight across the (raw) barrier: counted s_waitcnt vmcnt(N), never 0 in steady state;
-//   * rows past M / N are clamped to the last row (their results are never stored); K must be a multiple of 64.
+// bf16 with direct-to-LDS staging (`global_load_lds_dwordx4`) and an NST-deep ring: the pipelined variant.  The
+// register-staged kernel above keeps ONE 64-deep k-step in flight per workgroup, so a k-step costs a full global-load
+// latency (~1 us against 0.1-0.2 us of MFMA work on the projector shapes of the step); here up to NST-1 stages are in
+// flight across a single raw barrier per step, waited for with counted s_waitcnt vmcnt(N) (never 0 in steady state).
+//   * an LDS-DMA instruction writes wave-uniform base + lane * 16 B, so a stage image is the plain tile with no padding;
+//     bank conflicts of the fragment reads are removed by XOR swizzles applied to the SOURCE address of the DMA and to
+//     the ds_read address:
+//       [row][64 k] image (K-contiguous operand, 128-byte rows): 16-byte chunk ^= (row >> 1) & 7
+//       [64 k][R rows] image (row-contiguous operand, read with ds_read_b64_tr_b16): 64-byte group ^= k & 3 (R = 128)
+//         or ^= (k >> 1) & 1 (R = 64), so the four k-rows one transposing read touches fall on four distinct bank groups;
+//   * rows past M / N are clamped to the last row / last 8-row chunk (their results are never stored); K % 64 == 0.
 constexpr int GBK = 64;
-constexpr int GSTAGES = 4;
-constexpr int GOP_BYTES = 128 * GBK * 2;                 // one operand of one stage: 16 KB
-constexpr int GSTAGE_BYTES = 2 * GOP_BYTES;
 
 __device__ __forceinline__ void glds16(const bf16* src, char* dst) {
     typedef __attribute__((address_space(1))) const void* gptr_t;
@@ -323,106 +400,170 @@ __device__ __forceinline__ void glds16(const bf16* src, char* dst) {
     __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)dst, 16, 0, 0);
 }
 
-__global__ __launch_bounds__(256) void gemm_nt_glds_kernel(GemmArgs g) {
+template <int N_> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N_) : "memory"); }
+
+// One operand of the ring: R rows x 64 k per stage.
+template <bool TRANS, int R>
+struct RingOp {
+    static constexpr int BYTES = R * GBK * 2;
+    static constexpr int NI = BYTES / 4096;                  // DMA instructions per wave and stage (1 KiB each, 4 waves)
+    static constexpr int NB = R / 64;                        // 32-row fragment blocks per wave
+    const bf16* p[NI];
+    long kstride;
+    int foff[NB], fsw[NB];
+    __device__ __forceinline__ void init(const void* base_, long ld, int r0, int ext, int k0, int wave, int lane, int wr) {
+        const bf16* base = static_cast<const bf16*>(base_);
+        if (!TRANS) {
+#pragma unroll
+            for (int i = 0; i < NI; ++i) {
+                const int rl = wave * (R / 4) + i * 8 + (lane >> 3);
+                const int sc = (lane & 7) ^ ((rl >> 1) & 7);
+                p[i] = base + (long)min(r0 + rl, ext - 1) * ld + sc * 8 + k0;
+            }
+            kstride = GBK;
+#pragma unroll
+            for (int b = 0; b < NB; ++b) {
+                const int r = wr + b * 32 + (lane & 31);
+                foff[b] = r * 128; fsw[b] = (r >> 1) & 7;
+            }
+        } else {
+            constexpr int CPR = R / 8;                       // 16-byte chunks per k-row
+            constexpr int KPI = 64 / CPR;                    // k-rows per DMA instruction
+#pragma unroll
+            for (int i = 0; i < NI; ++i) {
+                const int kl = wave * 16 + i * KPI + lane / CPR, pc = lane % CPR;
+                const int sw = R == 128 ? (kl & 3) : ((kl >> 1) & 1);
+                const int roff = ((((pc >> 2) ^ sw) << 2) + (pc & 3)) * 8;
+                p[i] = base + (long)(k0 + kl) * ld + min(r0 + roff, ext - 8);
+            }
+            kstride = (long)GBK * ld;
+            const int q = (lane & 15) >> 2, pp = lane & 3, h4 = (lane >> 4) & 1, half = lane >> 5;
+#pragma unroll
+            for (int b = 0; b < NB; ++b) {
+                const int grp = ((wr + b * 32) >> 5) ^ (R == 128 ? q : (q >> 1));
+                foff[b] = (8 * half + q) * (R * 2) + grp * 64 + 32 * h4 + 8 * pp; fsw[b] = 0;
+            }
+        }
+    }
+    __device__ __forceinline__ void issue(long st, char* dst) const {
+#pragma unroll
+        for (int i = 0; i < NI; ++i) glds16(p[i] + st * kstride, dst + i * 1024);
+    }
+    // fragment of block b, 16-wide k-step kk (0..3) of the stage image at `img`
+    __device__ __forceinline__ Vec8<bf16> frag(const char* img, int b, int kk, int half) const {
+        if (!TRANS) return Vec8<bf16>::load(reinterpret_cast<const bf16*>(img + foff[b] + (((kk * 2 + half) ^ fsw[b]) << 4)));
+        typedef __attribute__((address_space(3))) bf16x4* lds4_t;
+        const char* a = img + foff[b] + kk * 16 * (R * 2);
+        const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds4_t)a);
+        const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds4_t)(a + 4 * (R * 2)));
+        Vec8<bf16> f;
+        f.v = bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        return f;
+    }
+};
+
+template <bool TA, bool TB, int MI, int NST>
+__global__ __launch_bounds__(256) void gemm_ring_kernel(GemmArgs g) {
+    constexpr int RA = 64 * MI;
+    using OA = RingOp<TA, RA>;
+    using OB = RingOp<TB, 128>;
+    constexpr int STAGE = OA::BYTES + OB::BYTES;
+    constexpr int NPS = OA::NI + OB::NI;                     // DMA instructions per wave and stage
     extern __shared__ __attribute__((aligned(1024))) char smem[];
     const int tiles_n = (g.N + BN - 1) / BN;
     // blocks that share an XCD (ids congruent mod 8) get consecutive tiles: they share A row panels / B column panels in L2
     const int nwg = gridDim.x, xcd = blockIdx.x & 7, q8 = nwg >> 3, r8 = nwg & 7;
     const int wg = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (blockIdx.x >> 3);
-    const int bm = (wg / tiles_n) * BM, bn = (wg % tiles_n) * BN;
+    const int bm = (wg / tiles_n) * RA, bn = (wg % tiles_n) * BN;
     const int ksteps = g.K / GBK;
     const int per = (ksteps + g.ksplit - 1) / g.ksplit;
     const int ks0 = blockIdx.z * per, ks1 = min(ksteps, ks0 + per);
     if (ks0 >= ks1) return;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, half = lane >> 5;
+    const int wm = (wave >> 1) * 32 * MI, wn = (wave & 1) * 64;
 
-    const bf16* Ap[4];
-    const bf16* Bp[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int rl = wave * 32 + i * 8 + (lane >> 3);
-        const int sc = (lane & 7) ^ ((rl >> 1) & 7);
-        Ap[i] = static_cast<const bf16*>(g.A) + (long)min(bm + rl, g.M - 1) * g.lda + sc * 8 + (long)ks0 * GBK;
-        Bp[i] = static_cast<const bf16*>(g.B) + (long)min(bn + rl, g.N - 1) * g.ldb + sc * 8 + (long)ks0 * GBK;
-    }
-    char* const wbase = smem + (wave * 32) * 128;        // this wave's first row inside an operand image
+    OA oa; OB ob;
+    oa.init(g.A, g.lda, bm, g.M, ks0 * GBK, wave, lane, wm);
+    ob.init(g.B, g.ldb, bn, g.N, ks0 * GBK, wave, lane, wn);
+    char* const wa = smem + wave * (OA::BYTES / 4);          // this wave's slice of the A image / the B image of slot 0
+    char* const wb = smem + OA::BYTES + wave * (OB::BYTES / 4);
 
-    f32x16 acc[2][2];
+    f32x16 acc[MI][2];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < MI; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     const int nk = ks1 - ks0;
+    int islot = 0;                                           // ring slot the next issued stage goes to
     auto issue = [&](int st) {
-        char* d = wbase + (st % GSTAGES) * GSTAGE_BYTES;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) glds16(Ap[i] + (long)st * GBK, d + i * 8 * 128);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) glds16(Bp[i] + (long)st * GBK, d + GOP_BYTES + i * 8 * 128);
+        oa.issue(st, wa + islot * STAGE);
+        ob.issue(st, wb + islot * STAGE);
+        islot = islot + 1 == NST ? 0 : islot + 1;
     };
-    for (int st = 0; st < GSTAGES - 1 && st < nk; ++st) issue(st);
+    for (int st = 0; st < NST - 1 && st < nk; ++st) issue(st);
 
-    // fragment addressing: row r, logical 16-byte chunk cc -> physical chunk cc ^ ((r >> 1) & 7)
-    const int half = lane >> 5, l31 = lane & 31;
-    int offA[2], offB[2], swA[2], swB[2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int ra = wm + i * 32 + l31, rb = wn + i * 32 + l31;
-        offA[i] = ra * 128; swA[i] = (ra >> 1) & 7;
-        offB[i] = GOP_BYTES + rb * 128; swB[i] = (rb >> 1) & 7;
-    }
+    int cslot = 0;
     for (int it = 0; it < nk; ++it) {
-        const int ahead = min(nk - 1 - it, GSTAGES - 2);
-        if (ahead >= 2)      asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-        else if (ahead == 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-        else                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();                    // stage `it` visible to every wave; slot of stage it-1 free again
-        if (it + GSTAGES - 1 < nk) issue(it + GSTAGES - 1);
-        const char* sb = smem + (it % GSTAGES) * GSTAGE_BYTES;
-        // fragment reads run one k-step ahead of the MFMAs that consume them (one wave per SIMD: nobody else hides the
-        // ~120-cycle LDS latency)
-        Vec8<bf16> fa[2][2], fb[2][2];
+        const int ahead = min(nk - 1 - it, NST - 2);
+        if (ahead == 0) wait_vm<0>();                        // all but the `ahead` youngest stages have landed
+        else if (ahead == 1) wait_vm<NPS>();
+        else if (ahead == 2) wait_vm<2 * NPS>();
+        else if (ahead == 3) wait_vm<3 * NPS>();
+        else wait_vm<4 * NPS>();
+        __builtin_amdgcn_s_barrier();                        // stage `it` visible to every wave; slot of stage it-1 free again
+        if (it + NST - 1 < nk) issue(it + NST - 1);
+        const char* sa = smem + cslot * STAGE;
+        const char* sb = sa + OA::BYTES;
+        cslot = cslot + 1 == NST ? 0 : cslot + 1;
+        // fragment reads run one k-step ahead of the MFMAs that consume them
+        Vec8<bf16> fa[2][MI], fb[2][2];
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            fa[0][i] = Vec8<bf16>::load(reinterpret_cast<const bf16*>(sb + offA[i] + ((half ^ swA[i]) << 4)));
-            fb[0][i] = Vec8<bf16>::load(reinterpret_cast<const bf16*>(sb + offB[i] + ((half ^ swB[i]) << 4)));
-        }
+        for (int i = 0; i < MI; ++i) fa[0][i] = oa.frag(sa, i, 0, half);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) fb[0][j] = ob.frag(sb, j, 0, half);
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) {
             const int cur = kk & 1, nxt = cur ^ 1;
             if (kk < 3) {
-                const int cc = (kk + 1) * 2 + half;
 #pragma unroll
-                for (int i = 0; i < 2; ++i) {
-                    fa[nxt][i] = Vec8<bf16>::load(reinterpret_cast<const bf16*>(sb + offA[i] + ((cc ^ swA[i]) << 4)));
-                    fb[nxt][i] = Vec8<bf16>::load(reinterpret_cast<const bf16*>(sb + offB[i] + ((cc ^ swB[i]) << 4)));
-                }
+                for (int i = 0; i < MI; ++i) fa[nxt][i] = oa.frag(sa, i, kk + 1, half);
+#pragma unroll
+                for (int j = 0; j < 2; ++j) fb[nxt][j] = ob.frag(sb, j, kk + 1, half);
             }
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+            for (int i = 0; i < MI; ++i)
 #pragma unroll
                 for (int j = 0; j < 2; ++j) Mma<bf16>::run(acc[i][j], fa[cur][i], fb[cur][j]);
         }
     }
 
-    epilogue_lds<bf16, 2>(g, acc, smem, bm + wm, bn + wn, lane, wave);
+    epilogue<bf16, MI>(g, acc, smem, bm + wm, bn + wn, lane, wave);
 }
 
-int launch_nt_glds(const GemmArgs& g, hipStream_t s) {
-    constexpr size_t lds = (size_t)GSTAGES * GSTAGE_BYTES;
+template <bool TA, bool TB, int MI, int NST>
+int launch_ring(const GemmArgs& g, hipStream_t s) {
+    constexpr size_t stage = RingOp<TA, 64 * MI>::BYTES + RingOp<TB, 128>::BYTES;
+    const size_t lds = max((size_t)NST * stage, EPI_LDS);
     static bool attr_set = false;
     if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_glds_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)lds) != hipSuccess) return ASSL_ELAUNCH;
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_ring_kernel<TA, TB, MI, NST>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return ASSL_ELAUNCH;
         attr_set = true;
     }
-    const int tiles = ceil_div(g.M, BM) * ceil_div(g.N, BN);
-    hipLaunchKernelGGL(gemm_nt_glds_kernel, dim3(tiles, 1, g.ksplit), dim3(256), lds, s, g);
+    const int tiles = ceil_div(g.M, 64 * MI) * ceil_div(g.N, BN);
+    hipLaunchKernelGGL((gemm_ring_kernel<TA, TB, MI, NST>), dim3(tiles, 1, g.ksplit), dim3(256), lds, s, g);
     ASSL_LAUNCH_CHECK();
+}
+
+template <int MI, int NST>
+int dispatch_ring(const GemmArgs& g, int ta, int tb, hipStream_t s) {
+    if (!ta && !tb) return launch_ring<false, false, MI, NST>(g, s);
+    if (!ta && tb) return launch_ring<false, true, MI, NST>(g, s);
+    if (ta && tb) return launch_ring<true, true, MI, NST>(g, s);
+    return launch_ring<true, false, MI, NST>(g, s);
 }
 
 template <typename T, int BK, int MI>
@@ -431,6 +572,19 @@ int dispatch(const GemmArgs& g, int ta, int tb, hipStream_t s) {
     if (!ta && tb) return launch<T, false, true, BK, MI>(g, s);
     if (ta && tb) return launch<T, true, true, BK, MI>(g, s);
     return launch<T, true, false, BK, MI>(g, s);
+}
+
+// the 8-columns-per-lane epilogue needs whole, aligned vectors of every operand it touches
+int epi_vectorisable(const GemmArgs& g, int dtype) {
+    static const bool on = getenv("AUDIOSSL_GEMM_VEC_EPI") ? atoi(getenv("AUDIOSSL_GEMM_VEC_EPI")) != 0 : true;
+    if (!on || dtype != 1 || g.atomic || g.N % 8) return 0;
+    const size_t csz = g.out_f32 ? 4 : 2;
+    if (((size_t)g.C * 1) % 16 || (g.ldc * csz) % 16) return 0;
+    if (g.bias && (size_t)g.bias % 16) return 0;
+    if (g.keep && ((size_t)g.keep % 8 || g.ldk % 8)) return 0;
+    if (g.gate && ((size_t)g.gate % 16 || g.ldg % 8)) return 0;
+    if (g.resid && ((size_t)g.resid % 16 || g.ldr % 4)) return 0;
+    return 1;
 }
 
 }  // namespace
@@ -451,7 +605,8 @@ extern "C" int audiossl_gemm_multi(int count, int trans_a, int trans_b, int M, i
         const long b_ext = (trans_b ? ((long)(K[i] - 1) * ldb[i] + N) : ((long)(N - 1) * ldb[i] + K[i])) * 2;
         ASSL_REQUIRE(a_ext < 0xFFFFFF00L && b_ext < 0xFFFFFF00L);
         gm.p[i] = GemmArgs{A[i], B[i], C[i], M, N, K[i], lda[i], ldb[i], ldc, alpha, nullptr, 0, nullptr, 0, 1.f, nullptr, 0,
-                           out_f32, atomic, ksplit, nullptr, 0, (unsigned)a_ext, (unsigned)b_ext};
+                           out_f32, atomic, ksplit, nullptr, 0, (unsigned)a_ext, (unsigned)b_ext, 0};
+        gm.p[i].vec_epi = epi_vectorisable(gm.p[i], 1);
         kmin = min(kmin, K[i]);
     }
     hipStream_t s = static_cast<hipStream_t>(stream);
@@ -490,15 +645,33 @@ extern "C" int audiossl_gemm(int dtype, int trans_a, int trans_b, int M, int N, 
     const long b_ext = (trans_b ? ((long)(K - 1) * ldb + N) : ((long)(N - 1) * ldb + K)) * esz;
     ASSL_REQUIRE(a_ext < 0xFFFFFF00L && b_ext < 0xFFFFFF00L);            // 32-bit buffer offsets
     GemmArgs g{A, B, C, M, N, K, lda, ldb, ldc, alpha, bias, relu, keep, ldk, keep_scale, gate, ldg,
-               (dtype == 0) ? 1 : out_f32, atomic, ksplit, resid, ldr, (unsigned)a_ext, (unsigned)b_ext};
+               (dtype == 0) ? 1 : out_f32, atomic, ksplit, resid, ldr, (unsigned)a_ext, (unsigned)b_ext, 0};
+    g.vec_epi = epi_vectorisable(g, dtype);
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (dtype == 0) return dispatch<float, 32, 2>(g, trans_a, trans_b, s);
-    static const bool use_glds = getenv("AUDIOSSL_GEMM_GLDS") ? atoi(getenv("AUDIOSSL_GEMM_GLDS")) != 0 : true;
     const long blocks = (long)ceil_div(M, BM) * ceil_div(N, BN) * ksplit;
-    // the 4-deep direct-to-LDS ring (one workgroup per CU) wins for one to two waves of workgroups (below that the 64-row
-    // tiles further down are faster still); beyond
-    // that two co-resident workgroups of the register-staged kernel overlap each other better (tools/gemm_floor.py)
-    if (use_glds && !trans_a && !trans_b && K % GBK == 0 && blocks > 128 && blocks <= 512) return launch_nt_glds(g, s);
+    // AUDIOSSL_GEMM_RING = 10 * MI + NST forces one ring variant (tools/gemm_shapes.py sweeps them); 0 disables the ring
+    static const int ring = getenv("AUDIOSSL_GEMM_RING") ? atoi(getenv("AUDIOSSL_GEMM_RING")) : -1;
+    const bool ring_ok = K % GBK == 0 && M >= 8 && N >= 8;
+    if (ring_ok && ring > 0) {
+        switch (ring) {
+            case 12: return dispatch_ring<1, 2>(g, trans_a, trans_b, s);
+            case 13: return dispatch_ring<1, 3>(g, trans_a, trans_b, s);
+            case 14: return dispatch_ring<1, 4>(g, trans_a, trans_b, s);
+            case 16: return dispatch_ring<1, 6>(g, trans_a, trans_b, s);
+            case 22: return dispatch_ring<2, 2>(g, trans_a, trans_b, s);
+            case 23: return dispatch_ring<2, 3>(g, trans_a, trans_b, s);
+            case 24: return dispatch_ring<2, 4>(g, trans_a, trans_b, s);
+            default: break;
+        }
+    }
+    // measured (tools/gemm_shapes.py): the ring wins for K-contiguous operands (NT) on grids of at most two waves of
+    // workgroups - 64-row tiles up to 128 full tiles, 128-row tiles up to 512; with a transposed operand or on larger grids
+    // two co-resident workgroups of the register-staged kernel overlap each other better
+    if (ring_ok && ring < 0 && !trans_a && !trans_b) {
+        if (blocks <= 128 && M > 64) return dispatch_ring<1, 4>(g, 0, 0, s);
+        if (blocks > 128 && blocks <= 512) return dispatch_ring<2, 4>(g, 0, 0, s);
+    }
     static const bool small_tiles = getenv("AUDIOSSL_GEMM_SMALL") ? atoi(getenv("AUDIOSSL_GEMM_SMALL")) != 0 : true;
     // these shapes are latency-bound per workgroup (~0.5 us per 64-deep k-step whatever the tile): when 128 x 128 tiles
     // would occupy at most half of the 256 CUs, halve the tile in M and run twice as many workgroups
