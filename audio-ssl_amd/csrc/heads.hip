@@ -175,6 +175,151 @@ __global__ __launch_bounds__(256) void colbn_bwd_apply_kernel(const TA* __restri
     o.store(da + idx * 8);
 }
 
+// ------------------------------------------------------------------- fused BatchNorm1d(train) for short batches
+// The projector batches are short (M = 512 rows per view): statistics, finalisation and normalisation as three launches
+// cost three dispatch latencies of a serial chain for a few microseconds of work.  Here one workgroup owns a strip of 32
+// columns (4 lanes x 8 columns per row) and keeps its M <= 64 * NR rows in registers between the statistics pass and the
+// normalisation.  Column sums: fp32 per thread (NR rows), fp64 across the 64 row-threads - like colstats_kernel.
+template <int NS>
+__device__ __forceinline__ void strip_reduce(const float (&part)[NS][8], float (*red)[65], double* tot) {
+    // part[k][i]: this thread's partial of statistic k, column (t & 3) * 8 + i  ->  tot[k * 32 + column]
+    const int cl = threadIdx.x & 3, r0 = threadIdx.x >> 2;
+#pragma unroll
+    for (int k = 0; k < NS; ++k) {
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 8; ++i) red[r0][cl * 8 + i] = part[k][i];
+        __syncthreads();
+        if (threadIdx.x < 32) {
+            double t = 0.0;
+            for (int r = 0; r < 64; ++r) t += (double)red[r][threadIdx.x];
+            tot[k * 32 + threadIdx.x] = t;
+        }
+    }
+    __syncthreads();
+}
+
+template <typename TA, typename T_, int NR>
+__global__ __launch_bounds__(256) void colbn_train_fwd_kernel(const TA* __restrict__ a, const float* __restrict__ gamma,
+                                                              const float* __restrict__ beta, float* running_mean,
+                                                              float* running_var, float momentum, float eps, int relu, int groups,
+                                                              int M, int C, T_* __restrict__ h, float* __restrict__ scale,
+                                                              float* __restrict__ shift, float* __restrict__ save_mean,
+                                                              float* __restrict__ save_rstd) {
+    __shared__ float red[64][65];
+    __shared__ double tot[64];
+    __shared__ float sc_s[32], sh_s[32];
+    const int cl = threadIdx.x & 3, r0 = threadIdx.x >> 2;
+    const int col0 = blockIdx.x * 32 + cl * 8;
+    const int c = blockIdx.x * 32 + threadIdx.x;             // threads 0..31: the column they finalise
+    float rm = 0.f, rv = 0.f;
+    if (threadIdx.x < 32 && running_mean) { rm = running_mean[c]; rv = running_var[c]; }
+    for (int g = 0; g < groups; ++g) {
+        const TA* ag = a + (long)g * M * C;
+        Vec8<TA> v[NR];
+        float part[2][8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { part[0][i] = 0.f; part[1][i] = 0.f; }
+#pragma unroll
+        for (int j = 0; j < NR; ++j) {
+            const int r = r0 + 64 * j;
+            if (r < M) {
+                v[j] = Vec8<TA>::load(ag + (long)r * C + col0);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) { const float f = v[j].get(i); part[0][i] += f; part[1][i] += f * f; }
+            }
+        }
+        strip_reduce<2>(part, red, tot);
+        if (threadIdx.x < 32) {
+            const double gm = gamma ? (double)gamma[c] : 1.0, bt = beta ? (double)beta[c] : 0.0;
+            const double mean = tot[threadIdx.x] / (double)M;
+            double var = tot[32 + threadIdx.x] / (double)M - mean * mean;
+            var = var < 0.0 ? 0.0 : var;
+            const double rstd = 1.0 / sqrt(var + (double)eps);
+            const float sc = (float)(gm * rstd), sh = (float)(bt - mean * gm * rstd);
+            const long o = (long)g * C + c;
+            scale[o] = sc; shift[o] = sh; save_mean[o] = (float)mean; save_rstd[o] = (float)rstd;
+            sc_s[threadIdx.x] = sc; sh_s[threadIdx.x] = sh;
+            rm = (1.f - momentum) * rm + momentum * (float)mean;
+            const double unb = M > 1 ? var * (double)M / ((double)M - 1.0) : var;
+            rv = (1.f - momentum) * rv + momentum * (float)unb;
+        }
+        __syncthreads();
+        float sc[8], sh[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { sc[i] = sc_s[cl * 8 + i]; sh[i] = sh_s[cl * 8 + i]; }
+        T_* hg = h + (long)g * M * C;
+#pragma unroll
+        for (int j = 0; j < NR; ++j) {
+            const int r = r0 + 64 * j;
+            if (r < M) {
+                Vec8<T_> o;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) { const float f = sc[i] * v[j].get(i) + sh[i]; o.set(i, relu ? fmaxf(f, 0.f) : f); }
+                o.store(hg + (long)r * C + col0);
+            }
+        }
+    }
+    if (threadIdx.x < 32 && running_mean) { running_mean[c] = rm; running_var[c] = rv; }
+}
+
+// backward of the same: grid (C / 32, groups); sg / sgx as in colbn_bwd_stats_kernel, then da in the same launch
+template <typename TA, typename TG, typename T_, int NR>
+__global__ __launch_bounds__(256) void colbn_bwd_fused_kernel(const TA* __restrict__ a, const TG* __restrict__ dh,
+                                                              const float* __restrict__ scale, const float* __restrict__ shift,
+                                                              const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                              int relu, int M, int C, T_* __restrict__ da, float* dgamma,
+                                                              float* dbeta) {
+    __shared__ float red[64][65];
+    __shared__ double tot[64];
+    const int cl = threadIdx.x & 3, r0 = threadIdx.x >> 2;
+    const int col0 = blockIdx.x * 32 + cl * 8;
+    const long go = (long)blockIdx.y * C, ro = (long)blockIdx.y * M * C;
+    a += ro; dh += ro; da += ro;
+    const Vec8<float> vsc = Vec8<float>::load(scale + go + col0), vsh = Vec8<float>::load(shift + go + col0);
+    const Vec8<float> vmu = Vec8<float>::load(mean + go + col0), vrs = Vec8<float>::load(rstd + go + col0);
+    float gq[NR][8], xh[NR][8];
+    float part[2][8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { part[0][i] = 0.f; part[1][i] = 0.f; }
+#pragma unroll
+    for (int j = 0; j < NR; ++j) {
+        const int r = r0 + 64 * j;
+        if (r < M) {
+            const Vec8<TA> va = Vec8<TA>::load(a + (long)r * C + col0);
+            const Vec8<TG> vg = Vec8<TG>::load(dh + (long)r * C + col0);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const float x = va.get(i);
+                float g = vg.get(i);
+                if (relu && !(vsc.get(i) * x + vsh.get(i) > 0.f)) g = 0.f;
+                const float xhat = (x - vmu.get(i)) * vrs.get(i);
+                gq[j][i] = g; xh[j][i] = xhat;
+                part[0][i] += g; part[1][i] += g * xhat;
+            }
+        }
+    }
+    strip_reduce<2>(part, red, tot);
+    if (threadIdx.x < 32 && dgamma) {
+        atomicAdd(&dgamma[blockIdx.x * 32 + threadIdx.x], (float)tot[32 + threadIdx.x]);
+        atomicAdd(&dbeta[blockIdx.x * 32 + threadIdx.x], (float)tot[threadIdx.x]);
+    }
+    const float invM = 1.f / (float)M;
+    float mg[8], mgx[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { mg[i] = (float)tot[cl * 8 + i] * invM; mgx[i] = (float)tot[32 + cl * 8 + i] * invM; }
+#pragma unroll
+    for (int j = 0; j < NR; ++j) {
+        const int r = r0 + 64 * j;
+        if (r < M) {
+            Vec8<T_> o;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) o.set(i, vsc.get(i) * (gq[j][i] - mg[i] - xh[j][i] * mgx[i]));
+            o.store(da + (long)r * C + col0);
+        }
+    }
+}
+
 __global__ void add_d2f_kernel(const double* __restrict__ src, float* __restrict__ dst, int n) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i < n) dst[i] += (float)src[i];
@@ -416,6 +561,31 @@ extern "C" int audiossl_colbn_fwd(int dtype, int adtype, const void* a, const fl
     ASSL_LAUNCH_CHECK();
 }
 
+// Statistics + finalisation (running statistics included) + normalisation of `colstats` -> `bn_finalize` -> `colbn_fwd`
+// in one launch; M <= 1024 rows per group, C % 32 == 0.  Returns ASSL_EINVAL for shapes outside that (callers then use
+// the three separate calls).
+extern "C" int audiossl_colbn_train_fwd(int dtype, int adtype, const void* a, const float* gamma, const float* beta,
+                                        float* running_mean, float* running_var, float momentum, float eps, int relu,
+                                        int groups, long M, int C, void* h, float* scale, float* shift, float* save_mean,
+                                        float* save_rstd, void* stream) {
+    ASSL_REQUIRE(a && h && scale && shift && save_mean && save_rstd && groups > 0 && M > 0 && M <= 1024 && C > 0 && (C % 32) == 0);
+    ASSL_REQUIRE((dtype == 0 || dtype == 1) && (adtype == 0 || adtype == dtype));
+    ASSL_REQUIRE((running_mean == nullptr) == (running_var == nullptr));
+    hipStream_t s = S_(stream);
+#define TF(TA, TO) do {                                                                                                        \
+    if (M <= 512) hipLaunchKernelGGL((colbn_train_fwd_kernel<TA, TO, 8>), dim3(C / 32), dim3(256), 0, s, (const TA*)a, gamma, beta, \
+                                     running_mean, running_var, momentum, eps, relu, groups, (int)M, C, (TO*)h, scale, shift,    \
+                                     save_mean, save_rstd);                                                                     \
+    else hipLaunchKernelGGL((colbn_train_fwd_kernel<TA, TO, 16>), dim3(C / 32), dim3(256), 0, s, (const TA*)a, gamma, beta,      \
+                            running_mean, running_var, momentum, eps, relu, groups, (int)M, C, (TO*)h, scale, shift, save_mean,  \
+                            save_rstd); } while (0)
+    if (dtype == 0) TF(float, float);
+    else if (adtype == 0) TF(float, bf16);
+    else TF(bf16, bf16);
+#undef TF
+    ASSL_LAUNCH_CHECK();
+}
+
 // tmp: 2*G*C doubles of scratch.  dgamma/dbeta may be null (affine=False); otherwise accumulated (+=).
 // adtype / gdtype: storage types of `a` and of the incoming gradient `dh` (0 = fp32); `da` is written in `dtype`.
 extern "C" int audiossl_colbn_bwd(int dtype, int adtype, int gdtype, const void* a, const void* dh, const float* scale,
@@ -424,6 +594,22 @@ extern "C" int audiossl_colbn_bwd(int dtype, int adtype, int gdtype, const void*
     ASSL_REQUIRE(a && dh && scale && shift && mean && rstd && tmp && da && groups > 0 && M > 0 && C > 0 && (C % 8) == 0);
     ASSL_REQUIRE((dtype == 0 || dtype == 1) && (C % 64) == 0 && (gdtype == 0 || gdtype == dtype) && (adtype == 0 || adtype == dtype));
     hipStream_t s = S_(stream);
+    static const bool fused_ok = getenv("AUDIOSSL_BN_FUSED") ? atoi(getenv("AUDIOSSL_BN_FUSED")) != 0 : true;
+    if (fused_ok && M <= 1024 && (C % 32) == 0) {             // short batches: statistics + apply in one launch
+        dim3 fgrid(C / 32, groups);
+#define CF(TA, TG, TO) do {                                                                                                    \
+    if (M <= 512) hipLaunchKernelGGL((colbn_bwd_fused_kernel<TA, TG, TO, 8>), fgrid, dim3(256), 0, s, (const TA*)a, (const TG*)dh, \
+                                     scale, shift, mean, rstd, relu, (int)M, C, (TO*)da, dgamma, dbeta);                        \
+    else hipLaunchKernelGGL((colbn_bwd_fused_kernel<TA, TG, TO, 16>), fgrid, dim3(256), 0, s, (const TA*)a, (const TG*)dh,      \
+                            scale, shift, mean, rstd, relu, (int)M, C, (TO*)da, dgamma, dbeta); } while (0)
+        if (dtype == 0) CF(float, float, float);
+        else if (adtype == 0 && gdtype == 0) CF(float, float, bf16);
+        else if (adtype == 0) CF(float, bf16, bf16);
+        else if (gdtype == 0) CF(bf16, float, bf16);
+        else CF(bf16, bf16, bf16);
+#undef CF
+        ASSL_LAUNCH_CHECK();
+    }
     ASSL_ZERO(tmp, sizeof(double) * 2 * C * groups, s);
     const int rpb = M >= 4096 ? 256 : 64;
     dim3 grid(ceil_div(M, rpb), C / 64, groups);

@@ -19,6 +19,7 @@ import os as _os
 _STEM_VALU = _os.environ.get("AUDIOSSL_STEM_VALU") == "1"     # debug switch: fp32 VALU stem on the bf16 path
 BN_MOMENTUM = 0.1
 BN_EPS = 1e-5
+_BN_FUSED = _os.environ.get("AUDIOSSL_BN_FUSED", "1") != "0"
 
 
 class SideStream:
@@ -192,6 +193,19 @@ def _bn_train(dtype, Y, M, C, gamma, beta, rm, rv, update_running, groups=1):
     N.call("bn_finalize", sq[0], sq[1], groups, float(M), C, gamma, beta, rm if update_running else None,
            rv if update_running else None, BN_MOMENTUM, BN_EPS, st[0], st[1], st[2], st[3])
     return st[0], st[1], st[2], st[3]
+
+
+def bn_train_apply(dtype, ad, a, M, C, gamma, beta, rm, rv, update_running, groups, relu, out):
+    """Train-mode BatchNorm1d of a [groups][M][C] (+ReLU) -> out; returns (scale, shift, mean, rstd).  One fused launch for
+    the short projector batches, colstats -> bn_finalize -> colbn_fwd otherwise."""
+    if M <= 1024 and C % 32 == 0 and _BN_FUSED:
+        st = _empty((4, groups * C), torch.float32, like=a)
+        N.call("colbn_train_fwd", dtype, ad, a, gamma, beta, rm if update_running else None, rv if update_running else None,
+               BN_MOMENTUM, BN_EPS, relu, groups, M, C, out, st[0], st[1], st[2], st[3])
+        return st[0], st[1], st[2], st[3]
+    st = _bn_train(ad, a, M, C, gamma, beta, rm, rv, update_running, groups)
+    N.call("colbn_fwd", dtype, ad, a, st[0], st[1], relu, out, groups, M, C)
+    return st
 
 
 def _bn_eval(like, C, gamma, beta, rm, rv):
@@ -417,11 +431,11 @@ def projector_forward(PP, Y, dtype, groups, B, update_running=True, Wc=None):
     c.D = D
     M = groups * B
 
-    def bn(a, prefix, affine):
+    def bn(a, prefix, affine, relu, out):
         g = PP[prefix + ".weight"] if affine else None
         b = PP[prefix + ".bias"] if affine else None
-        return _bn_train(ad, a, B, D, g, b, PP[prefix + ".running_mean"], PP[prefix + ".running_var"], update_running,
-                         groups)
+        return bn_train_apply(dtype, ad, a, B, D, g, b, PP[prefix + ".running_mean"], PP[prefix + ".running_var"],
+                              update_running, groups, relu, out)
     td = N.torch_dtype(dtype)
     ad = _ad(dtype)
     c.ad = ad
@@ -439,17 +453,14 @@ def projector_forward(PP, Y, dtype, groups, B, update_running=True, Wc=None):
     else:
         c.y_hi, c.y_lo = Y, None
         c.a1 = linear_fwd(dtype, Y, W[0], M, D, kin, out_f32=o32)
-    c.st1 = bn(c.a1, "projector.1", True)
     c.h1 = _empty((M, D), td, like=Y)
-    N.call("colbn_fwd", dtype, ad, c.a1, c.st1[0], c.st1[1], 1, c.h1, groups, B, D)
+    c.st1 = bn(c.a1, "projector.1", True, 1, c.h1)
     c.a2 = linear_fwd(dtype, c.h1, W[1], M, D, D, out_f32=o32)
-    c.st2 = bn(c.a2, "projector.4", True)
     c.h2 = _empty((M, D), td, like=Y)
-    N.call("colbn_fwd", dtype, ad, c.a2, c.st2[0], c.st2[1], 1, c.h2, groups, B, D)
+    c.st2 = bn(c.a2, "projector.4", True, 1, c.h2)
     c.z = linear_fwd(dtype, c.h2, W[2], M, D, D, out_f32=o32)
-    c.st0 = bn(c.z, "bn", False)
     c.zn = _empty((M, D), td, like=Y)
-    N.call("colbn_fwd", dtype, ad, c.z, c.st0[0], c.st0[1], 0, c.zn, groups, B, D)
+    c.st0 = bn(c.z, "bn", False, 0, c.zn)
     return c.zn, c
 
 
@@ -544,18 +555,17 @@ def barlow_heads_forward_backward(PPs, Gs, Ys, dtype, lambds, scale_losses, loss
     tad = torch.float32 if o32 else td
     H = range(nh)
 
-    def bn(h, a, prefix, affine):
+    def bn(h, a, prefix, affine, relu, out):
         PP = PPs[h]
-        return _bn_train(ad, a, B, D, PP[prefix + ".weight"] if affine else None, PP[prefix + ".bias"] if affine else None,
-                         PP[prefix + ".running_mean"], PP[prefix + ".running_var"], update_running, 2)
+        return bn_train_apply(dtype, ad, a, B, D, PP[prefix + ".weight"] if affine else None,
+                              PP[prefix + ".bias"] if affine else None, PP[prefix + ".running_mean"],
+                              PP[prefix + ".running_var"], update_running, 2, relu, out)
 
     def layer(xs, ws, ks, prefix, affine, relu):
         a = [torch.empty(M, D, dtype=tad, device=dev) for _ in H]
         gemm_multi(0, 0, M, D, ks, xs, ks, ws, ks, a, D, out_f32=o32)
-        st = [bn(h, a[h], prefix, affine) for h in H]
         out = [torch.empty(M, D, dtype=td, device=dev) for _ in H]
-        for h in H:
-            N.call("colbn_fwd", dtype, ad, a[h], st[h][0], st[h][1], relu, out[h], 2, B, D)
+        st = [bn(h, a[h], prefix, affine, relu, out[h]) for h in H]
         return a, st, out
     a1, st1, h1 = layer(Ys, [W[h][0] for h in H], kins, "projector.1", True, 1)
     a2, st2, h2 = layer(h1, [W[h][1] for h in H], [D] * nh, "projector.4", True, 1)

@@ -156,6 +156,14 @@ int audiossl_maxmean_bwd(int dtype, int gdtype, const void* dy, const uint8_t* a
  * barlow_loss: loss += coef * sum (c - I)^2 ; dc = dscale * (c - I). */
 int audiossl_colbn_fwd(int dtype, int adtype, const void* a, const float* scale, const float* shift, int relu, void* h,
                        int groups, long M, int C, void* stream);
+/* colbn_train_fwd: colstats + bn_finalize + colbn_fwd of one train-mode BatchNorm1d (`nn.BatchNorm1d` inside the projector,
+ * `src/upstream/delores_m/upstream_expert.py:18-29`) in a single launch for short batches (M <= 1024 rows per group,
+ * C % 32 == 0): h = act(BN(a)), scale/shift/mean/rstd [G][C] saved for the backward, running statistics updated group
+ * after group. */
+int audiossl_colbn_train_fwd(int dtype, int adtype, const void* a, const float* gamma, const float* beta,
+                             float* running_mean, float* running_var, float momentum, float eps, int relu, int groups,
+                             long M, int C, void* h, float* scale, float* shift, float* save_mean, float* save_rstd,
+                             void* stream);
 int audiossl_colbn_bwd(int dtype, int adtype, int gdtype, const void* a, const void* dh, const float* scale, const float* shift, const float* mean,
                        const float* rstd, int relu, int groups, long M, int C, double* tmp, void* da, float* dgamma,
                        float* dbeta, void* stream);

@@ -280,3 +280,54 @@ def test_conv3x3_implicit_gemm_fwd_dgrad_wgrad(N, shape):
     torch.cuda.synchronize()
     ref_dw = torch.nn.grad.conv2d_weight(x_nchw.double(), wq.shape, dy_nchw, padding=1)
     assert rel_l2(dW.cpu(), ref_dw.cpu()) < 1e-5
+
+
+# ------------------------------------------------------------------------- fused BatchNorm1d(train) of the projector
+@pytest.mark.parametrize("adtype,gdtype", [(1, 0), (0, 0), (1, 1)])
+@pytest.mark.parametrize("M,C,affine,relu", [(512, 256, True, 1), (200, 64, False, 0), (1000, 96, True, 1)])
+def test_colbn_train_fused_fwd_bwd_vs_torch(N, adtype, gdtype, M, C, affine, relu):
+    """colbn_train_fwd / the single-launch colbn_bwd against torch's train-mode batch_norm (fp32, autograd) on two groups
+    that share the layer: statistics per group, running statistics updated group after group."""
+    G = 2
+    g = torch.Generator().manual_seed(5)
+    a32 = (torch.randn(G, M, C, generator=g) * 1.7 + 0.4).cuda()
+    a = a32.to(N.torch_dtype(adtype)).contiguous()
+    aref = a.float().clone().requires_grad_(True)
+    gamma = (torch.rand(C, generator=g) + 0.5).cuda() if affine else None
+    beta = (torch.randn(C, generator=g) * 0.1).cuda() if affine else None
+    rm, rv = torch.zeros(C, device="cuda"), torch.ones(C, device="cuda")
+    rm_ref, rv_ref = rm.clone(), rv.clone()
+    gref = gamma.clone().requires_grad_(True) if affine else None
+    bref = beta.clone().requires_grad_(True) if affine else None
+    outs = []
+    for k in range(G):
+        y = torch.nn.functional.batch_norm(aref[k], rm_ref, rv_ref, gref, bref, True, 0.1, 1e-5)
+        outs.append(torch.relu(y) if relu else y)
+    href = torch.stack(outs)
+    h = torch.empty(G, M, C, device="cuda", dtype=torch.bfloat16)
+    st = torch.empty(4, G * C, device="cuda")
+    N.call("colbn_train_fwd", 1, adtype, a, gamma, beta, rm, rv, 0.1, 1e-5, relu, G, M, C, h, st[0], st[1], st[2], st[3])
+    torch.cuda.synchronize()
+    assert rel_l2(h.float().cpu(), href.detach().cpu()) < 4e-3
+    assert rel_l2(rm.cpu(), rm_ref.cpu()) < 1e-5 and rel_l2(rv.cpu(), rv_ref.cpu()) < 1e-5
+    # the separate kernels produce the same statistics
+    sq = torch.zeros(2, G * C, device="cuda", dtype=torch.float64)
+    st2 = torch.empty(4, G * C, device="cuda")
+    if C % 64 == 0:
+        N.call("colstats", adtype, a, G, M, C, C, 1, sq[0], sq[1])
+        N.call("bn_finalize", sq[0], sq[1], G, float(M), C, gamma, beta, None, None, 0.1, 1e-5, st2[0], st2[1], st2[2], st2[3])
+        torch.cuda.synchronize()
+        assert rel_l2(st.cpu(), st2.cpu()) < 1e-5
+    # backward
+    dh32 = torch.randn(G, M, C, generator=g).cuda()
+    dh = dh32.to(N.torch_dtype(gdtype)).contiguous()
+    href.backward(dh.float())
+    da = torch.empty(G, M, C, device="cuda", dtype=torch.bfloat16)
+    dg, db = (torch.zeros(C, device="cuda"), torch.zeros(C, device="cuda")) if affine else (None, None)
+    tmp = torch.zeros(2 * G * C, device="cuda", dtype=torch.float64)
+    if C % 64 == 0:
+        N.call("colbn_bwd", 1, adtype, gdtype, a, dh, st[0], st[1], st[2], st[3], relu, G, M, C, tmp, da, dg, db)
+        torch.cuda.synchronize()
+        assert rel_l2(da.float().cpu(), aref.grad.cpu()) < 6e-3
+        if affine:
+            assert rel_l2(dg.cpu(), gref.grad.cpu()) < 1e-4 and rel_l2(db.cpu(), bref.grad.cpu()) < 1e-4
