@@ -87,7 +87,22 @@ __global__ __launch_bounds__(64 * NW, 1) void conv3x3_kernel(ConvArgs a) {
     }
     H::zero_border(hl);
 
-    float ssum[2] = {0.f, 0.f}, ssq[2] = {0.f, 0.f};
+    // The MFMAs compute Y^T (A = weights: rows = output channels, B = pixels: columns), so a lane ends up with ONE pixel and
+    // 16 channels per accumulator in runs of four consecutive ones (C/D map: column = lane & 31 = pixel of the row-tile,
+    // row = (r & 3) + 8 * (r >> 2) + 4 * h = channel): the epilogue stores 8 bytes (bf16) or 16 bytes (fp32) per lane and
+    // run.  With channels across lanes it issued one 2-byte store per element - 256 wave-stores of 128 bytes per tile, which
+    // took ~5x longer than the tile's MFMAs.  Per-channel statistics are kept per lane and folded across lanes once.
+    float ssum[2][16], ssq[2][16];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { ssum[j][r] = 0.f; ssq[j][r] = 0.f; }
+    f32x4 bias4[2][4];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            bias4[j][q] = a.bias ? *reinterpret_cast<const f32x4*>(a.bias + j * 32 + 8 * q + 4 * h) : f32x4{0.f, 0.f, 0.f, 0.f};
     H halo;
     int tile = blockIdx.x;
     if (tile < a.tiles) { halo.load(a.X, tile * TT, a.rows_total); halo.put(hl); }
@@ -98,7 +113,7 @@ __global__ __launch_bounds__(64 * NW, 1) void conv3x3_kernel(ConvArgs a) {
         const int next = tile + gridDim.x;
         if (next < a.tiles) halo.load(a.X, next * TT, a.rows_total);
 
-        // per-lane geometry of the two 32-pixel row-tiles this wave owns
+        // per-lane geometry of the 32-pixel row-tiles this wave owns
         int tl[RT], fcol[RT];
         bool ok[RT][3];
 #pragma unroll
@@ -136,31 +151,30 @@ __global__ __launch_bounds__(64 * NW, 1) void conv3x3_kernel(ConvArgs a) {
                 for (int i = 0; i < RT; ++i)
 #pragma unroll
                     for (int j = 0; j < 2; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i].v, fb[j].v, acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[j].v, fa[i].v, acc[i][j], 0, 0, 0);
             }
         }
-        // epilogue: C/D map col = lane&31 (channel), row = (r&3) + 8*(r>>2) + 4*h (pixel of the row-tile)
+        // epilogue: this lane's pixel, channels j * 32 + 8 * q + 4 * h + (0..3) in accumulator registers 4q..4q+3
 #pragma unroll
         for (int i = 0; i < RT; ++i) {
-            const int rt = RT * wave + i;
+            const int g = g0 + tl[i];
+            if (g < a.rows_total) {
+                const long o = ((long)g * FI + fcol[i]) * CH;
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const int co = j * 32 + m;
-                const float bias = a.bias ? a.bias[co] : 0.f;
+                for (int j = 0; j < 2; ++j)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
-                    const int t_local = FI == 32 ? rt : 2 * rt + (row >> 4);
-                    const int f = FI == 32 ? row : (row & 15);
-                    const int g = g0 + t_local;
-                    if (g < a.rows_total) {
-                        const float v = acc[i][j][r] + bias;
-                        ssum[j] += v;
-                        ssq[j] += v * v;
-                        if (a.out_f32) reinterpret_cast<float*>(a.Y)[((long)g * FI + f) * CH + co] = v;
-                        else a.Y[((long)g * FI + f) * CH + co] = (bf16)v;
+                    for (int q = 0; q < 4; ++q) {
+                        f32x4 v;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            v[e] = acc[i][j][4 * q + e] + bias4[j][q][e];
+                            ssum[j][4 * q + e] += v[e];
+                            ssq[j][4 * q + e] += v[e] * v[e];
+                        }
+                        const int co = j * 32 + 8 * q + 4 * h;
+                        if (a.out_f32) *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(a.Y) + o + co) = v;
+                        else *reinterpret_cast<bf16x4*>(a.Y + o + co) = bf16x4{(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
                     }
-                }
             }
         }
         __syncthreads();                       // every wave is done reading this halo tile
@@ -169,10 +183,17 @@ __global__ __launch_bounds__(64 * NW, 1) void conv3x3_kernel(ConvArgs a) {
     }
     if (a.sum) {
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const float s = ssum[j] + __shfl_xor(ssum[j], 32, 64), q = ssq[j] + __shfl_xor(ssq[j], 32, 64);
-            if (h == 0) { red[(wave * 64 + j * 32 + m) * 2] = s; red[(wave * 64 + j * 32 + m) * 2 + 1] = q; }
-        }
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float s = ssum[j][r], q = ssq[j][r];
+#pragma unroll
+                for (int o = 16; o > 0; o >>= 1) { s += __shfl_xor(s, o, 64); q += __shfl_xor(q, o, 64); }   // over the 32 pixels
+                if (m == 0) {
+                    const int co = j * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                    red[(wave * 64 + co) * 2] = s; red[(wave * 64 + co) * 2 + 1] = q;
+                }
+            }
         __syncthreads();
         if (threadIdx.x < 128) {
             const int c = threadIdx.x >> 1, k = threadIdx.x & 1;
@@ -186,6 +207,7 @@ __global__ __launch_bounds__(64 * NW, 1) void conv3x3_kernel(ConvArgs a) {
 
 struct WgradArgs {
     const bf16* dY; const bf16* X; float* dW; int Ti, rows_total, tiles;
+    float* partial;           // [gridDim.x * KG][64 * 576] per-(workgroup, pixel-half) results, or null: fp32 atomics into dW
 };
 
 // KG = 2: 8 waves; waves 4-7 take the second half of each tile's pixels (the contraction dimension) with their own 9
@@ -245,6 +267,7 @@ __global__ __launch_bounds__(256 * KG, 1) void conv3x3_wgrad_kernel(WgradArgs a)
             const int g = g0 + t_local;
             if (g >= a.rows_total) break;                         // wave-uniform: the remaining rows are padding
             const int ti = g % a.Ti;
+            const bool okt[3] = {ti - 1 >= 0, true, ti + 1 < a.Ti};          // wave-uniform: tap row inside the image in t
             // A = dY^T: rows = co, k = pixel.  lane gets co = cot*32 + (lane&31), pixels 8h + {0..7}
             const bf16* ay = yl + (ks * 16 + 8 * h + q) * PIXW + cot * 32 + 16 * half + 4 * p;
             const bf16x4 a0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds4_t)ay);
@@ -254,11 +277,13 @@ __global__ __launch_bounds__(256 * KG, 1) void conv3x3_wgrad_kernel(WgradArgs a)
             for (int n = 0; n < 9; ++n) {
                 const int nt = n0 + n, tap = nt >> 1, cih = nt & 1;
                 const int dt = tap % 3, df = tap / 3;
-                if (ti + dt - 1 < 0 || ti + dt - 1 >= a.Ti) continue;       // wave-uniform: tap leaves the image in t
+                // no branch around a tap that leaves the image (the halo row exists in LDS, it belongs to the neighbouring
+                // image): the fragment is zeroed instead, so the 18 transposing reads of a k-step can all be in flight
                 const bf16* bx = hl + ((t_local + dt) * COLS + f0 + df + 8 * h + q) * PIXW + cih * 32 + 16 * half + 4 * p;
                 const bf16x4 b0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds4_t)bx);
                 const bf16x4 b1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds4_t)(bx + 4 * PIXW));
-                const bf16x8 fb = bf16x8{b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3]};
+                const bf16 z = (bf16)0.f;
+                const bf16x8 fb = okt[dt] ? bf16x8{b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3]} : bf16x8{z, z, z, z, z, z, z, z};
                 acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb, acc[n], 0, 0, 0);
             }
         }
@@ -266,7 +291,20 @@ __global__ __launch_bounds__(256 * KG, 1) void conv3x3_wgrad_kernel(WgradArgs a)
         if (next < a.tiles) { halo.put(hl); put_y(); }
         __syncthreads();
     }
-    // dW[co][tap*64 + ci] += acc: col = lane&31 -> ci, row -> co
+    // dW[co][tap*64 + ci] += acc: col = lane&31 -> ci, row -> co.  With a workspace every (workgroup, pixel-half) stores its
+    // 64 x 576 result with plain stores and wgrad_reduce_kernel folds them: 256 workgroups x 2 halves adding into the same
+    // 36,864 addresses with device-scope atomics took longer than the MFMAs of the whole pass.
+    if (a.partial) {
+        // workspace layout = accumulator layout, element ((wave * 9 + n) * 4 + r / 4) * 64 + lane holds registers 4(r/4)..+3:
+        // 16-byte stores, 1 KB contiguous per wave-instruction; wgrad_reduce_kernel undoes the map
+        f32x4* part = reinterpret_cast<f32x4*>(a.partial + ((long)blockIdx.x * KG + grp) * (CH * KTOT));
+#pragma unroll
+        for (int n = 0; n < 9; ++n)
+#pragma unroll
+            for (int r4 = 0; r4 < 4; ++r4)
+                part[((wave * 9 + n) * 4 + r4) * 64 + lane] = f32x4{acc[n][4 * r4], acc[n][4 * r4 + 1], acc[n][4 * r4 + 2], acc[n][4 * r4 + 3]};
+        return;
+    }
 #pragma unroll
     for (int n = 0; n < 9; ++n) {
         const int nt = n0 + n, tap = nt >> 1, cih = nt & 1;
@@ -277,6 +315,29 @@ __global__ __launch_bounds__(256 * KG, 1) void conv3x3_wgrad_kernel(WgradArgs a)
             atomicAdd(&a.dW[co * KTOT + col], acc[n][r]);
         }
     }
+}
+
+// dW[i] += sum over parts; blockIdx.y takes every gridDim.y-th part (a handful of atomics per address remain)
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ partial, int nparts, float* __restrict__ dW) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= CH * KTOT) return;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int w = blockIdx.y;
+    const int step = gridDim.y;
+    for (; w + 3 * step < nparts; w += 4 * step) {
+        s0 += partial[(long)w * (CH * KTOT) + i];
+        s1 += partial[(long)(w + step) * (CH * KTOT) + i];
+        s2 += partial[(long)(w + 2 * step) * (CH * KTOT) + i];
+        s3 += partial[(long)(w + 3 * step) * (CH * KTOT) + i];
+    }
+    for (; w < nparts; w += step) s0 += partial[(long)w * (CH * KTOT) + i];
+    // i = (((wave * 9 + n) * 4 + r4) * 64 + lane) * 4 + e  ->  dW[co][tap * 64 + ci]
+    const int e = i & 3, lane = (i >> 2) & 63, r4 = (i >> 8) & 3, wn = i >> 10;
+    const int wave = wn / 9, n = wn - wave * 9;
+    const int nt = (wave >> 1) * 9 + n, tap = nt >> 1, cih = nt & 1;
+    const int col = tap * 64 + cih * 32 + (lane & 31);
+    const int co = (wave & 1) * 32 + e + 8 * r4 + 4 * (lane >> 5);
+    atomicAdd(&dW[co * KTOT + col], (s0 + s1) + (s2 + s3));
 }
 
 template <typename K>
@@ -321,16 +382,20 @@ extern "C" int audiossl_conv3x3_fwd(const void* X, const void* W, const float* b
 }
 
 // dWp fp32 [64][576] += dY^T * im2col(X)   (caller zeroes dWp; unpack with audiossl_unpack_conv_dw)
-extern "C" int audiossl_conv3x3_wgrad(const void* dY, const void* X, float* dWp, int N, int Ti, int Fi, void* stream) {
+extern "C" int audiossl_conv3x3_wgrad(const void* dY, const void* X, float* dWp, float* workspace, long workspace_floats, int N,
+                                      int Ti, int Fi, void* stream) {
     ASSL_REQUIRE(dY && X && dWp && N > 0 && Ti > 0 && (Fi == 32 || Fi == 16));
     if (!ASSL_ALIGNED16(X) || !ASSL_ALIGNED16(dY)) return ASSL_EALIGN;
     hipStream_t s = static_cast<hipStream_t>(stream);
     const int rows = N * Ti, TT = 256 / Fi, tiles = (rows + TT - 1) / TT;
-    WgradArgs a{static_cast<const bf16*>(dY), static_cast<const bf16*>(X), dWp, Ti, rows, tiles};
     const int grid = tiles < 256 ? tiles : 256;
-    // measured: the pixel split pays on the 32-pixel-wide layer (304 -> 275 us) and costs on the 16-wide one (112 -> 119 us)
+    // workspace (optional): 2 * 256 * 64 * 576 floats cover every launch shape; without it the results go through atomics
+    const bool two_stage = workspace != nullptr && workspace_floats >= 2L * grid * CH * KTOT;
+    WgradArgs a{static_cast<const bf16*>(dY), static_cast<const bf16*>(X), dWp, Ti, rows, tiles, two_stage ? workspace : nullptr};
+    // measured in isolation (tools/conv_bench.py, B = 512): two-stage with the pixel split 122 / 46 us (32- / 16-wide layer),
+    // without it 140 / 51 us; atomics 147 / 67 us without the split and 155 / 91 us with it (twice the atomics)
     static const int kg_env = getenv("AUDIOSSL_WGRAD_KG") ? atoi(getenv("AUDIOSSL_WGRAD_KG")) : 0;
-    const int kg = kg_env ? kg_env : (Fi == 32 ? 2 : 1);
+    const int kg = kg_env ? kg_env : (two_stage ? 2 : 1);
     static bool attr[4] = {false, false, false, false};
 #define WGRAD_LAUNCH(FI_, KG_, SLOT)                                                                      \
     do {                                                                                                  \
@@ -341,5 +406,7 @@ extern "C" int audiossl_conv3x3_wgrad(const void* dY, const void* X, float* dWp,
     if (Fi == 32) { if (kg == 2) WGRAD_LAUNCH(32, 2, 0); else WGRAD_LAUNCH(32, 1, 1); }
     else          { if (kg == 2) WGRAD_LAUNCH(16, 2, 2); else WGRAD_LAUNCH(16, 1, 3); }
 #undef WGRAD_LAUNCH
+    if (two_stage)
+        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(CH * KTOT / 256, 8), dim3(256), 0, s, workspace, grid * kg, dWp);
     ASSL_LAUNCH_CHECK();
 }

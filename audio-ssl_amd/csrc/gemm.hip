@@ -35,7 +35,8 @@ struct GemmArgs {
     const void* gate;         // T [M][ldg]: out = gate > 0 ? out : 0
     long ldg;
     int out_f32;              // C is float even when T is bf16
-    int atomic;               // C (float) += via atomicAdd (split-K / multi-source accumulation)
+    int atomic;               // 1: C (float) += via atomicAdd (split-K / concurrent accumulation); 2: C += by plain
+                              // load-add-store (one launch at a time owns C: no split-K, no concurrent writers)
     int ksplit;               // gridDim.z
     const float* resid;       // fp32 [M][ldr] added to the result (out-of-place residual connection) or null
     long ldr;
@@ -105,7 +106,8 @@ __device__ __forceinline__ void epilogue_lds(const GemmArgs& g, f32x16 (&acc)[MI
         for (int u = 0; u < 8; ++u) {
             if (r0 + u >= rows) break;
             const long o = (long)(row0 + r0 + u) * g.ldc + col;
-            if (g.atomic)       atomicAdd(static_cast<float*>(g.C) + o, v[u]);
+            if (g.atomic == 1)  atomicAdd(static_cast<float*>(g.C) + o, v[u]);
+            else if (g.atomic)  static_cast<float*>(g.C)[o] += v[u];
             else if (g.out_f32) static_cast<float*>(g.C)[o] = v[u];
             else                static_cast<T*>(g.C)[o] = from_f32<T>(v[u]);
         }
@@ -168,6 +170,11 @@ __device__ __forceinline__ void epilogue_vec(const GemmArgs& g, f32x16 (&acc)[MI
         const long o = row * g.ldc + col;
         if (g.out_f32) {
             Vec8<float> out;
+            if (g.atomic) {                                   // exclusive accumulation (atomic == 2)
+                const Vec8<float> c0 = Vec8<float>::load(static_cast<const float*>(g.C) + o);
+#pragma unroll
+                for (int u = 0; u < 8; ++u) v[u] += c0.get(u);
+            }
 #pragma unroll
             for (int u = 0; u < 8; ++u) out.set(u, v[u]);
             out.store(static_cast<float*>(g.C) + o);
@@ -577,7 +584,7 @@ int dispatch(const GemmArgs& g, int ta, int tb, hipStream_t s) {
 // the 8-columns-per-lane epilogue needs whole, aligned vectors of every operand it touches
 int epi_vectorisable(const GemmArgs& g, int dtype) {
     static const bool on = getenv("AUDIOSSL_GEMM_VEC_EPI") ? atoi(getenv("AUDIOSSL_GEMM_VEC_EPI")) != 0 : true;
-    if (!on || dtype != 1 || g.atomic || g.N % 8) return 0;
+    if (!on || dtype != 1 || g.atomic == 1 || g.N % 8) return 0;
     const size_t csz = g.out_f32 ? 4 : 2;
     if (((size_t)g.C * 1) % 16 || (g.ldc * csz) % 16) return 0;
     if (g.bias && (size_t)g.bias % 16) return 0;
@@ -589,22 +596,25 @@ int epi_vectorisable(const GemmArgs& g, int dtype) {
 
 }  // namespace
 
-extern "C" int audiossl_gemm_multi(int count, int trans_a, int trans_b, int M, int N, const int* K, float alpha,
+extern "C" int audiossl_gemm_multi(int count, int trans_a, int trans_b, int M, const int* Nv, const int* K, float alpha,
                                    const void* const* A, const long* lda, const void* const* B, const long* ldb,
-                                   void* const* C, long ldc, int out_f32, int atomic, int ksplit, void* stream) {
-    ASSL_REQUIRE(count >= 1 && count <= MAX_MULTI && K && A && B && C && lda && ldb && M > 0 && N > 0 && ksplit >= 1);
+                                   void* const* C, const long* ldcv, int out_f32, int atomic, int ksplit, void* stream) {
+    ASSL_REQUIRE(count >= 1 && count <= MAX_MULTI && Nv && K && A && B && C && lda && ldb && ldcv && M > 0 && ksplit >= 1);
+    int N = 0;                                               // widest problem: sizes the grid, narrower ones leave blocks idle
+    for (int i = 0; i < count; ++i) { ASSL_REQUIRE(Nv[i] > 0); N = max(N, Nv[i]); }
+    ASSL_REQUIRE(atomic >= 0 && atomic <= 2);
     ASSL_REQUIRE(!atomic || out_f32);
-    ASSL_REQUIRE(ksplit == 1 || atomic);
+    ASSL_REQUIRE(ksplit == 1 || atomic == 1);
     GemmMulti gm;
     int kmin = 1 << 30;
     for (int i = 0; i < count; ++i) {
         ASSL_REQUIRE(A[i] && B[i] && C[i] && K[i] > 0);
-        ASSL_REQUIRE((trans_a ? M : K[i]) % 8 == 0 && (trans_b ? N : K[i]) % 8 == 0);
+        ASSL_REQUIRE((trans_a ? M : K[i]) % 8 == 0 && (trans_b ? Nv[i] : K[i]) % 8 == 0);
         if (!ASSL_ALIGNED16(A[i]) || !ASSL_ALIGNED16(B[i]) || lda[i] % 8 || ldb[i] % 8) return ASSL_EALIGN;
         const long a_ext = (trans_a ? ((long)(K[i] - 1) * lda[i] + M) : ((long)(M - 1) * lda[i] + K[i])) * 2;
-        const long b_ext = (trans_b ? ((long)(K[i] - 1) * ldb[i] + N) : ((long)(N - 1) * ldb[i] + K[i])) * 2;
+        const long b_ext = (trans_b ? ((long)(K[i] - 1) * ldb[i] + Nv[i]) : ((long)(Nv[i] - 1) * ldb[i] + K[i])) * 2;
         ASSL_REQUIRE(a_ext < 0xFFFFFF00L && b_ext < 0xFFFFFF00L);
-        gm.p[i] = GemmArgs{A[i], B[i], C[i], M, N, K[i], lda[i], ldb[i], ldc, alpha, nullptr, 0, nullptr, 0, 1.f, nullptr, 0,
+        gm.p[i] = GemmArgs{A[i], B[i], C[i], M, Nv[i], K[i], lda[i], ldb[i], ldcv[i], alpha, nullptr, 0, nullptr, 0, 1.f, nullptr, 0,
                            out_f32, atomic, ksplit, nullptr, 0, (unsigned)a_ext, (unsigned)b_ext, 0};
         gm.p[i].vec_epi = epi_vectorisable(gm.p[i], 1);
         kmin = min(kmin, K[i]);
@@ -634,8 +644,9 @@ extern "C" int audiossl_gemm(int dtype, int trans_a, int trans_b, int M, int N, 
                              void* stream) {
     ASSL_REQUIRE(A && B && C && M > 0 && N > 0 && K > 0 && ksplit >= 1);
     ASSL_REQUIRE(dtype == 0 || dtype == 1);
+    ASSL_REQUIRE(atomic >= 0 && atomic <= 2);
     ASSL_REQUIRE(!atomic || out_f32 || dtype == 0);
-    ASSL_REQUIRE(ksplit == 1 || atomic);
+    ASSL_REQUIRE(ksplit == 1 || atomic == 1);
     ASSL_REQUIRE(!resid || (ksplit == 1 && !atomic));
     // vector (8-element) dimension of each operand must be a multiple of 8 and its rows 16-byte aligned
     ASSL_REQUIRE((trans_a ? M : K) % 8 == 0 && (trans_b ? N : K) % 8 == 0);

@@ -200,7 +200,7 @@ __device__ __forceinline__ void strip_reduce(const float (&part)[NS][8], float (
 }
 
 template <typename TA, typename T_, int NR>
-__global__ __launch_bounds__(256) void colbn_train_fwd_kernel(const TA* __restrict__ a, const float* __restrict__ gamma,
+__device__ __forceinline__ void colbn_train_fwd_body(const TA* __restrict__ a, const float* __restrict__ gamma,
                                                               const float* __restrict__ beta, float* running_mean,
                                                               float* running_var, float momentum, float eps, int relu, int groups,
                                                               int M, int C, T_* __restrict__ h, float* __restrict__ scale,
@@ -263,13 +263,39 @@ __global__ __launch_bounds__(256) void colbn_train_fwd_kernel(const TA* __restri
     if (threadIdx.x < 32 && running_mean) { running_mean[c] = rm; running_var[c] = rv; }
 }
 
+template <typename TA, typename T_, int NR>
+__global__ __launch_bounds__(256) void colbn_train_fwd_kernel(const TA* __restrict__ a, const float* __restrict__ gamma,
+                                                              const float* __restrict__ beta, float* running_mean,
+                                                              float* running_var, float momentum, float eps, int relu, int groups,
+                                                              int M, int C, T_* __restrict__ h, float* __restrict__ scale,
+                                                              float* __restrict__ shift, float* __restrict__ save_mean,
+                                                              float* __restrict__ save_rstd) {
+    colbn_train_fwd_body<TA, T_, NR>(a, gamma, beta, running_mean, running_var, momentum, eps, relu, groups, M, C, h, scale, shift,
+                                     save_mean, save_rstd);
+}
+
+// Several layers of one shape in ONE launch (blockIdx.y / .z = problem): the BatchNorms of the three Barlow heads.
+constexpr int MAXP = 4;
+struct BnFwdMulti {
+    const void* a[MAXP]; const float* gamma[MAXP]; const float* beta[MAXP]; float* rm[MAXP]; float* rv[MAXP];
+    void* h[MAXP]; float* st[MAXP];                          // st: [4][G*C] = scale, shift, mean, rstd
+};
+template <typename TA, typename T_, int NR>
+__global__ __launch_bounds__(256) void colbn_train_fwd_multi_kernel(BnFwdMulti m, float momentum, float eps, int relu, int groups,
+                                                                    int M, int C) {
+    const int p = blockIdx.y;
+    const long GC = (long)groups * C;
+    float* st = m.st[p];
+    colbn_train_fwd_body<TA, T_, NR>(static_cast<const TA*>(m.a[p]), m.gamma[p], m.beta[p], m.rm[p], m.rv[p], momentum, eps, relu,
+                                     groups, M, C, static_cast<T_*>(m.h[p]), st, st + GC, st + 2 * GC, st + 3 * GC);
+}
+
 // backward of the same: grid (C / 32, groups); sg / sgx as in colbn_bwd_stats_kernel, then da in the same launch
 template <typename TA, typename TG, typename T_, int NR>
-__global__ __launch_bounds__(256) void colbn_bwd_fused_kernel(const TA* __restrict__ a, const TG* __restrict__ dh,
-                                                              const float* __restrict__ scale, const float* __restrict__ shift,
-                                                              const float* __restrict__ mean, const float* __restrict__ rstd,
-                                                              int relu, int M, int C, T_* __restrict__ da, float* dgamma,
-                                                              float* dbeta) {
+__device__ __forceinline__ void colbn_bwd_fused_body(const TA* __restrict__ a, const TG* __restrict__ dh,
+                                                     const float* __restrict__ scale, const float* __restrict__ shift,
+                                                     const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                     int relu, int M, int C, T_* __restrict__ da, float* dgamma, float* dbeta) {
     __shared__ float red[64][65];
     __shared__ double tot[64];
     const int cl = threadIdx.x & 3, r0 = threadIdx.x >> 2;
@@ -320,6 +346,27 @@ __global__ __launch_bounds__(256) void colbn_bwd_fused_kernel(const TA* __restri
     }
 }
 
+template <typename TA, typename TG, typename T_, int NR>
+__global__ __launch_bounds__(256) void colbn_bwd_fused_kernel(const TA* __restrict__ a, const TG* __restrict__ dh,
+                                                              const float* __restrict__ scale, const float* __restrict__ shift,
+                                                              const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                              int relu, int M, int C, T_* __restrict__ da, float* dgamma,
+                                                              float* dbeta) {
+    colbn_bwd_fused_body<TA, TG, T_, NR>(a, dh, scale, shift, mean, rstd, relu, M, C, da, dgamma, dbeta);
+}
+
+struct BnBwdMulti {
+    const void* a[MAXP]; const void* dh[MAXP]; const float* st[MAXP]; void* da[MAXP]; float* dgamma[MAXP]; float* dbeta[MAXP];
+};
+template <typename TA, typename TG, typename T_, int NR>
+__global__ __launch_bounds__(256) void colbn_bwd_multi_kernel(BnBwdMulti m, int relu, int groups, int M, int C) {
+    const int p = blockIdx.z;
+    const long GC = (long)groups * C;
+    const float* st = m.st[p];
+    colbn_bwd_fused_body<TA, TG, T_, NR>(static_cast<const TA*>(m.a[p]), static_cast<const TG*>(m.dh[p]), st, st + GC, st + 2 * GC,
+                                         st + 3 * GC, relu, M, C, static_cast<T_*>(m.da[p]), m.dgamma[p], m.dbeta[p]);
+}
+
 __global__ void add_d2f_kernel(const double* __restrict__ src, float* __restrict__ dst, int n) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i < n) dst[i] += (float)src[i];
@@ -347,6 +394,32 @@ __global__ __launch_bounds__(256) void barlow_loss_kernel(const float* __restric
     }
     acc = block_sum(acc, sh);
     if (threadIdx.x == 0) atomicAdd(loss_out, coef * acc);
+}
+
+struct BarlowMulti { const float* c[MAXP]; void* dc[MAXP]; float* loss[MAXP]; float coef[MAXP]; float dscale[MAXP]; };
+template <typename T_>
+__global__ __launch_bounds__(256) void barlow_loss_multi_kernel(BarlowMulti m, int D) {
+    __shared__ float sh[16];
+    const int p = blockIdx.y;
+    const float* c = m.c[p];
+    T_* dc = static_cast<T_*>(m.dc[p]);
+    const float dscale = m.dscale[p];
+    const int total8 = D * (D / 8);
+    float acc = 0.f;
+    for (int v = blockIdx.x * 256 + threadIdx.x; v < total8; v += gridDim.x * 256) {
+        const int i = v / (D / 8), j0 = (v - i * (D / 8)) * 8;
+        const Vec8<float> x = Vec8<float>::load(c + (long)v * 8);
+        Vec8<T_> o;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const float d = x.get(k) - (i == j0 + k ? 1.f : 0.f);
+            acc += d * d;
+            o.set(k, dscale * d);
+        }
+        o.store(dc + (long)v * 8);
+    }
+    acc = block_sum(acc, sh);
+    if (threadIdx.x == 0) atomicAdd(m.loss[p], m.coef[p] * acc);
 }
 
 // --------------------------------------------------------------------------------------------- MoCo head
@@ -626,6 +699,71 @@ extern "C" int audiossl_colbn_bwd(int dtype, int adtype, int gdtype, const void*
     else if (gdtype == 0) CB(bf16, float, bf16);
     else CB(bf16, bf16, bf16);
 #undef CB
+    ASSL_LAUNCH_CHECK();
+}
+
+// ---- multi-problem forms for the three Barlow heads (bf16 outputs): `count` layers of one shape per launch.
+// stats[p]: [4][groups*C] fp32 = scale, shift, mean, rstd of problem p (written by the forward, read by the backward).
+extern "C" int audiossl_colbn_train_fwd_multi(int count, int adtype, const void* const* a, const float* const* gamma,
+                                              const float* const* beta, float* const* running_mean, float* const* running_var,
+                                              float momentum, float eps, int relu, int groups, long M, int C, void* const* h,
+                                              float* const* stats, void* stream) {
+    ASSL_REQUIRE(count >= 1 && count <= MAXP && a && h && stats && groups > 0 && M > 0 && M <= 1024 && C > 0 && (C % 32) == 0);
+    ASSL_REQUIRE(adtype == 0 || adtype == 1);
+    BnFwdMulti m{};
+    for (int p = 0; p < count; ++p) {
+        ASSL_REQUIRE(a[p] && h[p] && stats[p]);
+        m.a[p] = a[p]; m.h[p] = h[p]; m.st[p] = stats[p];
+        m.gamma[p] = gamma ? gamma[p] : nullptr; m.beta[p] = beta ? beta[p] : nullptr;
+        m.rm[p] = running_mean ? running_mean[p] : nullptr; m.rv[p] = running_var ? running_var[p] : nullptr;
+        ASSL_REQUIRE((m.rm[p] == nullptr) == (m.rv[p] == nullptr));
+    }
+    hipStream_t s = S_(stream);
+    dim3 grid(C / 32, count);
+#define TFM(TA, NR_) hipLaunchKernelGGL((colbn_train_fwd_multi_kernel<TA, bf16, NR_>), grid, dim3(256), 0, s, m, momentum, eps, relu, \
+                                        groups, (int)M, C)
+    if (adtype == 0) { if (M <= 512) TFM(float, 8); else TFM(float, 16); }
+    else             { if (M <= 512) TFM(bf16, 8); else TFM(bf16, 16); }
+#undef TFM
+    ASSL_LAUNCH_CHECK();
+}
+
+extern "C" int audiossl_colbn_bwd_multi(int count, int adtype, int gdtype, const void* const* a, const void* const* dh,
+                                        const float* const* stats, int relu, int groups, long M, int C, void* const* da,
+                                        float* const* dgamma, float* const* dbeta, void* stream) {
+    ASSL_REQUIRE(count >= 1 && count <= MAXP && a && dh && stats && da && groups > 0 && M > 0 && M <= 1024 && C > 0 && (C % 32) == 0);
+    ASSL_REQUIRE((adtype == 0 || adtype == 1) && (gdtype == 0 || gdtype == 1));
+    BnBwdMulti m{};
+    for (int p = 0; p < count; ++p) {
+        ASSL_REQUIRE(a[p] && dh[p] && stats[p] && da[p]);
+        m.a[p] = a[p]; m.dh[p] = dh[p]; m.st[p] = stats[p]; m.da[p] = da[p];
+        m.dgamma[p] = dgamma ? dgamma[p] : nullptr; m.dbeta[p] = dbeta ? dbeta[p] : nullptr;
+        ASSL_REQUIRE((m.dgamma[p] == nullptr) == (m.dbeta[p] == nullptr));
+    }
+    hipStream_t s = S_(stream);
+    dim3 grid(C / 32, groups, count);
+#define BWM(TA, TG, NR_) hipLaunchKernelGGL((colbn_bwd_multi_kernel<TA, TG, bf16, NR_>), grid, dim3(256), 0, s, m, relu, groups, (int)M, C)
+#define BWM2(TA, TG) do { if (M <= 512) BWM(TA, TG, 8); else BWM(TA, TG, 16); } while (0)
+    if (adtype == 0 && gdtype == 0) BWM2(float, float);
+    else if (adtype == 0) BWM2(float, bf16);
+    else if (gdtype == 0) BWM2(bf16, float);
+    else BWM2(bf16, bf16);
+#undef BWM2
+#undef BWM
+    ASSL_LAUNCH_CHECK();
+}
+
+extern "C" int audiossl_barlow_loss_multi(int count, const float* const* c, int D, const float* coef, const float* dscale,
+                                          void* const* dc, float* const* loss_out, void* stream) {
+    ASSL_REQUIRE(count >= 1 && count <= MAXP && c && coef && dscale && dc && loss_out && D > 0 && (D % 8) == 0 && D <= 16384);
+    BarlowMulti m{};
+    for (int p = 0; p < count; ++p) {
+        ASSL_REQUIRE(c[p] && dc[p] && loss_out[p]);
+        if (!ASSL_ALIGNED16(c[p]) || !ASSL_ALIGNED16(dc[p])) return ASSL_EALIGN;
+        m.c[p] = c[p]; m.dc[p] = dc[p]; m.loss[p] = loss_out[p]; m.coef[p] = coef[p]; m.dscale[p] = dscale[p];
+    }
+    const int grid = min(512, ceil_div((long)D * (D / 8), 256));
+    hipLaunchKernelGGL(barlow_loss_multi_kernel<bf16>, dim3(grid, count), dim3(256), 0, S_(stream), m, D);
     ASSL_LAUNCH_CHECK();
 }
 

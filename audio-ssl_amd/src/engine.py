@@ -127,7 +127,9 @@ def linear_fwd(dtype, X, W, M, Nout, K, bias=None, relu=0, keep=None, keep_scale
 
 def linear_bwd_w(dtype, dY, X, dW, M, Nout, K):
     """dW[Nout,K] += dY[M,Nout]^T @ X[M,K]   (split-K, fp32 atomics)"""
-    gemm(dtype, 1, 1, Nout, K, M, dY, Nout, X, K, dW, K, out_f32=1, atomic=1, ksplit=_ksplit(Nout, K, M))
+    # every dW of the step is written by one stream at a time, so without split-K the accumulation needs no atomics
+    ks = _ksplit(Nout, K, M)
+    gemm(dtype, 1, 1, Nout, K, M, dY, Nout, X, K, dW, K, out_f32=1, atomic=1 if (ks > 1 or dtype != N.BF16) else 2, ksplit=ks)
 
 
 def linear_bwd_x(dtype, dY, W, M, Nout, K, alpha=1.0, gate=None, out=None, out_f32=0):
@@ -212,6 +214,19 @@ def _bn_eval(like, C, gamma, beta, rm, rv):
     scale, shift = _empty((C,), torch.float32, like=like), _empty((C,), torch.float32, like=like)
     N.call("bn_eval_affine", gamma, beta, rm, rv, BN_EPS, C, scale, shift)
     return scale, shift
+
+
+_WGRAD_WS = {}
+
+
+def _wgrad_workspace(device):
+    """Per-device scratch for the two-stage conv weight gradient (per-workgroup results + fold): 75.5 MB, allocated once
+    (before any graph capture: the eager priming steps come first).  Launches that share it are ordered on one stream."""
+    key = device.index if device.index is not None else torch.cuda.current_device()
+    ws = _WGRAD_WS.get(key)
+    if ws is None:
+        ws = _WGRAD_WS[key] = torch.empty(2 * 256 * 64 * 576, dtype=torch.float32, device=device)
+    return ws
 
 
 def _conv_block_fwd(dtype, Pin, Nimg, Ti, Fi, W, bias, bn, train, update_running, col):
@@ -332,7 +347,8 @@ def _conv_block_bwd(dtype, Y, dP, dxl, st, Nimg, Ti, Fi, Pin, Wd, G_w, G_gamma, 
     if fused:
         def wg():
             dWp = ARENA.zeros((64, 576), torch.float32, device=Y.device)
-            N.call("conv3x3_wgrad", dY, Pin, dWp, Nimg, Ti, Fi)
+            ws = _wgrad_workspace(Y.device)
+            N.call("conv3x3_wgrad", dY, Pin, dWp, ws, ws.numel(), Nimg, Ti, Fi)
             N.call("unpack_conv_dw", dWp, G_w)
             return dWp
         keep.append((dY, WGRAD.run(Y.device, wg)))             # off the critical path
@@ -521,27 +537,43 @@ def barlow_forward_backward(PP, G, Y, dtype, lambd, scale_loss, loss_out, need_d
 
 
 # =============================================================================================== several Barlow heads at once
+def _harr(ctype, xs):
+    """host array of scalars / device pointers for the multi-problem entry points (None -> null pointer)"""
+    import ctypes
+    vals = [x.data_ptr() if isinstance(x, torch.Tensor) else x for x in xs]
+    return (ctype * len(vals))(*vals)
+
+
+def _multi_check(*lists):
+    for ts in lists:
+        for t in ts:
+            if t is not None and (not t.is_cuda or not t.is_contiguous()):
+                raise RuntimeError("multi-problem launches need contiguous device tensors")
+
+
 def gemm_multi(ta, tb, M, Nn, Ks, As, ldas, Bs, ldbs, Cs, ldc, alpha=1.0, out_f32=0, atomic=0, ksplit=1):
-    """One launch for len(As) independent bf16 problems with common M, N, ldc, transposes and epilogue (audiossl_gemm_multi)."""
+    """One launch for len(As) independent bf16 problems with common M, transposes and epilogue (audiossl_gemm_multi).
+    Nn / ldc: one int for all problems or one per problem."""
     import ctypes
     n = len(As)
-    for t in list(As) + list(Bs) + list(Cs):
-        if not t.is_cuda or not t.is_contiguous():
-            raise RuntimeError("gemm_multi needs contiguous device tensors")
-    vp = lambda ts: (ctypes.c_void_p * n)(*[t.data_ptr() for t in ts])
-    li = lambda xs: (ctypes.c_long * n)(*[int(x) for x in xs])
-    K_, A_, B_, C_, la_, lb_ = (ctypes.c_int * n)(*[int(k) for k in Ks]), vp(As), vp(Bs), vp(Cs), li(ldas), li(ldbs)
+    _multi_check(As, Bs, Cs)
+    Ns = [Nn] * n if isinstance(Nn, int) else list(Nn)
+    ldcs = [ldc] * n if isinstance(ldc, int) else list(ldc)
     adr = ctypes.addressof
-    N.call("gemm_multi", n, ta, tb, M, Nn, adr(K_), float(alpha), adr(A_), adr(la_), adr(B_), adr(lb_), adr(C_), ldc, out_f32,
-           atomic, ksplit)
+    arrs = (_harr(ctypes.c_int, Ns), _harr(ctypes.c_int, Ks), _harr(ctypes.c_void_p, As), _harr(ctypes.c_long, ldas),
+            _harr(ctypes.c_void_p, Bs), _harr(ctypes.c_long, ldbs), _harr(ctypes.c_void_p, Cs), _harr(ctypes.c_long, ldcs))
+    N_, K_, A_, la_, B_, lb_, C_, lc_ = arrs
+    N.call("gemm_multi", n, ta, tb, M, adr(N_), adr(K_), float(alpha), adr(A_), adr(la_), adr(B_), adr(lb_), adr(C_), adr(lc_),
+           out_f32, atomic, ksplit)
 
 
 def barlow_heads_forward_backward(PPs, Gs, Ys, dtype, lambds, scale_losses, loss_outs, update_running=True, backward=True,
                                   Wcs=None):
-    """`barlow_forward_backward` for several heads in lock-step: every GEMM of the chain is ONE multi-problem launch over the
-    heads (they differ only in the first layer's K), the small BatchNorm / loss kernels are issued per head in between.
+    """`barlow_forward_backward` for several heads in lock-step: every step of the chain - GEMM, train-mode BatchNorm, loss -
+    is ONE multi-problem launch over the heads (they differ only in the width of the first layer's input).
     Ys[h]: [2B, in_h] stacked views; returns dY_h [B, in_h] (gradient of view 1's input) per head, fp32.
-    Not used on the bf16_hp path (split first GEMM) nor with the cross-GPU correlation all-reduce."""
+    bf16 path only (not bf16_hp: split first GEMM), no cross-GPU correlation all-reduce; B <= 1024."""
+    import ctypes
     nh = len(Ys)
     B = Ys[0].shape[0] // 2
     M = 2 * B
@@ -551,70 +583,68 @@ def barlow_heads_forward_backward(PPs, Gs, Ys, dtype, lambds, scale_losses, loss
     D = W[0][0].shape[0]
     kins = [Y.shape[1] for Y in Ys]
     ad = _ad(dtype)
-    o32 = int(ad == N.F32)
-    tad = torch.float32 if o32 else td
+    if dtype != N.BF16 or ad != N.BF16 or B > 1024 or D % 32:
+        raise RuntimeError("grouped Barlow heads: bf16 path with B <= 1024 only")
     H = range(nh)
-
-    def bn(h, a, prefix, affine, relu, out):
-        PP = PPs[h]
-        return bn_train_apply(dtype, ad, a, B, D, PP[prefix + ".weight"] if affine else None,
-                              PP[prefix + ".bias"] if affine else None, PP[prefix + ".running_mean"],
-                              PP[prefix + ".running_var"], update_running, 2, relu, out)
+    vp, fl, adr = ctypes.c_void_p, ctypes.c_float, ctypes.addressof
+    new = lambda rows, cols, t: [torch.empty(rows, cols, dtype=t, device=dev) for _ in H]
 
     def layer(xs, ws, ks, prefix, affine, relu):
-        a = [torch.empty(M, D, dtype=tad, device=dev) for _ in H]
-        gemm_multi(0, 0, M, D, ks, xs, ks, ws, ks, a, D, out_f32=o32)
-        out = [torch.empty(M, D, dtype=td, device=dev) for _ in H]
-        st = [bn(h, a[h], prefix, affine, relu, out[h]) for h in H]
+        a = new(M, D, td)
+        gemm_multi(0, 0, M, D, ks, xs, ks, ws, ks, a, D)
+        out, st = new(M, D, td), new(4, 2 * D, torch.float32)
+        par = lambda suffix, on=True: _harr(vp, [PP[prefix + suffix] if on else None for PP in PPs])
+        arrs = (_harr(vp, a), par(".weight", affine), par(".bias", affine), par(".running_mean", update_running),
+                par(".running_var", update_running), _harr(vp, out), _harr(vp, st))
+        _multi_check(a, out, st)
+        N.call("colbn_train_fwd_multi", nh, ad, adr(arrs[0]), adr(arrs[1]), adr(arrs[2]), adr(arrs[3]), adr(arrs[4]),
+               BN_MOMENTUM, BN_EPS, relu, 2, B, D, adr(arrs[5]), adr(arrs[6]))
         return a, st, out
     a1, st1, h1 = layer(Ys, [W[h][0] for h in H], kins, "projector.1", True, 1)
     a2, st2, h2 = layer(h1, [W[h][1] for h in H], [D] * nh, "projector.4", True, 1)
     z, st0, zn = layer(h2, [W[h][2] for h in H], [D] * nh, "bn", False, 0)
     # correlation c_h = zn1^T zn2 / B, loss, dc
-    cm = [torch.empty(D, D, dtype=torch.float32, device=dev) for _ in H]
+    cm = new(D, D, torch.float32)
     gemm_multi(1, 1, D, D, [B] * nh, [zn[h][:B] for h in H], [D] * nh, [zn[h][B:] for h in H], [D] * nh, cm, D,
                alpha=1.0 / B, out_f32=1)
-    dc = [torch.empty(D, D, dtype=td, device=dev) for _ in H]
-    for h in H:
-        coef = (lambds[h] if lambds[h] else 1.0) * scale_losses[h]
-        N.call("barlow_loss", dtype, cm[h], D, coef, 2.0 * coef / B, dc[h], loss_outs[h])
+    dc = new(D, D, td)
+    coefs = [(lambds[h] if lambds[h] else 1.0) * scale_losses[h] for h in H]
+    arrs = (_harr(vp, cm), _harr(fl, coefs), _harr(fl, [2.0 * c / B for c in coefs]), _harr(vp, dc), _harr(vp, list(loss_outs)))
+    _multi_check(list(loss_outs))
+    N.call("barlow_loss_multi", nh, adr(arrs[0]), D, adr(arrs[1]), adr(arrs[2]), adr(arrs[3]), adr(arrs[4]))
     if not backward:
         return [None] * nh
-    dzn = [torch.empty(M, D, dtype=torch.float32, device=dev) for _ in H]
+    dzn = new(M, D, torch.float32)
     gemm_multi(0, 0, B, D, [D] * nh, [zn[h][B:] for h in H], [D] * nh, dc, [D] * nh, [dzn[h][:B] for h in H], D, out_f32=1)
     gemm_multi(0, 1, B, D, [D] * nh, [zn[h][:B] for h in H], [D] * nh, dc, [D] * nh, [dzn[h][B:] for h in H], D, out_f32=1)
 
     def bn_bwd(a, dh, st, relu, names):
-        out = [torch.empty(M, D, dtype=td, device=dev) for _ in H]
-        for h in H:
-            tmp = ARENA.scratch((2 * 2 * D,), torch.float64, dh[h])
-            N.call("colbn_bwd", dtype, ad, GD, a[h], dh[h], *st[h], relu, 2, B, D, tmp, out[h],
-                   Gs[h][names[0]] if names else None, Gs[h][names[1]] if names else None)
+        out = new(M, D, td)
+        grads = lambda k: _harr(vp, [Gs[h][names[k]] if names else None for h in H])
+        arrs = (_harr(vp, a), _harr(vp, dh), _harr(vp, st), _harr(vp, out), grads(0), grads(1))
+        _multi_check(a, dh, st)
+        N.call("colbn_bwd_multi", nh, ad, GD, adr(arrs[0]), adr(arrs[1]), adr(arrs[2]), relu, 2, B, D, adr(arrs[3]),
+               adr(arrs[4]), adr(arrs[5]))
         return out
 
-    def wgrad(dys, xs, name, ks):
-        dWs = [Gs[h][name] for h in H]
-        if len(set(ks)) == 1:
-            gemm_multi(1, 1, D, ks[0], [M] * nh, dys, [D] * nh, xs, ks, dWs, ks[0], out_f32=1, atomic=1,
-                       ksplit=_ksplit(D, ks[0], M, max(256 // nh, 1)))
-        else:                                           # first layer: the heads' input widths (= N of this GEMM) differ
-            for h in H:
-                linear_bwd_w(dtype, dys[h], xs[h], dWs[h], M, D, ks[h])
+    def wgrad(dys, xs, name, ks):                        # dW_h [D, k_h] += dy_h^T x_h; one writer per dW, so no atomics unless split
+        split = _ksplit(D, max(ks), M, max(256 // nh, 1))
+        gemm_multi(1, 1, D, ks, [M] * nh, dys, [D] * nh, xs, ks, [Gs[h][name] for h in H], ks, out_f32=1,
+                   atomic=1 if split > 1 else 2, ksplit=split)
 
-    def dgrad(dys, ws, K, rows):
-        out = [torch.empty(rows, K, dtype=torch.float32, device=dev) for _ in H]
-        gemm_multi(0, 1, rows, K, [D] * nh, dys, [D] * nh, ws, [K] * nh, out, K, out_f32=1)
+    def dgrad(dys, ws, Ks, rows):
+        out = [torch.empty(rows, k, dtype=torch.float32, device=dev) for k in Ks]
+        gemm_multi(0, 1, rows, Ks, [D] * nh, [dy[:rows] for dy in dys], [D] * nh, ws, Ks, out, Ks, out_f32=1)
         return out
     dz = bn_bwd(z, dzn, st0, 0, None)
     wgrad(dz, h2, "projector.6.weight", [D] * nh)
-    dh2 = dgrad(dz, [W[h][2] for h in H], D, M)
+    dh2 = dgrad(dz, [W[h][2] for h in H], [D] * nh, M)
     da2 = bn_bwd(a2, dh2, st2, 1, ("projector.4.weight", "projector.4.bias"))
     wgrad(da2, h1, "projector.3.weight", [D] * nh)
-    dh1 = dgrad(da2, [W[h][1] for h in H], D, M)
+    dh1 = dgrad(da2, [W[h][1] for h in H], [D] * nh, M)
     da1 = bn_bwd(a1, dh1, st1, 1, ("projector.1.weight", "projector.1.bias"))
     wgrad(da1, Ys, "projector.0.weight", kins)
-    # dY for view 1 only (rows [0, B)); widths differ per head
-    return [linear_bwd_x(dtype, da1[h], W[h][0], B, D, kins[h], out_f32=1) for h in H]
+    return dgrad(da1, [W[h][0] for h in H], kins, B)      # dY for view 1 only (rows [0, B)); widths differ per head
 
 
 # =============================================================================================== MoCo head

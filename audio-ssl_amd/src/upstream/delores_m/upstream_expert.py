@@ -8,6 +8,8 @@ InfoNCE against the queue, enqueue, three projector heads, and the complete back
 Multi-GPU (torch.distributed over RCCL): batch shuffle / unshuffle for the key encoder's BatchNorm, key all-gather
 before the enqueue (`:156-219`), keyed off the process group instead of the removed `trainer.use_ddp`.
 """
+import os
+
 import torch
 import torch.nn as nn
 
@@ -53,7 +55,7 @@ class Upstream_Expert(MocoQueueMixin, FusedExpertMixin, UpstreamModule):
         prec = config.get("run", {}).get("precision")
         self.precision = {"fp32": N.F32, "bf16": N.BF16, "bf16_hp": N.BF16}.get(prec, default_precision())
         self.high_precision = prec == "bf16_hp"
-        self.grouped_heads = bool(config.get("run", {}).get("grouped_heads", False))
+        self.grouped_heads = bool(config.get("run", {}).get("grouped_heads", os.environ.get("AUDIOSSL_GROUPED_HEADS", "1") != "0"))
         self.encoder_q.encoder.precision = self.encoder_k.encoder.precision = self.precision
         self.flat_k = None
         self._key_stream = E.SideStream()

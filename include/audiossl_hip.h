@@ -120,10 +120,13 @@ int audiossl_unpack_conv_dw(const float* dWp, float* dW, void* stream);
 /* Implicit-GEMM 3x3 / 64->64 convolution on the bf16 MFMA pipe (no im2col buffer); bf16 only, Fi in {32, 16}.
  * conv3x3_fwd : Y = conv(X, W) (+bias); W = packed [64][576] (pack_conv_w: Wf = forward, Wd = data gradient);
  *               optional BatchNorm batch statistics of the fp32 accumulators: sum / sumsq fp64 [64] (zeroed inside).
- * conv3x3_wgrad: dWp fp32 [64][576] += dY^T * patches(X) (caller zeroes; unpack_conv_dw maps back to [co][ci][3][3]). */
+ * conv3x3_wgrad: dWp fp32 [64][576] += dY^T * patches(X) (caller zeroes; unpack_conv_dw maps back to [co][ci][3][3]).
+ *   workspace (optional, 2 * 256 * 64 * 576 floats = 75.5 MB covers every shape): per-workgroup results are stored there and
+ *   folded by a second kernel; null = every workgroup adds its result to dWp with fp32 atomics. */
 int audiossl_conv3x3_fwd(const void* X, const void* W, const float* bias, void* Y, int out_f32, double* sum,
                          double* sumsq, int N, int Ti, int Fi, void* stream);
-int audiossl_conv3x3_wgrad(const void* dY, const void* X, float* dWp, int N, int Ti, int Fi, void* stream);
+int audiossl_conv3x3_wgrad(const void* dY, const void* X, float* dWp, float* workspace, long workspace_floats, int N, int Ti,
+                           int Fi, void* stream);
 
 /* ---- K9-K12 GEMM: every nn.Linear / matmul / einsum of the path ------------------------------------------
  * (audiontt.py:62-68; delores_s/upstream_expert.py:15-22, 36; delores_m/upstream_expert.py:250-252)
@@ -132,18 +135,19 @@ int audiossl_conv3x3_wgrad(const void* dY, const void* X, float* dWp, int N, int
  *   trans_b = 0: B is [N][K] (ldb)   trans_b = 1: B is [K][N] (ldb)     (torch Linear weights are [N][K])
  * Epilogue, in order: + bias[N]; ReLU; * keep[M][ldk] * keep_scale (dropout); zero where gate[M][ldg] <= 0;
  * + resid[M][ldr] (fp32, out-of-place residual connection of the transformer blocks; ksplit 1, not atomic);
- * store as dtype, or fp32 (out_f32), or fp32 atomicAdd (atomic; required when ksplit > 1). */
+ * store as dtype, or fp32 (out_f32), or accumulate into fp32 C: atomic = 1 by atomicAdd (required when ksplit > 1 or when
+ * other launches may add to C concurrently), atomic = 2 by plain load-add-store (this launch owns C; ksplit 1). */
 int audiossl_gemm(int dtype, int trans_a, int trans_b, int M, int N, int K, float alpha, const void* A, long lda,
                   const void* B, long ldb, void* C, long ldc, const float* bias, int relu, const uint8_t* keep, long ldk,
                   float keep_scale, const void* gate, long ldg, int out_f32, int atomic, int ksplit, const float* resid,
                   long ldr, void* stream);
 
-/* `count` (<= 4) independent bf16 problems of one kind in one launch (the three Barlow heads of delores_m): same M, N, ldc,
- * transposes and epilogue (alpha, fp32 / atomic output, split-K), per-problem K, operand pointers and leading dimensions.
- * K, A, lda, B, ldb, C are HOST arrays of `count` entries. */
-int audiossl_gemm_multi(int count, int trans_a, int trans_b, int M, int N, const int* K, float alpha, const void* const* A,
-                        const long* lda, const void* const* B, const long* ldb, void* const* C, long ldc, int out_f32,
-                        int atomic, int ksplit, void* stream);
+/* `count` (<= 4) independent bf16 problems of one kind in one launch (the three Barlow heads of delores_m): same M,
+ * transposes and epilogue (alpha, fp32 / accumulating output, split-K), per-problem N, K, operand pointers and leading
+ * dimensions.  N, K, A, lda, B, ldb, C, ldc are HOST arrays of `count` entries. */
+int audiossl_gemm_multi(int count, int trans_a, int trans_b, int M, const int* N, const int* K, float alpha,
+                        const void* const* A, const long* lda, const void* const* B, const long* ldb, void* const* C,
+                        const long* ldc, int out_f32, int atomic, int ksplit, void* stream);
 
 /* ---- encoder tail: delores_s/upstream_encoder.py:26-28 ---------------------------------------------------- */
 int audiossl_maxmean_fwd(int dtype, int out_f32, const void* H, void* y, uint8_t* arg, int N, int Tt, int D, void* stream);
@@ -167,6 +171,19 @@ int audiossl_colbn_train_fwd(int dtype, int adtype, const void* a, const float* 
 int audiossl_colbn_bwd(int dtype, int adtype, int gdtype, const void* a, const void* dh, const float* scale, const float* shift, const float* mean,
                        const float* rstd, int relu, int groups, long M, int C, double* tmp, void* da, float* dgamma,
                        float* dbeta, void* stream);
+/* Multi-problem forms (count <= 4 layers of one shape per launch, bf16 outputs) for the three Barlow heads p1-p3 of
+ * DeLoRes-M (`src/upstream/delores_m/upstream_expert.py:133-135, 271`), which run the same chain on different operands.
+ * The arrays are host arrays of device pointers (null array = null for every problem); stats[p] is [4][groups*C] fp32
+ * (scale, shift, mean, rstd), written by the forward and read by the backward.  coef / dscale: host arrays. */
+int audiossl_colbn_train_fwd_multi(int count, int adtype, const void* const* a, const float* const* gamma,
+                                   const float* const* beta, float* const* running_mean, float* const* running_var,
+                                   float momentum, float eps, int relu, int groups, long M, int C, void* const* h,
+                                   float* const* stats, void* stream);
+int audiossl_colbn_bwd_multi(int count, int adtype, int gdtype, const void* const* a, const void* const* dh,
+                             const float* const* stats, int relu, int groups, long M, int C, void* const* da,
+                             float* const* dgamma, float* const* dbeta, void* stream);
+int audiossl_barlow_loss_multi(int count, const float* const* c, int D, const float* coef, const float* dscale,
+                               void* const* dc, float* const* loss_out, void* stream);
 int audiossl_add_d2f(const double* src, float* dst, int n, void* stream);
 int audiossl_barlow_loss(int dtype, const float* c, int D, float coef, float dscale, void* dc, float* loss_out,
                          void* stream);

@@ -76,6 +76,24 @@ def test_gemm_epilogue(N, dtype):
     assert rel_l2(out.float().cpu(), ref.cpu()) < (1e-5 if dtype == 0 else 4e-3)
 
 
+@pytest.mark.parametrize("shape", [(72, 200, 64, 200), (256, 128, 192, 128), (64, 104, 128, 105)])
+def test_gemm_exclusive_accumulate(N, shape):
+    """atomic = 2: C += A^T B by plain load-add-store (the weight-gradient GEMMs without split-K); ldc = 105 breaks the
+    16-byte row alignment and so exercises the one-column-per-lane epilogue."""
+    M, Nn, K, ldc = shape
+    A = dev(fill.uniform((K, M), 31)).bfloat16()
+    B = dev(fill.uniform((K, Nn), 32)).bfloat16()
+    C0 = dev(fill.uniform((M, ldc), 33))
+    C = C0.clone()
+    N.call("gemm", 1, 1, 1, M, Nn, K, 0.5, A, M, B, Nn, C, ldc, None, 0, None, 0, 1.0, None, 0, 1, 2, 1, None, 0)
+    torch.cuda.synchronize()
+    ref = C0.clone()
+    ref[:, :Nn] += 0.5 * (A.float().T @ B.float())
+    assert rel_l2(C.cpu(), ref.cpu()) < 1e-5
+    with pytest.raises(RuntimeError, match="EINVAL"):                              # split-K needs the atomic form
+        N.call("gemm", 1, 1, 1, M, Nn, K, 0.5, A, M, B, Nn, C, ldc, None, 0, None, 0, 1.0, None, 0, 1, 2, 2, None, 0)
+
+
 def test_gemm_rejects_bad_arguments(N):
     a = torch.zeros(16, 16, device="cuda")
     with pytest.raises(RuntimeError, match="EINVAL"):
@@ -273,13 +291,15 @@ def test_conv3x3_implicit_gemm_fwd_dgrad_wgrad(N, shape):
     ref_dx = torch.nn.grad.conv2d_input(x_nchw.shape, wq.double(), dy_nchw, padding=1).permute(0, 3, 2, 1)
     assert rel_l2(dx.cpu(), ref_dx.cpu()) < 1e-5
     # weight gradient
-    dWp = torch.zeros(64, 576, device="cuda")
-    N.call("conv3x3_wgrad", dy, x, dWp, Nimg, Ti, Fi)
-    dW = torch.zeros(64, 64, 3, 3, device="cuda")
-    N.call("unpack_conv_dw", dWp, dW)
-    torch.cuda.synchronize()
     ref_dw = torch.nn.grad.conv2d_weight(x_nchw.double(), wq.shape, dy_nchw, padding=1)
-    assert rel_l2(dW.cpu(), ref_dw.cpu()) < 1e-5
+    ws = torch.empty(2 * 256 * 64 * 576, device="cuda")
+    for workspace in (None, ws):                                   # fp32 atomics / per-workgroup results + fold
+        dWp = torch.zeros(64, 576, device="cuda")
+        N.call("conv3x3_wgrad", dy, x, dWp, workspace, 0 if workspace is None else workspace.numel(), Nimg, Ti, Fi)
+        dW = torch.zeros(64, 64, 3, 3, device="cuda")
+        N.call("unpack_conv_dw", dWp, dW)
+        torch.cuda.synchronize()
+        assert rel_l2(dW.cpu(), ref_dw.cpu()) < 1e-5
 
 
 # ------------------------------------------------------------------------- fused BatchNorm1d(train) of the projector
