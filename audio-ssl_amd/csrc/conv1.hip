@@ -17,7 +17,7 @@
 namespace {
 
 constexpr int NTAP = 9, NMOM = 9 + 45;
-constexpr int MOM_REPL = 16;     // replicas of the moment accumulator (`mom` scratch = MOM_REPL * 54 doubles)
+constexpr int MOM_REPL = 16;  // replicas of the moment accumulator (`mom` scratch = MOM_REPL * 54 doubles)
 
 __device__ __forceinline__ int tri(int a, int b) {   // index of pair (a<=b) in the packed upper triangle
     return a * 9 - a * (a - 1) / 2 + (b - a);
@@ -29,12 +29,13 @@ __global__ __launch_bounds__(256) void conv1_moments_kernel(const float* __restr
     float acc[NMOM];
 #pragma unroll
     for (int i = 0; i < NMOM; ++i) acc[i] = 0.f;
-    const long total = (long)N * F * T;
-    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
-        const int t = (int)(idx % T);
-        const long r = idx / T;
-        const int f = (int)(r % F);
-        const float* im = img + (r / F) * (long)F * T;
+    const int total = N * F * T;                                  // < 2^31 (checked by the launcher): 32-bit index arithmetic
+    for (int idx = blockIdx.x * 256 + threadIdx.x; idx < total; idx += gridDim.x * 256) {
+        const int r = idx / T;
+        const int t = idx - r * T;
+        const int n = r / F;
+        const int f = r - n * F;
+        const float* im = img + (long)n * F * T;
         float x[NTAP];
 #pragma unroll
         for (int kh = 0; kh < 3; ++kh)
@@ -553,13 +554,14 @@ extern "C" int audiossl_conv1_stats(const float* img, int N, int F, int T, const
                                     float momentum, float eps, double* mom, float* scale, float* shift,
                                     float* save_mean, float* save_rstd, void* stream) {
     ASSL_REQUIRE(img && w && bias && gamma && beta && mom && scale && shift && save_mean && save_rstd);
-    ASSL_REQUIRE(N > 0 && F >= 2 && T >= 2);
+    ASSL_REQUIRE(N > 0 && F >= 2 && T >= 2 && (long)N * F * T < 0x7FFFFFFFL - 0x1000000L);
     hipStream_t s = static_cast<hipStream_t>(stream);
     ASSL_ZERO(mom, sizeof(double) * NMOM * MOM_REPL, s);
     const long total = (long)N * F * T;
     // every workgroup ends with 54 fp64 atomics; on ONE set of 54 addresses they serialise at the memory side (2048
     // workgroups: a 116 us launch) - MOM_REPL replicas of the accumulator, folded by the finalize kernel
-    const int grid = (int)min((long)1024, (total + 255) / 256);
+    static const int mom_grid = getenv("AUDIOSSL_MOM_GRID") ? atoi(getenv("AUDIOSSL_MOM_GRID")) : 1024;
+    const int grid = (int)min((long)mom_grid, (total + 255) / 256);
     hipLaunchKernelGGL(conv1_moments_kernel, dim3(grid), dim3(256), 0, s, img, mom, N, F, T);
     hipLaunchKernelGGL(conv1_finalize_kernel, dim3(1), dim3(64), 0, s, mom, w, bias, gamma, beta, running_mean,
                        running_var, momentum, eps, (double)total, scale, shift, save_mean, save_rstd);

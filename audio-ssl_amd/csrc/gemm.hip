@@ -42,6 +42,7 @@ struct GemmArgs {
     long ldr;
     unsigned a_bytes, b_bytes; // extents of A and B for the buffer descriptors (hardware bounds check)
     int vec_epi;              // every epilogue operand allows 8-column vectors (set by epi_vectorisable)
+    int xcd_remap;            // grid is a multiple of 8 workgroups: contiguous tile runs per XCD (set by the launchers)
 };
 
 template <typename T> struct Mma;
@@ -65,7 +66,7 @@ template <> struct Mma<float> {
 // The fully unrolled per-element version this replaces was ~35 KB of straight-line code executed once per workgroup - the
 // instruction fetch alone cost ~14 us per launch (a one-tile, one-k-step GEMM took 16.7 us; tools/gemm_floor.py).
 constexpr int EPI_PITCH = 65;                                    // floats; odd pitch: conflict-free row reads
-constexpr size_t EPI_LDS = sizeof(float) * 4 * 64 * EPI_PITCH;   // 66,560 B, fits inside every variant's staging LDS
+constexpr size_t EPI_LDS = sizeof(float) * 4 * 64 * EPI_PITCH;   // 66,560 B for four waves (8-wave workgroups: twice that)
 
 // MI = 32-row MFMA blocks per wave in M (wave tile = 32*MI x 64)
 template <typename T, int MI>
@@ -196,13 +197,13 @@ __device__ __forceinline__ void epilogue(const GemmArgs& g, f32x16 (&acc)[MI][2]
 }
 
 // One operand's staging: 128 rows x 32 k per step, two Vec8 per thread.
-template <typename T, bool TRANS, int BK_, int ROWS = 128>
+template <typename T, bool TRANS, int BK_, int ROWS = 128, int NTH = 256>
 struct Stage {
     static constexpr int BK = BK_;
     static constexpr int NT_PITCH = BK + 8;          // elements; [row][k] image, conflict-free 16-byte row reads
     static constexpr int TR_PITCH = ROWS + 32;       // elements; [k][row] image: 4 consecutive k-rows fall on distinct 32-byte bank groups
     static constexpr int VR = ROWS / 8;              // vectors per k-row of the [k][row] image
-    static constexpr int NV = ROWS * BK / 8 / 256;   // 8-element vectors per thread and step
+    static constexpr int NV = ROWS * BK / 8 / NTH;   // 8-element vectors per thread and step
     static constexpr int VPR = BK / 8;               // vectors per row of the [row][k] image
     Vec8<T> r[NV];
     // Branch-free staging loads: a raw buffer load per 16 bytes, out-of-range vectors get an offset past the
@@ -223,7 +224,7 @@ struct Stage {
         const int t = threadIdx.x;
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
-            const int v = t + i * 256;
+            const int v = t + i * NTH;
             int row, k;
             long idx;
             if (!TRANS) { row = row0 + v / VPR; k = k0 + (v % VPR) * 8; idx = (long)row * ld + k; }
@@ -238,7 +239,7 @@ struct Stage {
         const int t = threadIdx.x;
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
-            const int v = t + i * 256;
+            const int v = t + i * NTH;
             if (!TRANS) r[i].store(lds + (v / VPR) * NT_PITCH + (v % VPR) * 8);
             else        r[i].store(lds + (v / VR) * TR_PITCH + (v % VR) * 8);
         }
@@ -271,16 +272,24 @@ struct Stage {
     static constexpr int LDS_ELEMS = TRANS ? BK * TR_PITCH : ROWS * NT_PITCH;
 };
 
-template <typename T, bool TA, bool TB, int BK, int MI>
+// NW = 4 waves (2 x 2): 128 x 128 tile (MI = 2) or 64 x 128 (MI = 1: twice the workgroups for grids that would leave CUs idle).
+// NW = 8 waves (4 x 2): 256 x 128 tile - twice the MFMA work per byte staged (the 128 x 128 tile needs as many L1->LDS cycles
+// per k-step as MFMA cycles) and two waves per SIMD, so one wave's MFMAs cover the other's LDS reads and staging stores.
+template <typename T, bool TA, bool TB, int BK, int MI, int NW = 4>
 __device__ __forceinline__ void gemm_body(const GemmArgs& g, char* smem) {
-    constexpr int BMv = 64 * MI;                                 // 128 x 128 tile (MI = 2) or 64 x 128 (MI = 1: twice the
-    using SA = Stage<T, TA, BK, BMv>;                            // workgroups for grids that would leave CUs idle)
-    using SB = Stage<T, TB, BK, BN>;
+    constexpr int BMv = 16 * MI * NW;
+    using SA = Stage<T, TA, BK, BMv, 64 * NW>;
+    using SB = Stage<T, TB, BK, BN, 64 * NW>;
     T* const ldsA0 = reinterpret_cast<T*>(smem);                 // two A buffers, then two B buffers
     T* const ldsB0 = ldsA0 + 2 * SA::LDS_ELEMS;
 
     const int tiles_n = (g.N + BN - 1) / BN;
-    const int bm = (blockIdx.x / tiles_n) * BMv, bn = (blockIdx.x % tiles_n) * BN;
+    // Workgroups are dealt to the 8 XCDs round-robin (id mod 8), each with its own 4 MB L2.  Give every XCD a CONTIGUOUS run
+    // of tiles (whole tile rows: one A row panel is then fetched into one L2 instead of all eight) - operand re-reads
+    // that miss L2 are served by the Infinity Cache at about half the L2 rate, which bounded the 6144-row GEMMs.
+    int wg = blockIdx.x;
+    if (g.xcd_remap) wg = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+    const int bm = (wg / tiles_n) * BMv, bn = (wg % tiles_n) * BN;
     // split-K range, in whole BK steps
     const int ksteps = (g.K + BK - 1) / BK;
     const int per = (ksteps + g.ksplit - 1) / g.ksplit;
@@ -339,10 +348,10 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g, char* smem) {
     epilogue<T, MI>(g, acc, smem, bm + wm, bn + wn, lane, wave);
 }
 
-template <typename T, bool TA, bool TB, int BK, int MI>
-__global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
+template <typename T, bool TA, bool TB, int BK, int MI, int NW = 4>
+__global__ __launch_bounds__(64 * NW) void gemm_kernel(GemmArgs g) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    gemm_body<T, TA, TB, BK, MI>(g, smem);
+    gemm_body<T, TA, TB, BK, MI, NW>(g, smem);
 }
 
 // Several independent problems of one kind in ONE launch (blockIdx.y = problem): the three Barlow heads of delores_m run
@@ -351,39 +360,49 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
 constexpr int MAX_MULTI = 4;
 struct GemmMulti { GemmArgs p[MAX_MULTI]; };
 
-template <typename T, bool TA, bool TB, int BK, int MI>
-__global__ __launch_bounds__(256) void gemm_multi_kernel(GemmMulti gm) {
+template <typename T, bool TA, bool TB, int BK, int MI, int NW = 4>
+__global__ __launch_bounds__(64 * NW) void gemm_multi_kernel(GemmMulti gm) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const GemmArgs& g = gm.p[blockIdx.y];
-    const int tiles = ((g.M + 64 * MI - 1) / (64 * MI)) * ((g.N + BN - 1) / BN);
+    const int tiles = ((g.M + 16 * MI * NW - 1) / (16 * MI * NW)) * ((g.N + BN - 1) / BN);
     if ((int)blockIdx.x >= tiles) return;
-    gemm_body<T, TA, TB, BK, MI>(g, smem);
+    gemm_body<T, TA, TB, BK, MI, NW>(g, smem);
 }
 
-template <typename T, bool TA, bool TB, int BK, int MI>
+template <typename T, bool TA, bool TB, int BK, int MI, int NW>
+constexpr size_t gemm_lds() {
+    constexpr size_t stage = sizeof(T) * 2 * (Stage<T, TA, BK, 16 * MI * NW, 64 * NW>::LDS_ELEMS + Stage<T, TB, BK, BN, 64 * NW>::LDS_ELEMS);
+    constexpr size_t epi = EPI_LDS * (NW / 4);
+    return stage > epi ? stage : epi;
+}
+
+template <typename T, bool TA, bool TB, int BK, int MI, int NW = 4>
 int launch_multi(const GemmMulti& gm, int count, int max_tiles, int ksplit, hipStream_t s) {
-    const size_t lds = max(sizeof(T) * 2 * (Stage<T, TA, BK, 64 * MI>::LDS_ELEMS + Stage<T, TB, BK, BN>::LDS_ELEMS), EPI_LDS);
+    const size_t lds = gemm_lds<T, TA, TB, BK, MI, NW>();
     static bool attr_set = false;
     if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_multi_kernel<T, TA, TB, BK, MI>),
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_multi_kernel<T, TA, TB, BK, MI, NW>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return ASSL_ELAUNCH;
         attr_set = true;
     }
-    hipLaunchKernelGGL((gemm_multi_kernel<T, TA, TB, BK, MI>), dim3(max_tiles, count, ksplit), dim3(256), lds, s, gm);
+    hipLaunchKernelGGL((gemm_multi_kernel<T, TA, TB, BK, MI, NW>), dim3(max_tiles, count, ksplit), dim3(64 * NW), lds, s, gm);
     ASSL_LAUNCH_CHECK();
 }
 
-template <typename T, bool TA, bool TB, int BK, int MI>
+template <typename T, bool TA, bool TB, int BK, int MI, int NW = 4>
 int launch(const GemmArgs& g, hipStream_t s) {
-    const size_t lds = max(sizeof(T) * 2 * (Stage<T, TA, BK, 64 * MI>::LDS_ELEMS + Stage<T, TB, BK, BN>::LDS_ELEMS), EPI_LDS);
+    const size_t lds = gemm_lds<T, TA, TB, BK, MI, NW>();
     static bool attr_set = false;
     if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<T, TA, TB, BK, MI>),
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<T, TA, TB, BK, MI, NW>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return ASSL_ELAUNCH;
         attr_set = true;
     }
-    const int tiles = ceil_div(g.M, 64 * MI) * ceil_div(g.N, BN);
-    hipLaunchKernelGGL((gemm_kernel<T, TA, TB, BK, MI>), dim3(tiles, 1, g.ksplit), dim3(256), lds, s, g);
+    const int tiles = ceil_div(g.M, 16 * MI * NW) * ceil_div(g.N, BN);
+    static const bool remap = getenv("AUDIOSSL_GEMM_XCD") ? atoi(getenv("AUDIOSSL_GEMM_XCD")) != 0 : true;
+    GemmArgs ga = g;
+    ga.xcd_remap = remap && tiles % 8 == 0 && tiles >= 64;
+    hipLaunchKernelGGL((gemm_kernel<T, TA, TB, BK, MI, NW>), dim3(tiles, 1, g.ksplit), dim3(64 * NW), lds, s, ga);
     ASSL_LAUNCH_CHECK();
 }
 
@@ -573,12 +592,12 @@ int dispatch_ring(const GemmArgs& g, int ta, int tb, hipStream_t s) {
     return launch_ring<true, false, MI, NST>(g, s);
 }
 
-template <typename T, int BK, int MI>
+template <typename T, int BK, int MI, int NW = 4>
 int dispatch(const GemmArgs& g, int ta, int tb, hipStream_t s) {
-    if (!ta && !tb) return launch<T, false, false, BK, MI>(g, s);
-    if (!ta && tb) return launch<T, false, true, BK, MI>(g, s);
-    if (ta && tb) return launch<T, true, true, BK, MI>(g, s);
-    return launch<T, true, false, BK, MI>(g, s);
+    if (!ta && !tb) return launch<T, false, false, BK, MI, NW>(g, s);
+    if (!ta && tb) return launch<T, false, true, BK, MI, NW>(g, s);
+    if (ta && tb) return launch<T, true, true, BK, MI, NW>(g, s);
+    return launch<T, true, false, BK, MI, NW>(g, s);
 }
 
 // the 8-columns-per-lane epilogue needs whole, aligned vectors of every operand it touches
@@ -623,16 +642,18 @@ extern "C" int audiossl_gemm_multi(int count, int trans_a, int trans_b, int M, c
     const long blocks = (long)ceil_div(M, BM) * ceil_div(N, BN) * ksplit * count;
     const bool small = blocks <= 128 && M > 64;
     const int max_tiles = ceil_div(M, small ? 64 : BM) * ceil_div(N, BN);
-#define MULTI(BK_, MI_)                                                                                   \
+#define MULTI(BK_, MI_, NW_, TILES)                                                                       \
     do {                                                                                                  \
-        if (!trans_a && !trans_b) return launch_multi<bf16, false, false, BK_, MI_>(gm, count, max_tiles, ksplit, s); \
-        if (!trans_a && trans_b) return launch_multi<bf16, false, true, BK_, MI_>(gm, count, max_tiles, ksplit, s);   \
-        if (trans_a && trans_b) return launch_multi<bf16, true, true, BK_, MI_>(gm, count, max_tiles, ksplit, s);     \
-        return launch_multi<bf16, true, false, BK_, MI_>(gm, count, max_tiles, ksplit, s);                            \
+        if (!trans_a && !trans_b) return launch_multi<bf16, false, false, BK_, MI_, NW_>(gm, count, TILES, ksplit, s); \
+        if (!trans_a && trans_b) return launch_multi<bf16, false, true, BK_, MI_, NW_>(gm, count, TILES, ksplit, s);   \
+        if (trans_a && trans_b) return launch_multi<bf16, true, true, BK_, MI_, NW_>(gm, count, TILES, ksplit, s);     \
+        return launch_multi<bf16, true, false, BK_, MI_, NW_>(gm, count, TILES, ksplit, s);                            \
     } while (0)
-    if (small) MULTI(64, 1);
-    if (blocks <= 256 && kmin >= 512) MULTI(128, 2);
-    MULTI(64, 2);
+    static const int w8 = getenv("AUDIOSSL_GEMM_W8") ? atoi(getenv("AUDIOSSL_GEMM_W8")) : 0;
+    if (w8 && M >= 256) MULTI(64, 2, 8, ceil_div(M, 256) * ceil_div(N, BN));
+    if (small) MULTI(64, 1, 4, max_tiles);
+    if (blocks <= 256 && kmin >= 512) MULTI(128, 2, 4, max_tiles);
+    MULTI(64, 2, 4, max_tiles);
 #undef MULTI
 }
 
@@ -664,6 +685,8 @@ extern "C" int audiossl_gemm(int dtype, int trans_a, int trans_b, int M, int N, 
     // AUDIOSSL_GEMM_RING = 10 * MI + NST forces one ring variant (tools/gemm_shapes.py sweeps them); 0 disables the ring
     static const int ring = getenv("AUDIOSSL_GEMM_RING") ? atoi(getenv("AUDIOSSL_GEMM_RING")) : -1;
     const bool ring_ok = K % GBK == 0 && M >= 8 && N >= 8;
+    static const int w8 = getenv("AUDIOSSL_GEMM_W8") ? atoi(getenv("AUDIOSSL_GEMM_W8")) : 0;
+    if (w8 && M >= 256) return dispatch<bf16, 64, 2, 8>(g, trans_a, trans_b, s);
     if (ring_ok && ring > 0) {
         switch (ring) {
             case 12: return dispatch_ring<1, 2>(g, trans_a, trans_b, s);

@@ -18,3 +18,11 @@ for Nimg, Ti, Fi in ((512, 50, 32), (512, 25, 16)):
     t = timeit(lambda: N.call("conv3x3_fwd", dy, Wd, None, dx, 1, None, None, Nimg, Ti, Fi)); print(f"{(Nimg,Ti,Fi)} dgrad f32 {t:7.1f} us {gf/t:6.1f} TF/s")
     t = timeit(lambda: N.call("conv3x3_wgrad", dy, x, dWp, ws, ws.numel(), Nimg, Ti, Fi)); print(f"{(Nimg,Ti,Fi)} wgrad 2-stage {t:7.1f} us {gf/t:6.1f} TF/s")
     t = timeit(lambda: N.call("conv3x3_wgrad", dy, x, dWp, None, 0, Nimg, Ti, Fi)); print(f"{(Nimg,Ti,Fi)} wgrad atomics {t:7.1f} us {gf/t:6.1f} TF/s")
+# stem: batch statistics from the 54 image moments, forward, backward
+Nimg, F, T = 512, 64, 101
+img = torch.randn(Nimg, F, T, device="cuda"); w = torch.randn(64, 1, 3, 3, device="cuda") * 0.3; b = torch.randn(64, device="cuda")
+gm = torch.rand(64, device="cuda") + 0.5; bt = torch.randn(64, device="cuda"); rm = torch.zeros(64, device="cuda"); rv = torch.ones(64, device="cuda")
+mom = torch.zeros(16 * 54, dtype=torch.float64, device="cuda"); st = torch.empty(4, 64, device="cuda")
+t = timeit(lambda: N.call("conv1_stats", img, Nimg, F, T, w, b, gm, bt, rm, rv, 0.1, 1e-5, mom, st[0], st[1], st[2], st[3])); print(f"conv1_stats {t:7.1f} us")
+P = torch.empty(Nimg, T // 2, F // 2, 64, device="cuda", dtype=torch.bfloat16)
+t = timeit(lambda: N.call("conv1_fwd", 1, img, Nimg, F, T, w, b, st[0], st[1], P)); print(f"conv1_fwd (MFMA) {t:7.1f} us")
