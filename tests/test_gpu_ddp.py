@@ -101,7 +101,7 @@ def test_two_rank_graph_phases_match_eager(which):
     g0, g1 = _run(which, graph=True)
     h0, _ = _run(which, graph=True)                           # a second, independent run: the graph step must be repeatable
     np.testing.assert_allclose(h0["losses"], g0["losses"], rtol=2e-3)
-    want = ["encoder_bwd", "head1", "head2", "head3", "key", "moco", "query"] if which == "delores_m" else ["encoder_bwd", "forward"]
+    want = ["encoder_bwd", "heads", "key", "moco", "query"] if which == "delores_m" else ["encoder_bwd", "forward"]   # grouped heads: one phase
     assert g0["graphs"] == (want, None) and g1["graphs"] == (want, None)
     for n in g0["w"]:
         np.testing.assert_array_equal(g0["w"][n], g1["w"][n], err_msg=n)
