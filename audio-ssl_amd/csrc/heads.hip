@@ -489,11 +489,23 @@ template <typename T_>
 __global__ __launch_bounds__(256) void moco_ce_bwd_kernel(const float* __restrict__ lpos, const float* __restrict__ lneg,
                                                           const float* __restrict__ lse, int K, float gscale,
                                                           T_* __restrict__ P, float* __restrict__ dlpos) {
+    // 8 consecutive columns per thread (two 16-byte loads, one 16-byte bf16 store) when the row length allows; the
+    // one-element-per-thread form wrote 2 bytes per lane and ran at a third of the HBM rate
     const long b = blockIdx.y;
     const float l = lse[b];
-    const long k = (long)blockIdx.x * 256 + threadIdx.x;
-    if (k < K) P[b * K + k] = from_f32<T_>(expf(lneg[b * K + k] - l) * gscale);
-    if (k == 0) dlpos[b] = (expf(lpos[b] - l) - 1.f) * gscale;
+    const long k0 = ((long)blockIdx.x * 256 + threadIdx.x) * 8;
+    if ((K & 7) == 0) {
+        if (k0 < K) {
+            const Vec8<float> v = Vec8<float>::load(lneg + b * K + k0);
+            Vec8<T_> o;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) o.set(i, expf(v.get(i) - l) * gscale);
+            o.store(P + b * K + k0);
+        }
+    } else {
+        for (long k = k0; k < k0 + 8 && k < K; ++k) P[b * K + k] = from_f32<T_>(expf(lneg[b * K + k] - l) * gscale);
+    }
+    if (k0 == 0) dlpos[b] = (expf(lpos[b] - l) - 1.f) * gscale;
 }
 
 // dq = (g - qn <qn, g>) * inv_norm with g = dqn + dlpos * kn
@@ -566,12 +578,30 @@ __global__ __launch_bounds__(256) void sgd_kernel(float* __restrict__ p, const f
 // pk = pk*m + pq*(1-m)
 __global__ __launch_bounds__(256) void ema_kernel(float* __restrict__ pk, const float* __restrict__ pq, long n, float m) {
     const float om = 1.f - m;
-    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) pk[i] = pk[i] * m + pq[i] * om;
+    const bool vec = ((reinterpret_cast<size_t>(pk) | reinterpret_cast<size_t>(pq)) & 15) == 0;
+    const long n4 = vec ? n / 4 : 0;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+        f32x4 a = *reinterpret_cast<const f32x4*>(pk + i * 4);
+        const f32x4 b = *reinterpret_cast<const f32x4*>(pq + i * 4);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) a[k] = a[k] * m + b[k] * om;
+        *reinterpret_cast<f32x4*>(pk + i * 4) = a;
+    }
+    for (long i = n4 * 4 + (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) pk[i] = pk[i] * m + pq[i] * om;
 }
 
+// 8 elements per thread and trip (16-byte stores of bf16); `vec` = both pointers 16-byte aligned
 template <typename T_>
-__global__ __launch_bounds__(256) void cast_kernel(const float* __restrict__ src, T_* __restrict__ dst, long n) {
-    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) dst[i] = from_f32<T_>(src[i]);
+__global__ __launch_bounds__(256) void cast_kernel(const float* __restrict__ src, T_* __restrict__ dst, long n, int vec) {
+    const long n8 = vec ? n / 8 : 0;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n8; i += (long)gridDim.x * 256) {
+        const Vec8<float> v = Vec8<float>::load(src + i * 8);
+        Vec8<T_> o;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) o.set(k, v.get(k));
+        o.store(dst + i * 8);
+    }
+    for (long i = n8 * 8 + (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) dst[i] = from_f32<T_>(src[i]);
 }
 
 template <typename T_>
@@ -584,13 +614,25 @@ __global__ __launch_bounds__(256) void dropout_mask_kernel(uint8_t* __restrict__
                                                            const long long* __restrict__ counter) {
     if (counter) seed = (seed + (unsigned long long)counter[0]) & 0xFFFFFFFFFFFFull;
     const unsigned int thr = (unsigned int)fminf(p * 4294967296.f, 4294967295.f);
-    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    auto bit = [&](long i) -> unsigned int {
         unsigned long long z = seed + 0x9E3779B97F4A7C15ull * (unsigned long long)(i + 1);
         z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
         z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
         z = z ^ (z >> 31);
-        keep[i] = ((unsigned int)(z >> 32) >= thr) ? 1 : 0;
+        return ((unsigned int)(z >> 32) >= thr) ? 1u : 0u;
+    };
+    // 16 mask bytes per thread and trip, one 16-byte store (one byte per lane: 64-byte wave stores, 5x slower)
+    const long n16 = ((reinterpret_cast<size_t>(keep) & 15) == 0) ? n / 16 : 0;
+    for (long v = (long)blockIdx.x * 256 + threadIdx.x; v < n16; v += (long)gridDim.x * 256) {
+        unsigned int w[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const long i = v * 16 + q * 4;
+            w[q] = bit(i) | (bit(i + 1) << 8) | (bit(i + 2) << 16) | (bit(i + 3) << 24);
+        }
+        *reinterpret_cast<uint4*>(keep + v * 16) = make_uint4(w[0], w[1], w[2], w[3]);
     }
+    for (long i = n16 * 16 + (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) keep[i] = (uint8_t)bit(i);
 }
 
 }  // namespace
@@ -805,7 +847,7 @@ extern "C" int audiossl_moco_ce_fwd(const float* lpos, const float* lneg, int B,
 extern "C" int audiossl_moco_ce_bwd(int dtype, const float* lpos, const float* lneg, const float* lse, int B, int K, float gscale,
                                     void* P, float* dlpos, void* stream) {
     ASSL_REQUIRE(lpos && lneg && lse && P && dlpos && B > 0 && K > 0 && (dtype == 0 || dtype == 1));
-    dim3 grid(ceil_div(K, 256), B);
+    dim3 grid(ceil_div(K, 256 * 8), B);
     if (dtype == 0) hipLaunchKernelGGL(moco_ce_bwd_kernel<float>, grid, dim3(256), 0, S_(stream), lpos, lneg, lse, K, gscale, (float*)P, dlpos);
     else            hipLaunchKernelGGL(moco_ce_bwd_kernel<bf16>, grid, dim3(256), 0, S_(stream), lpos, lneg, lse, K, gscale, (bf16*)P, dlpos);
     ASSL_LAUNCH_CHECK();
@@ -841,16 +883,17 @@ extern "C" int audiossl_sgd_momentum(float* p, const float* g, float* buf, long 
 
 extern "C" int audiossl_ema_update(float* pk, const float* pq, long n, float m, void* stream) {
     ASSL_REQUIRE(pk && pq && n > 0);
-    const int grid = (int)min((long)2048, (n + 255) / 256);
+    const int grid = (int)min((long)2048, (n / 4 + 255) / 256 + 1);
     hipLaunchKernelGGL(ema_kernel, dim3(grid), dim3(256), 0, S_(stream), pk, pq, n, m);
     ASSL_LAUNCH_CHECK();
 }
 
 extern "C" int audiossl_cast(int dtype, const float* src, void* dst, long n, void* stream) {
     ASSL_REQUIRE(src && dst && n > 0 && (dtype == 0 || dtype == 1));
-    const int grid = (int)min((long)4096, (n + 255) / 256);
-    if (dtype == 0) hipLaunchKernelGGL(cast_kernel<float>, dim3(grid), dim3(256), 0, S_(stream), src, (float*)dst, n);
-    else            hipLaunchKernelGGL(cast_kernel<bf16>, dim3(grid), dim3(256), 0, S_(stream), src, (bf16*)dst, n);
+    const int grid = (int)min((long)4096, (n / 8 + 255) / 256 + 1);
+    const int vec = ASSL_ALIGNED16(src) && ASSL_ALIGNED16(dst);
+    if (dtype == 0) hipLaunchKernelGGL(cast_kernel<float>, dim3(grid), dim3(256), 0, S_(stream), src, (float*)dst, n, vec);
+    else            hipLaunchKernelGGL(cast_kernel<bf16>, dim3(grid), dim3(256), 0, S_(stream), src, (bf16*)dst, n, vec);
     ASSL_LAUNCH_CHECK();
 }
 
@@ -864,7 +907,7 @@ extern "C" int audiossl_cast_back(int dtype, const void* src, float* dst, long n
 
 extern "C" int audiossl_dropout_mask(uint8_t* keep, long n, unsigned long long seed, float p, const long long* counter, void* stream) {
     ASSL_REQUIRE(keep && n > 0 && p >= 0.f && p < 1.f);
-    const int grid = (int)min((long)4096, (n + 255) / 256);
+    const int grid = (int)min((long)4096, (n / 16 + 255) / 256 + 1);
     hipLaunchKernelGGL(dropout_mask_kernel, dim3(grid), dim3(256), 0, S_(stream), keep, n, seed, p, counter);
     ASSL_LAUNCH_CHECK();
 }
