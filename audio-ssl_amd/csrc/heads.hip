@@ -547,9 +547,11 @@ __global__ void advance_ptr_kernel(long long* ptr_dev, int B, int K) { ptr_dev[0
 
 // --------------------------------------------------------------------------------------------- flat-buffer plumbing
 // torch.optim.SGD: g += wd*p; buf = first ? g : mom*buf + g; p -= lr*buf
-__global__ __launch_bounds__(256) void sgd_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ buf,
+// Optional tail work on the same pass (saves two full sweeps of the buffers at the start of the next step): `shadow` =
+// bf16 copy of the updated parameters (the MFMA operands of the next step), `zero_grad` = clear g after it has been read.
+__global__ __launch_bounds__(256) void sgd_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ buf,
                                                   long n, float lr, float mom, float wd, int first, float gscale_host,
-                                                  const float* __restrict__ gscale_dev) {
+                                                  const float* __restrict__ gscale_dev, bf16* __restrict__ shadow, int zero_grad) {
     const float gscale = gscale_dev ? gscale_host * gscale_dev[0] : gscale_host;
     for (long i = ((long)blockIdx.x * 256 + threadIdx.x) * 4; i < n; i += (long)gridDim.x * 1024) {
         if (i + 4 <= n) {
@@ -564,12 +566,16 @@ __global__ __launch_bounds__(256) void sgd_kernel(float* __restrict__ p, const f
             }
             *reinterpret_cast<f32x4*>(buf + i) = bv;
             *reinterpret_cast<f32x4*>(p + i) = pv;
+            if (shadow) *reinterpret_cast<bf16x4*>(shadow + i) = bf16x4{(bf16)pv[0], (bf16)pv[1], (bf16)pv[2], (bf16)pv[3]};
+            if (zero_grad) *reinterpret_cast<f32x4*>(g + i) = f32x4{0.f, 0.f, 0.f, 0.f};
         } else {
             for (long j = i; j < n; ++j) {
                 const float gg = g[j] * gscale + wd * p[j];
                 const float b = first ? gg : mom * buf[j] + gg;
                 buf[j] = b;
                 p[j] -= lr * b;
+                if (shadow) shadow[j] = (bf16)p[j];
+                if (zero_grad) g[j] = 0.f;
             }
         }
     }
@@ -872,12 +878,15 @@ extern "C" int audiossl_enqueue(int dtype, const float* keys, int B, int D, int 
     ASSL_LAUNCH_CHECK();
 }
 
-extern "C" int audiossl_sgd_momentum(float* p, const float* g, float* buf, long n, float lr, float momentum, float weight_decay,
-                                     int first, float grad_scale, const float* grad_scale_dev, void* stream) {
+extern "C" int audiossl_sgd_momentum(float* p, float* g, float* buf, long n, float lr, float momentum, float weight_decay,
+                                     int first, float grad_scale, const float* grad_scale_dev, void* shadow_bf16, int zero_grad,
+                                     void* stream) {
     ASSL_REQUIRE(p && g && buf && n > 0);
     if (!ASSL_ALIGNED16(p) || !ASSL_ALIGNED16(g) || !ASSL_ALIGNED16(buf)) return ASSL_EALIGN;
+    if (shadow_bf16 && (reinterpret_cast<size_t>(shadow_bf16) & 7)) return ASSL_EALIGN;
     const int grid = (int)min((long)2048, (n + 1023) / 1024);
-    hipLaunchKernelGGL(sgd_kernel, dim3(grid), dim3(256), 0, S_(stream), p, g, buf, n, lr, momentum, weight_decay, first, grad_scale, grad_scale_dev);
+    hipLaunchKernelGGL(sgd_kernel, dim3(grid), dim3(256), 0, S_(stream), p, g, buf, n, lr, momentum, weight_decay, first, grad_scale,
+                       grad_scale_dev, static_cast<bf16*>(shadow_bf16), zero_grad);
     ASSL_LAUNCH_CHECK();
 }
 

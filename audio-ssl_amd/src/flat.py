@@ -38,6 +38,9 @@ class FlatGroup:
         self.grad = torch.zeros(off, dtype=torch.float32, device=device)
         self.momentum = None
         self._shadow = None
+        self._fresh_shadow = False             # the optimiser's fused tail (HipSGD.fused_refresh) left the bf16 shadow current
+        self._fresh_grad = False               # ... and the gradient zero; each flag buys ONE skipped sweep
+        self._early_fused = False
         self._views = {}                       # cached view dictionaries (the step asks for the same ones every time)
         for p, o in zip(self.params, self.offsets):
             v = self.data[o:o + p.numel()].view(p.shape)
@@ -58,6 +61,10 @@ class FlatGroup:
             return
         if self._shadow is None or self._shadow.device != self.data.device:
             self._shadow = torch.empty(self.numel, dtype=torch.bfloat16, device=self.data.device)
+            self._fresh_shadow = False
+        if self._fresh_shadow:                 # written by the SGD pass of the previous step
+            self._fresh_shadow = False
+            return
         N.call("cast", dtype, self.data, self._shadow, self.numel)
 
     def shadow_dict(self, prefix=""):
@@ -97,7 +104,13 @@ class FlatGroup:
         return {n[len(prefix):]: p.data for n, p in zip(self.names, self.params) if n.startswith(prefix)}
 
     def zero_grad(self):
+        if self._fresh_grad:                   # cleared by the SGD pass of the previous step
+            self._fresh_grad = False
+            return
         self.grad.zero_()
+
+    def mark_fresh(self):
+        self._fresh_shadow = self._fresh_grad = True
 
     def attach_grads(self, scale=None):
         """Expose the flat gradient through p.grad (alias when p.grad is None, else accumulate)."""

@@ -13,6 +13,14 @@ class HipSGD(torch.optim.Optimizer):
         self.grad_scale_tensor = None      # optional device scalar multiplied in (loss.backward(g))
         self.steps = 0
         self._early = {}                   # id(flat group) -> first element already stepped by step_tail() this step
+        # fused_refresh (set by GraphedStep): the SGD pass also writes the bf16 shadow of the updated weights and clears the
+        # gradient, and tells the flat group so - its next refresh_shadow() / zero_grad() are then no-ops.  Off by default:
+        # with it, gradients read back as zero after step().
+        self.fused_refresh = False
+
+    def _tail(self, fg, lo, hi):
+        fused = self.fused_refresh and fg._shadow is not None
+        return (fg._shadow[lo:hi] if fused else None), int(fused)
 
     @torch.no_grad()
     def step(self, closure=None):
@@ -25,9 +33,14 @@ class HipSGD(torch.optim.Optimizer):
             done = self._early.pop(id(fg), None)
             if done is not None:                      # [done, numel) was already stepped by step_tail() during this step
                 hi = done
+            shadow, zero = self._tail(fg, lo, hi)
             if hi > lo:
                 N.call("sgd_momentum", fg.data[lo:hi], fg.grad[lo:hi], fg.momentum[lo:hi], hi - lo, float(g0["lr"]),
-                       float(g0["momentum"]), float(g0["weight_decay"]), int(first), float(self.grad_scale), self.grad_scale_tensor)
+                       float(g0["momentum"]), float(g0["weight_decay"]), int(first), float(self.grad_scale), self.grad_scale_tensor,
+                       shadow, zero)
+            if zero and (done is None or fg._early_fused):
+                fg.mark_fresh()                       # the whole buffer has been stepped with the fused tail
+            fg._early_fused = False
         self.steps += 1
 
     @torch.no_grad()
@@ -38,8 +51,10 @@ class HipSGD(torch.optim.Optimizer):
         if fg.momentum is None or start >= fg.numel or start % 64:
             return False
         g0 = self.param_groups[0]
+        shadow, zero = self._tail(fg, start, fg.numel)
         N.call("sgd_momentum", fg.data[start:], fg.grad[start:], fg.momentum[start:], fg.numel - start, float(g0["lr"]),
-               float(g0["momentum"]), float(g0["weight_decay"]), 0, float(self.grad_scale), self.grad_scale_tensor)
+               float(g0["momentum"]), float(g0["weight_decay"]), 0, float(self.grad_scale), self.grad_scale_tensor, shadow, zero)
+        fg._early_fused = bool(zero)
         return True
 
     def mark_early(self, fg, start):

@@ -207,8 +207,11 @@ int audiossl_ema_update(float* pk, const float* pq, long n, float m, void* strea
 int audiossl_set_prezeroed(int on);
 
 /* ---- K17 optimiser + plumbing: delores_s/upstream_expert.py:236-243 (torch.optim.SGD) ---------------------- */
-int audiossl_sgd_momentum(float* p, const float* g, float* buf, long n, float lr, float momentum, float weight_decay,
-                          int first, float grad_scale, const float* grad_scale_dev, void* stream);
+/* sgd_momentum: optional tail work of the same pass - shadow_bf16 (nullable): bf16 copy of the updated parameters (what
+ * `cast` would produce at the start of the next step); zero_grad: clear g after reading it. */
+int audiossl_sgd_momentum(float* p, float* g, float* buf, long n, float lr, float momentum, float weight_decay,
+                          int first, float grad_scale, const float* grad_scale_dev, void* shadow_bf16, int zero_grad,
+                          void* stream);
 int audiossl_cast(int dtype, const float* src, void* dst, long n, void* stream);
 int audiossl_cast_back(int dtype, const void* src, float* dst, long n, void* stream);
 /* keep[i] = splitmix64(seed', i) >= p; seed' = (seed + *counter) mod 2^48 when `counter` (device int64) is given, so that
