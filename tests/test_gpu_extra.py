@@ -185,3 +185,48 @@ def test_decar_v2_epoch_end_to_end():
     assert not torch.equal(m.fc[3].weight.detach(), enc0)
     assert not torch.equal(st.local_memory_embeddings[0, :2 * B], mem0[0, :2 * B])
     assert torch.equal(st.local_memory_embeddings[0, 2 * B:], mem0[0, 2 * B:])
+
+
+# ------------------------------------------------------------------------------- 16-byte-store forms of the small kernels
+def test_vectorised_elementwise_kernels_match_scalar_definitions():
+    """dropout_mask / cast / ema_update / moco_ce_bwd write 16 bytes per lane where alignment allows; lengths that are not a
+    multiple of the vector width and misaligned bases exercise the tails and the scalar fall-backs."""
+    from src import _native as N
+    # dropout mask = splitmix64 finaliser of (seed + 0x9E37..15 * (i + 1)), keep iff high word >= p * 2^32
+    def ref_mask(n, seed, p):
+        M = (1 << 64) - 1
+        i = np.arange(1, n + 1, dtype=np.uint64)
+        with np.errstate(over="ignore"):
+            z = (np.uint64(seed) + np.uint64(0x9E3779B97F4A7C15) * i) & np.uint64(M)
+            z = ((z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)) & np.uint64(M)
+            z = ((z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)) & np.uint64(M)
+            z = z ^ (z >> np.uint64(31))
+        thr = np.uint64(min(int(np.float32(p) * np.float32(4294967296.0)), 4294967295))
+        return ((z >> np.uint64(32)) >= thr).astype(np.uint8)
+    for n, off in ((4099, 0), (4099, 1), (37, 0)):
+        buf = torch.zeros(n + off + 16, dtype=torch.uint8, device="cuda")
+        N.call("dropout_mask", buf[off:off + n], n, 12345, 0.3, None)
+        torch.cuda.synchronize()
+        np.testing.assert_array_equal(buf[off:off + n].cpu().numpy(), ref_mask(n, 12345, 0.3))
+        assert int(buf[off + n:].sum()) == 0 and int(buf[:off].sum()) == 0
+    g = torch.Generator().manual_seed(3)
+    for n, off in ((1003, 0), (1003, 1)):
+        src = torch.randn(n + off, generator=g).cuda()
+        dst = torch.zeros(n + off, dtype=torch.bfloat16, device="cuda")
+        N.call("cast", 1, src[off:], dst[off:], n)
+        pk, pq = torch.randn(n + off, generator=g).cuda(), torch.randn(n + off, generator=g).cuda()
+        want = pk[off:] * 0.99 + pq[off:] * (1.0 - 0.99)
+        N.call("ema_update", pk[off:], pq[off:], n, 0.99)
+        torch.cuda.synchronize()
+        assert torch.equal(dst[off:], src[off:].bfloat16())
+        np.testing.assert_allclose(pk[off:].cpu().numpy(), want.cpu().numpy(), rtol=1e-6, atol=1e-7)
+    for K in (64, 100):                                            # K % 8 != 0 takes the scalar path
+        B = 5
+        lpos, lneg = torch.randn(B, generator=g).cuda(), torch.randn(B, K, generator=g).cuda()
+        lse = torch.logsumexp(torch.cat([lpos[:, None], lneg], 1), 1).contiguous()
+        P = torch.empty(B, K, dtype=torch.bfloat16, device="cuda")
+        dl = torch.empty(B, device="cuda")
+        N.call("moco_ce_bwd", 1, lpos, lneg, lse, B, K, 0.25, P, dl)
+        torch.cuda.synchronize()
+        np.testing.assert_allclose(P.float().cpu().numpy(), (torch.exp(lneg - lse[:, None]) * 0.25).cpu().numpy(), rtol=1e-2, atol=1e-6)
+        np.testing.assert_allclose(dl.cpu().numpy(), ((torch.exp(lpos - lse) - 1) * 0.25).cpu().numpy(), rtol=1e-5, atol=1e-7)
