@@ -354,6 +354,99 @@ __global__ __launch_bounds__(64 * NW) void gemm_kernel(GemmArgs g) {
     gemm_body<T, TA, TB, BK, MI, NW>(g, smem);
 }
 
+// 256 x 256 output tile, 512 threads = 8 waves (2 x 4), each wave 128 x 64 = 4 x 2 accumulators: per 64-deep k-step the
+// tile needs 1,024 L1->LDS cycles against 2,048 MFMA cycles (the 128 x 128 tile: 512 / 512) and 6 fragment reads per 8
+// MFMAs.  For the 6144-row layers (24 x 8 = 192 tiles: one round on 256 CUs).  bf16 only.
+template <bool TA, bool TB>
+__global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs g) {
+    constexpr int BK = 64, T256 = 256;
+    using SA = Stage<bf16, TA, BK, T256, 512>;
+    using SB = Stage<bf16, TB, BK, T256, 512>;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    bf16* const ldsA0 = reinterpret_cast<bf16*>(smem);
+    bf16* const ldsB0 = ldsA0 + 2 * SA::LDS_ELEMS;
+    const int tiles_n = (g.N + T256 - 1) / T256;
+    int wg = blockIdx.x;
+    if (g.xcd_remap) wg = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+    const int bm = (wg / tiles_n) * T256, bn = (wg % tiles_n) * T256;
+    const int ksteps = (g.K + BK - 1) / BK;
+    const int per = (ksteps + g.ksplit - 1) / g.ksplit;
+    const int ks0 = blockIdx.z * per, ks1 = min(ksteps, ks0 + per);
+    if (ks0 >= ks1) return;
+    const int kend = min(g.K, ks1 * BK);
+    const __amdgpu_buffer_rsrc_t A = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(g.A), 0, g.a_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t B = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(g.B), 0, g.b_bytes, 0x00020000);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wm = (wave >> 2) * 128, wn = (wave & 3) * 64;
+
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    SA sa; SB sb;
+    sa.load(A, g.lda, bm, g.M, ks0 * BK, kend);
+    sb.load(B, g.ldb, bn, g.N, ks0 * BK, kend);
+    sa.put(ldsA0); sb.put(ldsB0);
+    __syncthreads();
+    int cur = 0;
+    for (int ks = ks0; ks < ks1; ++ks) {
+        const bool more = ks + 1 < ks1;
+        if (more) {
+            sa.load(A, g.lda, bm, g.M, (ks + 1) * BK, kend);
+            sb.load(B, g.ldb, bn, g.N, (ks + 1) * BK, kend);
+        }
+        const bf16* la = ldsA0 + cur * SA::LDS_ELEMS;
+        const bf16* lb = ldsB0 + cur * SB::LDS_ELEMS;
+#pragma unroll
+        for (int kk = 0; kk < BK; kk += 16) {
+            Vec8<bf16> fa[4], fb[2];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) fa[i] = SA::frag(la, wm + i * 32, kk, lane);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) fb[j] = SB::frag(lb, wn + j * 32, kk, lane);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) Mma<bf16>::run(acc[i][j], fa[i], fb[j]);
+        }
+        if (more) { sa.put(ldsA0 + (cur ^ 1) * SA::LDS_ELEMS); sb.put(ldsB0 + (cur ^ 1) * SB::LDS_ELEMS); }
+        __syncthreads();
+        cur ^= 1;
+    }
+    // the wave-private epilogue tile holds 64 rows: two passes over the wave's 128
+    epilogue<bf16, 2>(g, *reinterpret_cast<f32x16 (*)[2][2]>(&acc[0]), smem, bm + wm, bn + wn, lane, wave);
+    epilogue<bf16, 2>(g, *reinterpret_cast<f32x16 (*)[2][2]>(&acc[2]), smem, bm + wm + 64, bn + wn, lane, wave);
+}
+
+template <bool TA, bool TB>
+int launch256(const GemmArgs& g, hipStream_t s) {
+    constexpr size_t stage = sizeof(bf16) * 2 * (Stage<bf16, TA, 64, 256, 512>::LDS_ELEMS + Stage<bf16, TB, 64, 256, 512>::LDS_ELEMS);
+    constexpr size_t epi = EPI_LDS * 2;
+    constexpr size_t lds = stage > epi ? stage : epi;
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm256_kernel<TA, TB>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)lds) != hipSuccess) return ASSL_ELAUNCH;
+        attr_set = true;
+    }
+    const int tiles = ceil_div(g.M, 256) * ceil_div(g.N, 256);
+    GemmArgs ga = g;
+    ga.xcd_remap = tiles % 8 == 0 && tiles >= 64;
+    hipLaunchKernelGGL((gemm256_kernel<TA, TB>), dim3(tiles, 1, g.ksplit), dim3(512), lds, s, ga);
+    ASSL_LAUNCH_CHECK();
+}
+
+int dispatch256(const GemmArgs& g, int ta, int tb, hipStream_t s) {
+    if (!ta && !tb) return launch256<false, false>(g, s);
+    if (!ta && tb) return launch256<false, true>(g, s);
+    if (ta && tb) return launch256<true, true>(g, s);
+    return launch256<true, false>(g, s);
+}
+
 // Several independent problems of one kind in ONE launch (blockIdx.y = problem): the three Barlow heads of delores_m run
 // the same chain of GEMMs on different operands; issued as separate launches on separate streams they were serialised by
 // the hardware-queue mapping of the graph executor (1.6 ms of a 3.3 ms step), and each launch filled half the chip at best.
@@ -687,6 +780,8 @@ extern "C" int audiossl_gemm(int dtype, int trans_a, int trans_b, int M, int N, 
     const bool ring_ok = K % GBK == 0 && M >= 8 && N >= 8;
     static const int w8 = getenv("AUDIOSSL_GEMM_W8") ? atoi(getenv("AUDIOSSL_GEMM_W8")) : 0;
     if (w8 && M >= 256) return dispatch<bf16, 64, 2, 8>(g, trans_a, trans_b, s);
+    static const int t256 = getenv("AUDIOSSL_GEMM_T256") ? atoi(getenv("AUDIOSSL_GEMM_T256")) : 0;
+    if (t256 && M >= 1024 && N >= 512) return dispatch256(g, trans_a, trans_b, s);
     if (ring_ok && ring > 0) {
         switch (ring) {
             case 12: return dispatch_ring<1, 2>(g, trans_a, trans_b, s);
