@@ -16,5 +16,5 @@ for mode, M, Nn, K, f32, atomic in (("NT", 1024, 2048, 2048, 0, 0), ("NN", 1024,
         for h in range(3):
             E.gemm(1, ta, tb, M, Nn, K, As[h], As[h].shape[1], Bs[h], Bs[h].shape[1], Cs[h], Nn, out_f32=f32, atomic=2 if atomic else 0)
     def multi():
-        E.gemm_multi(ta, tb, M, Nn, [K] * 3, As, [a.shape[1] for a in As], Bs, [b.shape[1] for b in Bs], Cs, Nn, out_f32=f32, atomic=atomic)
+        E.gemm_multi(ta, tb, M, Nn, [K] * 3, As, [a.shape[1] for a in As], Bs, [b.shape[1] for b in Bs], Cs, Nn, out_f32=f32, atomic=2 if atomic else 0)
     print(f"{mode} {M}x{Nn}x{K}: 3 launches {timeit(single):.1f} us, one multi launch {timeit(multi):.1f} us", flush=True)
