@@ -270,7 +270,7 @@ def _col_buffer(dtype, Nimg, T1, F1, like):
 
 
 def encoder_forward(P, x, dtype, keep=None, p_drop=0.3, train=True, update_running=True, want_layers=True, Wc=None,
-                    layer_out=None):
+                    layer_out=None, before_fc=None):
     """P: dict of fp32 device tensors with the reference's state_dict keys (features_1.0.weight, ...).
     x [N,1,F,T] fp32.  keep: uint8 [N*T3, d] dropout keep-mask or None (no dropout).
     Wc: optional {"fc.0.weight", "fc.3.weight"} already in the activation dtype (flat shadow); layer_out: optional
@@ -322,6 +322,8 @@ def encoder_forward(P, x, dtype, keep=None, p_drop=0.3, train=True, update_runni
     kin = F3 * 64
     M = Nimg * T3
     c.d, c.kin, c.M = d, kin, M
+    if before_fc is not None:
+        before_fc()                      # e.g. join the stream that refreshes the bf16 weight shadow: first use is below
     if Wc is not None:
         c.fw1, c.fw2 = Wc["fc.0.weight"], Wc["fc.3.weight"]
     else:

@@ -23,6 +23,9 @@ from src.upstream.delores_m.upstream_encoder import DELORES_M as DELORES_M_ENCOD
 from src.utils import concat_all_gather
 
 
+_PREP_ASIDE = os.environ.get("AUDIOSSL_PREP_ASIDE", "1") != "0"
+
+
 def _world():
     import torch.distributed as dist
     return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
@@ -59,6 +62,7 @@ class Upstream_Expert(MocoQueueMixin, FusedExpertMixin, UpstreamModule):
         self.encoder_q.encoder.precision = self.encoder_k.encoder.precision = self.precision
         self.flat_k = None
         self._key_stream = E.SideStream()
+        self._prep_stream = E.SideStream()
 
     def init_encoders(self, base_encoder):
         return DELORES_M_ENCODER(self.config, base_encoder), DELORES_M_ENCODER(self.config, base_encoder)
@@ -120,15 +124,24 @@ class Upstream_Expert(MocoQueueMixin, FusedExpertMixin, UpstreamModule):
 
         # ---- query encoder (main stream)
         def query_phase():
-            if need_grad:
-                flat.zero_grad()
-            flat.refresh_shadow(dt)
+            # clearing the flat gradient and refreshing the bf16 weight shadow are two HBM-bound sweeps (152 MB written,
+            # 228 MB moved) that nothing needs before the encoder's fc layers: they run on a side stream beside the stem and
+            # the convolutions (which read the fp32 parameters) and are joined right before the first shadow weight is used
+            def prep():
+                if need_grad:
+                    flat.zero_grad()
+                flat.refresh_shadow(dt)
+            if _PREP_ASIDE:
+                self._prep_stream.run(dev, prep)
+            else:
+                prep()
             Wq = flat.shadow_dict("encoder_q.")
             wq = Wq["fc.weight"]
             loss = torch.zeros(4, dtype=torch.float32, device=dev)          # [ce, barlow1, barlow2, barlow3]
             keep = eq.encoder.next_keep_mask(B, img_q.shape[-1])
             _, _, _, Hq, cq = E.encoder_forward(eq.encoder.param_dict(), img_q, dt, keep=keep, p_drop=0.3, train=self.training,
-                                                Wc=strip(Wq, "encoder."), layer_out=tuple(y[:B] for y in Ys))
+                                                Wc=strip(Wq, "encoder."), layer_out=tuple(y[:B] for y in Ys),
+                                                before_fc=(lambda: self._prep_stream.join(dev)) if _PREP_ASIDE else None)
             yq, argq = E.maxmean_forward(dt, Hq)
             q = E.linear_fwd(dt, yq, wq, B, wq.shape[0], wq.shape[1], bias=eq.fc.bias.data, out_f32=1)
             return loss, wq, Hq, cq, yq, argq, q
