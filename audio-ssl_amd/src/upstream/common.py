@@ -258,6 +258,17 @@ class MocoQueueMixin:
         self.ensure_flat()
         N.call("ema_update", self.flat_k.data, self.flat.data, self.flat_k.numel, float(self.hparams.encoder_momentum))
 
+    def queue_shadow(self, dtype):
+        """bf16 copy of the negatives' queue, kept current by `enqueue` (which writes the new keys into both): one full cast
+        when it is first needed or after the queue tensor was replaced / overwritten by torch (load_state_dict, .to())."""
+        if dtype == N.F32:
+            return self.queue
+        tag = (self.queue.data_ptr(), self.queue._version)
+        if getattr(self, "_qshadow", None) is None or self._qshadow_tag != tag:
+            self._qshadow = E.cast(dtype, self.queue)
+            self._qshadow_tag = tag
+        return self._qshadow
+
     @torch.no_grad()
     def _dequeue_and_enqueue(self, keys32, shadow):
         if _world() > 1:

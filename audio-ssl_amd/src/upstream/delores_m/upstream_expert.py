@@ -183,7 +183,7 @@ class Upstream_Expert(MocoQueueMixin, FusedExpertMixin, UpstreamModule):
                 dys = list(R.phase("heads", heads_phase))
 
         def moco_phase():
-            shadow = E.cast(dt, self.queue) if dt != N.F32 else self.queue
+            shadow = self.queue_shadow(dt)              # maintained by enqueue: no per-step cast of the 16.8 MB queue
             dq, kn32 = E.moco_forward_backward(dt, q, k, self.queue, shadow, float(self.hparams.softmax_temperature),
                                                loss[0:1], backward=need_grad)
             dA2 = None
@@ -195,7 +195,8 @@ class Upstream_Expert(MocoQueueMixin, FusedExpertMixin, UpstreamModule):
                 dA2 = E.maxmean_backward(dt, dyq, argq, Hq)
             return kn32, dA2
         kn32, dA2 = R.phase("moco", moco_phase)
-        self._dequeue_and_enqueue(kn32, None)               # after the logits and dq GEMMs have read the queue
+        # after the logits and dq GEMMs have read the queue; the new keys go into the fp32 queue and its bf16 shadow
+        self._dequeue_and_enqueue(kn32, self.queue_shadow(dt) if dt != N.F32 else None)
         for st in streams:
             main.wait_stream(st)
         for d in dys:
