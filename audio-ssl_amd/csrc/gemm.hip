@@ -73,7 +73,7 @@ template <typename T, int MI>
 __device__ __forceinline__ void epilogue_lds(const GemmArgs& g, f32x16 (&acc)[MI][2], char* smem, int row0, int col0, int lane,
                                              int wave) {
     __syncthreads();                                             // every wave is done with the staging buffers
-    float* ct = reinterpret_cast<float*>(smem) + wave * 64 * EPI_PITCH;
+    float* ct = reinterpret_cast<float*>(smem) + wave * (32 * MI) * EPI_PITCH;
     const int half = lane >> 5, l31 = lane & 31;
 #pragma unroll
     for (int i = 0; i < MI; ++i)
@@ -93,7 +93,7 @@ __device__ __forceinline__ void epilogue_lds(const GemmArgs& g, f32x16 (&acc)[MI
     for (int r0 = 0; r0 < rows; r0 += 8) {
         float v[8];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) v[u] = ct[min(r0 + u, 63) * EPI_PITCH + lane];
+        for (int u = 0; u < 8; ++u) v[u] = ct[min(r0 + u, 32 * MI - 1) * EPI_PITCH + lane];
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
             const long row = row0 + min(r0 + u, rows - 1);
@@ -123,7 +123,7 @@ template <int MI>
 __device__ __forceinline__ void epilogue_vec(const GemmArgs& g, f32x16 (&acc)[MI][2], char* smem, int row0, int col0, int lane,
                                              int wave) {
     __syncthreads();
-    float* ct = reinterpret_cast<float*>(smem) + wave * 64 * EPI_PITCH;
+    float* ct = reinterpret_cast<float*>(smem) + wave * (32 * MI) * EPI_PITCH;
     const int half = lane >> 5, l31 = lane & 31;
 #pragma unroll
     for (int i = 0; i < MI; ++i)
@@ -275,7 +275,7 @@ struct Stage {
 // NW = 4 waves (2 x 2): 128 x 128 tile (MI = 2) or 64 x 128 (MI = 1: twice the workgroups for grids that would leave CUs idle).
 // NW = 8 waves (4 x 2): 256 x 128 tile - twice the MFMA work per byte staged (the 128 x 128 tile needs as many L1->LDS cycles
 // per k-step as MFMA cycles) and two waves per SIMD, so one wave's MFMAs cover the other's LDS reads and staging stores.
-template <typename T, bool TA, bool TB, int BK, int MI, int NW = 4>
+template <typename T, bool TA, bool TB, int BK, int MI, int NW = 4, bool SPLIT_EPI = false>
 __device__ __forceinline__ void gemm_body(const GemmArgs& g, char* smem) {
     constexpr int BMv = 16 * MI * NW;
     using SA = Stage<T, TA, BK, BMv, 64 * NW>;
@@ -345,7 +345,12 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g, char* smem) {
         cur ^= 1;
     }
 
-    epilogue<T, MI>(g, acc, smem, bm + wm, bn + wn, lane, wave);
+    if constexpr (SPLIT_EPI && MI == 2) {                    // half-height epilogue tile: 33 KB of LDS instead of 66.5 KB
+        epilogue<T, 1>(g, *reinterpret_cast<f32x16 (*)[1][2]>(&acc[0]), smem, bm + wm, bn + wn, lane, wave);
+        epilogue<T, 1>(g, *reinterpret_cast<f32x16 (*)[1][2]>(&acc[1]), smem, bm + wm + 32, bn + wn, lane, wave);
+    } else {
+        epilogue<T, MI>(g, acc, smem, bm + wm, bn + wn, lane, wave);
+    }
 }
 
 template <typename T, bool TA, bool TB, int BK, int MI, int NW = 4>
@@ -685,6 +690,36 @@ int dispatch_ring(const GemmArgs& g, int ta, int tb, hipStream_t s) {
     return launch_ring<true, false, MI, NST>(g, s);
 }
 
+// BK = 32 with a register budget for THREE workgroups per CU (41 KB of LDS each; the epilogue runs on half-height tiles so
+// that it fits the same 41 KB); AUDIOSSL_GEMM_BK32=0 disables, =2 also uses it for transposed-A problems.
+template <bool TA, bool TB>
+__global__ __launch_bounds__(256, 3) void gemm_bk32_kernel(GemmArgs g) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    gemm_body<bf16, TA, TB, 32, 2, 4, true>(g, smem);
+}
+template <bool TA, bool TB>
+int launch_bk32(const GemmArgs& g, hipStream_t s) {
+    constexpr size_t stage = sizeof(bf16) * 2 * (Stage<bf16, TA, 32, 128, 256>::LDS_ELEMS + Stage<bf16, TB, 32, BN, 256>::LDS_ELEMS);
+    const size_t lds = stage > EPI_LDS / 2 ? stage : EPI_LDS / 2;
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bk32_kernel<TA, TB>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)lds) != hipSuccess) return ASSL_ELAUNCH;
+        attr_set = true;
+    }
+    const int tiles = ceil_div(g.M, 128) * ceil_div(g.N, BN);
+    GemmArgs ga = g;
+    ga.xcd_remap = tiles % 8 == 0 && tiles >= 64;
+    hipLaunchKernelGGL((gemm_bk32_kernel<TA, TB>), dim3(tiles, 1, g.ksplit), dim3(256), lds, s, ga);
+    ASSL_LAUNCH_CHECK();
+}
+int dispatch_bk32(const GemmArgs& g, int ta, int tb, hipStream_t s) {
+    if (!ta && !tb) return launch_bk32<false, false>(g, s);
+    if (!ta && tb) return launch_bk32<false, true>(g, s);
+    if (ta && tb) return launch_bk32<true, true>(g, s);
+    return launch_bk32<true, false>(g, s);
+}
+
 template <typename T, int BK, int MI, int NW = 4>
 int dispatch(const GemmArgs& g, int ta, int tb, hipStream_t s) {
     if (!ta && !tb) return launch<T, false, false, BK, MI, NW>(g, s);
@@ -780,6 +815,12 @@ extern "C" int audiossl_gemm(int dtype, int trans_a, int trans_b, int M, int N, 
     const bool ring_ok = K % GBK == 0 && M >= 8 && N >= 8;
     static const int w8 = getenv("AUDIOSSL_GEMM_W8") ? atoi(getenv("AUDIOSSL_GEMM_W8")) : 0;
     if (w8 && M >= 256) return dispatch<bf16, 64, 2, 8>(g, trans_a, trans_b, s);
+    // grids of >= 2 workgroups per CU with a K-contiguous A operand: K-step 32 and THREE co-resident workgroups per CU (41 KB
+    // of LDS each, 126 VGPRs) - 12 waves per CU hide the staged-load and barrier waits better than two workgroups at K-step
+    // 64 (6144x2048x2048 NT 80.9 -> 71.5 us, NN 90.2 -> 76.8 us; with a transposed A operand it measured slower)
+    static const int bk32 = getenv("AUDIOSSL_GEMM_BK32") ? atoi(getenv("AUDIOSSL_GEMM_BK32")) : 1;
+    if (bk32 && (!trans_a || bk32 == 2) && (long)ceil_div(M, BM) * ceil_div(N, BN) * ksplit >= 512)
+        return dispatch_bk32(g, trans_a, trans_b, s);
     static const int t256 = getenv("AUDIOSSL_GEMM_T256") ? atoi(getenv("AUDIOSSL_GEMM_T256")) : 0;
     if (t256 && M >= 1024 && N >= 512) return dispatch256(g, trans_a, trans_b, s);
     if (ring_ok && ring > 0) {

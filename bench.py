@@ -44,11 +44,12 @@ def pmc_traffic(ta, tb):
         return None
     tot, n = 0.0, 0
     for name, v in json.load(open(path))["kernels"].items():
-        if ("gemm_kernel" not in name and "gemm_ring_kernel" not in name) or v["read_bytes_per_launch"] is None:
+        if not any(k in name for k in ("gemm_kernel", "gemm_ring_kernel", "gemm_bk32_kernel")) or v["read_bytes_per_launch"] is None:
             continue
-        m = re.search(r"gemm_kernelIDF16bLb(\d)ELb(\d)ELi\d+E", name) or re.search(r"gemm_ring_kernelILb(\d)ELb(\d)ELi\d+E", name)
+        m = (re.search(r"gemm_kernelIDF16bLb(\d)ELb(\d)ELi\d+E", name) or re.search(r"gemm_ring_kernelILb(\d)ELb(\d)ELi\d+E", name)
+             or re.search(r"gemm_bk32_kernelILb(\d)ELb(\d)E", name))
         key = (int(m.group(1)), int(m.group(2))) if m else ((1, 1) if re.search(r"E, true, \d+(, \d+)*>", name) else None)
-        d = re.search(r"gemm_ring_kernel<(false|true), (false|true)", name)          # demangled form of the ring kernels
+        d = re.search(r"gemm_(?:ring|bk32)_kernel<(false|true), (false|true)", name)    # demangled form of the ring / BK=32 kernels
         if d:
             key = (int(d.group(1) == "true"), int(d.group(2) == "true"))
         if key == (ta, tb):
