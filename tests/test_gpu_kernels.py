@@ -351,3 +351,67 @@ def test_colbn_train_fused_fwd_bwd_vs_torch(N, adtype, gdtype, M, C, affine, rel
         assert rel_l2(da.float().cpu(), aref.grad.cpu()) < 6e-3
         if affine:
             assert rel_l2(dg.cpu(), gref.grad.cpu()) < 1e-4 and rel_l2(db.cpu(), bref.grad.cpu()) < 1e-4
+
+
+# ------------------------------------------------------------------------------------ GEMM: multi-problem and tile variants
+def test_gemm_multi_per_problem_shapes(N):
+    """audiossl_gemm_multi with per-problem N / K / leading dimensions (the first projector layer of the three Barlow heads:
+    widths 2048 / 1024 / 512) in every transpose mode, plain and exclusive-accumulate outputs."""
+    from src import engine as E
+    g = torch.Generator().manual_seed(11)
+    M = 200
+    for ta, tb in ((0, 0), (0, 1), (1, 1)):
+        Ns, Ks = [256, 128, 72], [192, 64, 128]
+        if ta:
+            Ks = [200, 200, 200]                                   # the weight-gradient form: the contraction runs over the batch rows
+        As = [torch.randn((k, M) if ta else (M, k), generator=g).cuda().bfloat16() for k in Ks]
+        Bs = [torch.randn((k, n) if tb else (n, k), generator=g).cuda().bfloat16() for n, k in zip(Ns, Ks)]
+        refs = [(a.float().T if ta else a.float()) @ (b.float() if tb else b.float().T) for a, b in zip(As, Bs)]
+        Cs = [torch.empty(M, n, device="cuda", dtype=torch.bfloat16) for n in Ns]
+        E.gemm_multi(ta, tb, M, Ns, Ks, As, [a.shape[1] for a in As], Bs, [b.shape[1] for b in Bs], Cs, Ns)
+        C0 = [torch.randn(M, n, generator=g).cuda() for n in Ns]
+        Cacc = [c.clone() for c in C0]
+        E.gemm_multi(ta, tb, M, Ns, Ks, As, [a.shape[1] for a in As], Bs, [b.shape[1] for b in Bs], Cacc, Ns, alpha=0.5, out_f32=1, atomic=2)
+        torch.cuda.synchronize()
+        for c, c0, ca, r in zip(Cs, C0, Cacc, refs):
+            assert rel_l2(c.float().cpu(), r.cpu()) < 4e-3
+            assert rel_l2(ca.cpu(), (c0 + 0.5 * r).cpu()) < 1e-5
+
+
+_VARIANT_SCRIPT = r"""
+import sys, torch
+sys.path[:0] = [{root!r}, {pkg!r}]
+from src import engine as E
+torch.manual_seed(0)
+worst = 0.0
+for mode, M, Nn, K in {shapes!r}:
+    ta, tb = {{"NT": (0, 0), "NN": (0, 1), "TN": (1, 1)}}[mode]
+    A = torch.randn((K, M) if ta else (M, K), device="cuda").bfloat16()
+    B = torch.randn((K, Nn) if tb else (Nn, K), device="cuda").bfloat16()
+    C = torch.empty(M, Nn, device="cuda", dtype=torch.float32)
+    E.gemm(1, ta, tb, M, Nn, K, A, A.shape[1], B, B.shape[1], C, Nn, out_f32=1)
+    torch.cuda.synchronize()
+    ref = (A.float().t() if ta else A.float()) @ (B.float() if tb else B.float().t())
+    worst = max(worst, float((C - ref).norm() / ref.norm()))
+print("WORST", worst)
+"""
+
+
+@pytest.mark.parametrize("env,shapes", [
+    ({"AUDIOSSL_GEMM_RING": "24"}, [("NT", 300, 264, 128), ("NN", 300, 264, 128), ("TN", 296, 264, 128)]),
+    ({"AUDIOSSL_GEMM_RING": "13"}, [("NT", 300, 264, 192), ("NN", 300, 264, 192), ("TN", 296, 264, 192)]),
+    ({"AUDIOSSL_GEMM_T256": "1"}, [("NT", 1100, 520, 128), ("NN", 1100, 520, 128), ("TN", 1096, 520, 128)]),
+    ({"AUDIOSSL_GEMM_W8": "1"}, [("NT", 300, 264, 128), ("NN", 300, 264, 128), ("TN", 296, 264, 128)]),
+    ({"AUDIOSSL_GEMM_BK32": "2"}, [("NT", 2048, 4096, 96), ("NN", 2048, 4096, 96), ("TN", 2048, 4096, 96)]),
+])
+def test_gemm_tile_variants_in_subprocess(env, shapes):
+    """The tile variants that the default dispatch does not pick for these shapes (ring of every layout, 256x256 and 256x128
+    8-wave tiles, K-step 32 with a transposed A) stay correct: each is forced through its environment switch in a child
+    process (the switches are read once per process) on shapes with partial tiles."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = _VARIANT_SCRIPT.format(root=root, pkg=os.path.join(root, "audio-ssl_amd"), shapes=shapes)
+    out = subprocess.run([sys.executable, "-c", code], env={**os.environ, **env}, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    worst = float(out.stdout.strip().split("WORST")[-1])
+    assert worst < 1e-5, (env, worst)
