@@ -415,3 +415,24 @@ def test_gemm_tile_variants_in_subprocess(env, shapes):
     assert out.returncode == 0, out.stderr[-2000:]
     worst = float(out.stdout.strip().split("WORST")[-1])
     assert worst < 1e-5, (env, worst)
+
+
+def test_gemm_epilogue_large_grid(N):
+    """>= 512 tiles: the default dispatch takes the K-step-32 kernel (three workgroups per CU, half-height epilogue tiles);
+    bias + ReLU + keep mask + gate + fp32 residual on a 6144-row problem like the encoder's fc layers, partial tiles in M."""
+    M, Nn, K = 6100, 2048, 96
+    g = torch.Generator().manual_seed(7)
+    A = torch.randn(M, K, generator=g).cuda().bfloat16()
+    W = torch.randn(Nn, K, generator=g).cuda().bfloat16()
+    bias = torch.randn(Nn, generator=g).cuda()
+    keep = (torch.rand(M, Nn, generator=g) >= 0.3).to(torch.uint8).cuda()
+    gate = torch.randn(M, Nn, generator=g).cuda().bfloat16()
+    out = torch.empty(M, Nn, device="cuda", dtype=torch.bfloat16)
+    N.call("gemm", 1, 0, 0, M, Nn, K, 1.0, A, K, W, K, out, Nn, bias, 1, keep, Nn, 1.0 / 0.7, gate, Nn, 0, 0, 1, None, 0)
+    ref = torch.relu(A.float() @ W.float().T + bias) * keep.float() / 0.7 * (gate.float() > 0)
+    resid = torch.randn(M, Nn, generator=g).cuda()
+    out32 = torch.empty(M, Nn, device="cuda")
+    N.call("gemm", 1, 0, 0, M, Nn, K, 0.5, A, K, W, K, out32, Nn, None, 0, None, 0, 1.0, None, 0, 1, 0, 1, resid, Nn)
+    torch.cuda.synchronize()
+    assert rel_l2(out.float().cpu(), ref.cpu()) < 4e-3
+    assert rel_l2(out32.cpu(), (0.5 * (A.float() @ W.float().T) + resid).cpu()) < 1e-5
