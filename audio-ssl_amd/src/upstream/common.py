@@ -227,15 +227,24 @@ class GraphedStep:
         if self.graph is None or key != self.key:
             self.in_1, self.in_2 = torch.empty_like(img_1), torch.empty_like(img_2)
             torch.cuda.synchronize()
-            self.graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.graph):
-                self.loss = self._eager(self.in_1, self.in_2)
+            # AUDIOSSL_GRAPH_COPIES instantiations of the same step, replayed in turn (same buffers, same stream: the
+            # device-side order is unchanged): launching an executable graph again while its previous launch is still
+            # running makes the runtime wait on the host before it enqueues anything
+            n = max(1, int(os.environ.get("AUDIOSSL_GRAPH_COPIES", "1")))
+            self.graphs, self.losses = [], []
+            for _ in range(n):
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    self.losses.append(self._eager(self.in_1, self.in_2))
+                self.graphs.append(g)
+            self.graph, self.loss = self.graphs[0], self.losses[0]
             self.key = key
         self.in_1.copy_(img_1)
         self.in_2.copy_(img_2)
-        self.graph.replay()
+        i = self.replays % len(self.graphs)
+        self.graphs[i].replay()
         self.replays += 1
-        return self.loss
+        return self.losses[i]
 
 
 def _world():
