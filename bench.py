@@ -4,8 +4,10 @@
 One "step" = one pass of the hot path over one synthetic batch already resident in HBM:
   waveforms [B,16000] -> log-mel -> running norm + two augmented views -> q/k encoders, MoCo InfoNCE (65,536-key
   queue), three Barlow heads, full backward -> [all-reduce] -> SGD(momentum) step.
-Contract: `python bench.py --gpus N --steps K --warmup W`; for N > 1 launch with torch.distributed.run (one rank per
-GPU, RCCL).  Weak scaling (per-GPU batch fixed).  Rank 0 prints ONE JSON line.
+Contract: `python bench.py --gpus N --steps K --warmup W`.  For N > 1 either launch it under torch.distributed.run (one
+rank per GPU, RCCL; RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the environment) or run it directly: the parent then
+starts the N ranks itself as fresh child processes BEFORE touching the GPU, relays rank 0's JSON line and exits non-zero
+if any rank failed.  Weak scaling (per-GPU batch fixed).  Rank 0 prints ONE JSON line.
 """
 import argparse
 import copy
@@ -120,6 +122,32 @@ def cpu_baseline(B, steps, queue):
             "sample": f"{steps} steps of batch {B} (log-mel + two views + delores_m fwd/bwd/SGD, queue {queue}), fp32, torch-CPU oracle"}
 
 
+def spawn_ranks(n, argv):
+    """`python bench.py --gpus N` without a launcher: start N fresh rank processes (this process never touches the GPU and
+    is not replaced), stream their stderr through, print rank 0's stdout (the JSON line), return the worst exit code."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
+    out0, _ = procs[0].communicate()
+    rcs = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    if out0:
+        sys.stdout.write(out0)
+        sys.stdout.flush()
+    bad = [(r, rc) for r, rc in enumerate(rcs) if rc != 0]
+    if bad:
+        print(f"[bench] ranks failed (rank, exit code): {bad}", file=sys.stderr)
+    return max((abs(rc) for rc in rcs), default=0)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -137,8 +165,10 @@ def main():
 
     rank, world = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
     local = int(os.environ.get("LOCAL_RANK", 0))
-    if world != args.gpus and world == 1 and args.gpus > 1:
-        raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        raise SystemExit(spawn_ranks(args.gpus, sys.argv[1:]))         # no GPU call has happened in this process
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if os.environ.get("AUDIOSSL_SHARE_GPU") == "1":                # rehearsal of the N > 1 path on a one-GPU box: every rank on
         local = 0                                                  # cuda:0, gloo transport (RCCL refuses two ranks per device)
     torch.cuda.set_device(local)

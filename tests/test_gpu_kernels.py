@@ -260,10 +260,14 @@ def test_conv1_block_fwd_bwd(N, dtype, T):
 
 
 # ------------------------------------------------------------------------------------------------ implicit-GEMM conv
-@pytest.mark.parametrize("shape", [(3, 50, 32), (2, 48, 32), (3, 25, 16), (5, 24, 16), (1, 3, 32)])
+@pytest.mark.parametrize("shape", [(3, 50, 32), (2, 48, 32), (3, 25, 16), (5, 24, 16), (1, 3, 32),
+                                   (80, 50, 32), (600, 25, 16), (261, 24, 16)])
 def test_conv3x3_implicit_gemm_fwd_dgrad_wgrad(N, shape):
     """bf16 implicit-GEMM conv vs torch conv2d on the same (bf16-exact) operands: forward + fused BN statistics,
-    data gradient, weight gradient.  Tiles end inside images and images end inside tiles for these shapes."""
+    data gradient, weight gradient.  Tiles end inside images and images end inside tiles for these shapes.
+    The last three shapes have 500 / 938 / 392 tiles of 256 pixels: more than the 256 persistent workgroups, so every
+    workgroup walks several tiles (`tile += gridDim.x` with the next tile's halo prefetched) and the weight gradient folds
+    256 per-workgroup partial results - the path the B = 512 step runs."""
     import torch.nn.functional as Fnn
     Nimg, Ti, Fi = shape
     x = torch.from_numpy(fill.normalish((Nimg, Ti, Fi, 64), 61 + Ti)).cuda().bfloat16()          # [N][T][F][C]
@@ -283,6 +287,9 @@ def test_conv3x3_implicit_gemm_fwd_dgrad_wgrad(N, shape):
     assert rel_l2(Y.float().cpu(), ref_cl.cpu()) < 4e-3                                           # bf16 output rounding only
     np.testing.assert_allclose(sq[0].cpu().numpy(), ref_cl.sum((0, 1, 2)).cpu().numpy(), rtol=1e-4, atol=1e-2)
     np.testing.assert_allclose(sq[1].cpu().numpy(), (ref_cl ** 2).sum((0, 1, 2)).cpu().numpy(), rtol=1e-4)
+    Y32 = torch.full((Nimg, Ti, Fi, 64), float("nan"), device="cuda", dtype=torch.float32)        # fp32-output variant (bf16_hp)
+    N.call("conv3x3_fwd", x, Wf, b, Y32, 1, None, None, Nimg, Ti, Fi)
+    assert rel_l2(Y32.cpu(), ref_cl.cpu()) < 1e-5
     # data gradient = the same kernel on dY with the flipped / transposed weights
     dy = torch.from_numpy(fill.normalish((Nimg, Ti, Fi, 64), 64 + Ti)).cuda().bfloat16()
     dx = torch.empty(Nimg, Ti, Fi, 64, device="cuda", dtype=torch.float32)       # fp32 output variant

@@ -231,6 +231,67 @@ def test_delores_m_b32_vs_oracle(cfg_m, prec):
         assert rel_l2(gp, gr) < {"fp32": 2e-3, "bf16": 0.25, "bf16_hp": 0.16}[prec], n
 
 
+def test_delores_m_full_config_b512_k65536_bf16_vs_fp32_path(cfg_m):
+    """BASELINE config 2 at its full size - batch 512, queue 65,536, T = 101 - one step: the default bf16 path against the
+    fp32 HIP path (which the tests above pin to the reference goldens / the CPU oracle; the oracle itself needs minutes
+    at this size) AND both against the CPU oracle itself.  Every loss term, the queue pointer, the enqueued keys, finiteness and norm of every gradient.  This is
+    the only test in which `moco_ce_*` see K = 65,536, `colbn_train_fwd_multi` M = 2 x 512, `tmean` / `bn_relu_pool`
+    N = 512 and the persistent conv3x3 kernels 3,200 / 800 tiles.  Reference: delores_m/upstream_expert.py:222-278."""
+    from src.encoder import AudioNTT2020Task6
+    from src.upstream.delores_m.upstream_expert import Upstream_Expert
+    B, T, Tp, K = 512, 101, 12, 65536
+    a, b = views(B, T, 9900).cuda(), views(B, T, 9901).cuda()
+    mq, mk = drop_mask((B, Tp, 2048), 9902), drop_mask((B, Tp, 2048), 9903)
+    outs = {}
+    ref = OM.DeloresMExpert(copy.deepcopy(cfg_m), num_negatives=K)           # the oracle: ~10 s of CPU at this size
+    fill.fill_state_dict_(ref, seed=13)
+    for pq, pk in zip(ref.encoder_q.parameters(), ref.encoder_k.parameters()):
+        pk.data.copy_(pq.data)
+    ref.queue.copy_(closed_queue(128, K))
+    ref.train()
+    rparts = {}
+    ref.training_loss(a.cpu(), b.cpu(), mq, mk, rparts).backward()
+    rn, rnorm, _ = grad_digest(ref)
+    want4 = np.array([float(rparts[k]) for k in ("ce", "b1", "b2", "b3")])
+    del ref
+    for prec in ("fp32", "bf16"):
+        em = Upstream_Expert(_cfg(cfg_m, prec), base_encoder=AudioNTT2020Task6, num_negatives=K)
+        fill.fill_state_dict_(em, seed=13)
+        for pq, pk in zip(em.encoder_q.parameters(), em.encoder_k.parameters()):
+            pk.data.copy_(pq.data)
+        em.queue.copy_(closed_queue(128, K))
+        em = em.cuda().train()
+        em.encoder_q.encoder.dropout_masks.queue = [mq]
+        em.encoder_k.encoder.dropout_masks.queue = [mk]
+        parts = {}
+        loss = em.fused_loss(a, b, True, parts)
+        em.flat.attach_grads()
+        torch.cuda.synchronize()
+        names, norms, _ = grad_digest(em)
+        outs[prec] = dict(loss=float(loss), parts=parts["losses"].cpu().numpy(), names=names, norms=norms,
+                          ptr=int(em.queue_ptr[0]), keys=em.queue[:, :B].float().cpu(), tail=em.queue[:, B:B + 64].float().cpu(),
+                          grads={n: p.grad.float().cpu() for n, p in em.named_parameters() if p.grad is not None
+                                 and n in ("encoder_q.fc.weight", "encoder_q.encoder.fc.3.weight", "p1.projector.6.weight",
+                                           "encoder_q.encoder.features_3.0.weight", "encoder_q.encoder.features_2.0.weight")})
+        assert all(bool(torch.isfinite(p.grad).all()) for p in em.parameters() if p.grad is not None)
+        del em
+        torch.cuda.empty_cache()
+    f, h = outs["fp32"], outs["bf16"]
+    np.testing.assert_allclose(f["parts"], want4, rtol=LOSS_TOL["fp32"])       # fp32 HIP path == oracle at full size
+    assert f["names"] == rn
+    _check_grad_norms(f["names"], f["norms"], rnorm, "fp32")
+    np.testing.assert_allclose(h["parts"], want4, rtol=LOSS_TOL["bf16"])
+    np.testing.assert_allclose(h["parts"], f["parts"], rtol=2e-2)
+    assert abs(h["loss"] - f["loss"]) <= 2e-2 * abs(f["loss"])
+    assert h["ptr"] == f["ptr"] == B % K
+    assert rel_l2(h["keys"], f["keys"]) < 3e-2                     # the 512 enqueued (normalised) keys
+    assert torch.equal(f["tail"], closed_queue(128, K)[:, B:B + 64])        # columns past the pointer untouched
+    assert h["names"] == f["names"]
+    _check_grad_norms(h["names"], h["norms"], f["norms"], "bf16")
+    for n in f["grads"]:
+        assert rel_l2(h["grads"][n], f["grads"][n]) < 0.25, n
+
+
 @pytest.mark.parametrize("prec", ["fp32", "bf16"])
 def test_slicer_steps_vs_reference_golden(golden, cfg_s, prec):
     """SLICER: symmetric MoCo + ClusterLoss, two SGD steps, against numbers produced by the reference's own plugin
