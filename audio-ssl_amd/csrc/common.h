@@ -14,9 +14,27 @@
 // Scratch zeroing.  Entry points that accumulate into caller-provided scratch zero it themselves - unless the caller has
 // declared (audiossl_set_prezeroed) that every scratch pointer it passes is already zero: the fused training step takes all
 // of them from one arena cleared by a single memset, which removes ~30 tiny memset nodes from the step's graph.
+//
+// The clear is a KERNEL, never hipMemsetAsync: a memset captured into a hipGraph becomes a memset node, and on ROCm 7.2 the
+// replayed graph did not reliably order such nodes against the kernel nodes around them.  Round 1's two-rank graph step
+// (both ranks on one GPU) produced a wrong update in 2 of 8 runs with ~30 memset nodes clearing recycled statistics scratch
+// inside the phase graphs; the same build with every memset replaced by this kernel: 0 of 20 (tools/bisect_ddp.sh,
+// DESIGN.md section 5).  All sizes cleared here are multiples of 4 bytes.
 extern int g_assl_prezeroed;
+static __global__ void assl_zero_kernel(unsigned int* __restrict__ p, long n) {
+    long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = 0u;
+}
+static inline hipError_t assl_zero_async(void* p, size_t bytes, hipStream_t s) {
+    long n = (long)((bytes + 3) / 4);
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(assl_zero_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (unsigned int*)p, n);
+    return hipGetLastError();
+}
 #define ASSL_ZERO(ptr, bytes, s) \
-    do { if (!g_assl_prezeroed && hipMemsetAsync((ptr), 0, (bytes), (s)) != hipSuccess) return ASSL_ELAUNCH; } while (0)
+    do { if (!g_assl_prezeroed && assl_zero_async((ptr), (bytes), (s)) != hipSuccess) return ASSL_ELAUNCH; } while (0)
+#define ASSL_ZERO_ALWAYS(ptr, bytes, s) \
+    do { if (assl_zero_async((ptr), (bytes), (s)) != hipSuccess) return ASSL_ELAUNCH; } while (0)
 
 #define ASSL_LAUNCH_CHECK() do { if (hipGetLastError() != hipSuccess) return ASSL_ELAUNCH; return ASSL_OK; } while (0)
 

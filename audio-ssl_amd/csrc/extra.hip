@@ -240,8 +240,8 @@ extern "C" int audiossl_kmeans_accumulate(const float* x, const long long* assig
                                           void* stream) {
     ASSL_REQUIRE(x && assign && sums && counts && N > 0 && K > 0 && D > 0);
     hipStream_t s = S_(stream);
-    if (hipMemsetAsync(sums, 0, sizeof(float) * K * D, s) != hipSuccess) return ASSL_ELAUNCH;
-    if (hipMemsetAsync(counts, 0, sizeof(int) * K, s) != hipSuccess) return ASSL_ELAUNCH;
+    ASSL_ZERO_ALWAYS(sums, sizeof(float) * K * D, s);
+    ASSL_ZERO_ALWAYS(counts, sizeof(int) * K, s);
     hipLaunchKernelGGL(kmeans_accumulate_kernel, dim3(ceil_div(N, 4)), dim3(256), 0, s, x, assign, N, D, sums, counts);
     ASSL_LAUNCH_CHECK();
 }
@@ -257,7 +257,7 @@ extern "C" int audiossl_ce_rows(int dtype, const float* logits, const long long*
                                 float* loss_out, void* dlogits, void* stream) {
     ASSL_REQUIRE(logits && target && cnt && loss_out && B > 0 && K > 0 && (dtype == 0 || dtype == 1));
     hipStream_t s = S_(stream);
-    if (hipMemsetAsync(cnt, 0, sizeof(int), s) != hipSuccess) return ASSL_ELAUNCH;
+    ASSL_ZERO_ALWAYS(cnt, sizeof(int), s);
     hipLaunchKernelGGL(count_valid_kernel, dim3(1), dim3(256), 0, s, target, B, ignore_index, cnt);
     if (dtype == 0) hipLaunchKernelGGL(ce_rows_kernel<float>, dim3(B), dim3(256), 0, s, logits, target, K, ignore_index, cnt, loss_out, (float*)dlogits);
     else            hipLaunchKernelGGL(ce_rows_kernel<bf16>, dim3(B), dim3(256), 0, s, logits, target, K, ignore_index, cnt, loss_out, (bf16*)dlogits);
@@ -282,7 +282,7 @@ extern "C" int audiossl_lars_step(float* p, const float* g, float* mu, const voi
                                   float momentum, float eta, float grad_scale, double* norms, void* stream) {
     ASSL_REQUIRE(p && g && mu && seg && lr && norms && n_seg > 0);
     hipStream_t s = S_(stream);
-    if (hipMemsetAsync(norms, 0, sizeof(double) * 2 * n_seg, s) != hipSuccess) return ASSL_ELAUNCH;
+    ASSL_ZERO_ALWAYS(norms, sizeof(double) * 2 * n_seg, s);
     const LarsSeg* sg = static_cast<const LarsSeg*>(seg);
     hipLaunchKernelGGL(lars_norms_kernel, dim3(64, n_seg), dim3(256), 0, s, p, g, sg, weight_decay, grad_scale, norms);
     hipLaunchKernelGGL(lars_update_kernel, dim3(64, n_seg), dim3(256), 0, s, p, g, mu, sg, norms, lr, weight_decay, momentum, eta,

@@ -108,10 +108,6 @@ class EagerPhases:
 EAGER = EagerPhases()
 
 
-_GRAPH_TICK = os.environ.get("AUDIOSSL_GRAPH_TICK", "0") == "1"
-_DDP_DRAIN = os.environ.get("AUDIOSSL_DDP_DRAIN", "1") == "1"
-
-
 class GraphPhases:
     """Phase runner of the data-parallel graph step.  The step is cut at its collectives into phases (query encoder,
     key encoder, loss heads, encoder backward); each phase is captured into its own hipGraph the first time it runs and
@@ -140,17 +136,7 @@ class GraphPhases:
                 return fn()
             self.graphs[name] = g
         g.replay()
-        if _GRAPH_TICK:
-            self._tick_after_replay()
         return self.results[name]
-
-    def _tick_after_replay(self):
-        """diagnostic: one ordinary kernel on the launch stream right after the graph launch"""
-        dev = torch.cuda.current_device()
-        t = self.buffers.get(("tick", dev))
-        if t is None:
-            t = self.buffers[("tick", dev)] = torch.zeros(64, device="cuda")
-        t.add_(1.0)
 
     def static(self, name, t):
         buf = self.buffers.get(name)
@@ -213,12 +199,8 @@ class GraphedStep:
         self.opt.grad_scale_tensor = None
         loss = self.expert.fused_loss(img_1, img_2, True, **kw)
         self.expert.all_reduce_grads()             # no-op on one rank
-        if runner is not None and _DDP_DRAIN:
-            # graph-phase mode: the optimiser launch that follows must not be issued while the phase graphs are still in
-            # flight on this stream.  Without this drain the two-rank test (tools/ddp_flaky.py) produced a wrong - but on
-            # both ranks identical - update in about half of the runs; syncing before the collectives or after the
-            # optimiser did not help, draining the launch stream here did (8/8 runs, twice).  Root cause not established.
-            torch.cuda.current_stream().synchronize()
+        # No host drain here.  Round 1 needed one to hide a wrong update in the two-rank graph step; its cause was the
+        # hipMemsetAsync nodes inside the phase graphs (csrc/common.h ASSL_ZERO), which no longer exist.
         self.opt.grad_scale_tensor = None
         self.opt.step()
         return loss

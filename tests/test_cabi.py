@@ -58,3 +58,15 @@ def test_product_does_not_import_the_oracle():
             if f.endswith((".py", ".hip", ".h")):
                 txt = open(os.path.join(dp, f)).read()
                 assert "import oracle" not in txt and "from oracle" not in txt, f
+
+
+def test_no_memset_nodes_in_the_library():
+    """Scratch is cleared by a kernel, never by hipMemsetAsync: memset nodes inside replayed hipGraphs were the cause of
+    round 1's wrong two-rank update (csrc/common.h).  Static check over the HIP sources."""
+    import glob
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for path in glob.glob(os.path.join(root, "audio-ssl_amd", "csrc", "*")):
+        code = re.sub(r"//[^\n]*", "", open(path).read())
+        code = re.sub(r"/\*.*?\*/", "", code, flags=re.S)
+        assert "hipMemsetAsync" not in code and "hipMemset(" not in code, path
