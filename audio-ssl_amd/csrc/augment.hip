@@ -4,7 +4,7 @@
 // `augmentations.py:8-12, 14-61, 82-116, 215-282`).  All randomness stays on the host (the reference
 // draws from numpy / python `random`; indices must be bit-exact), so the kernels take parameter tables.
 //   clip_moments   : per-clip sum / sum-of-squares in fp64                       (read 4*F*T B/clip)
-//   runnorm_scan   : the sequential RunningNorm recurrence over the batch, one thread (B steps)
+//   runnorm_scan   : the sequential RunningNorm recurrence over the batch, bit for bit, as two pipelined serial chains
 //   aug_normalize  : (x - mu_c) / sd_c into the device ring that doubles as the mixup memory bank
 //   aug_views      : per (clip, view) block: mix with the partner clip into LDS, then bicubic
 //                    (A=-0.75, align_corners) resize of the random crop of the zero canvas
@@ -27,42 +27,103 @@ __global__ __launch_bounds__(256) void clip_moments_kernel(const float* __restri
     if (threadIdx.x == 0) { mom[2 * blockIdx.x] = s; mom[2 * blockIdx.x + 1] = q; }
 }
 
-// (the moments are staged in LDS first: the scan itself is one thread, ~20 cycles per clip)
-// state_i = {n_seen, max_update}; state_f = {mu, s2}.  Reference recurrence (augmentations.py:222-227):
-// first sample sets, later samples do  v += (new - v) / n  with n the count BEFORE the increment.
-__global__ void runnorm_scan_kernel(const double* __restrict__ mom, int B, int n_elem, long long* state_i,
-                                    float* state_f, float* __restrict__ mu_out, float* __restrict__ sd_out) {
-    extern __shared__ __attribute__((aligned(16))) double sm[];           // [2B] moments in, (mu, sd) float pairs out
-    for (int i = threadIdx.x; i < 2 * B; i += blockDim.x) sm[i] = mom[i];
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        long long n = state_i[0];
-        const long long max_update = state_i[1];
-        float mu = state_f[0], s2 = state_f[1];
-        const double inv = 1.0 / (double)n_elem;
-        for (int c = 0; c < B; ++c) {
-            if (n < max_update) {
-                const double ex = sm[2 * c] * inv, ex2 = sm[2 * c + 1] * inv;
-                const float m = (float)ex;
-                mu = (n == 0) ? m : mu + (m - mu) / (float)n;
-                const double mud = (double)mu;
-                const float v = (float)(ex2 - 2.0 * mud * ex + mud * mud);
-                s2 = (n == 0) ? v : s2 + (v - s2) / (float)n;
-                ++n;
-            }
-            float* o = reinterpret_cast<float*>(&sm[2 * c]);
-            o[0] = mu;
-            o[1] = fminf(fmaxf(sqrtf(s2), F32_EPS), F32_MAX);
-        }
-        state_i[0] = n;
-        state_f[0] = mu;
-        state_f[1] = s2;
+// state_i = {n_seen, max_update}; state_f = {mu, s2}.  Reference recurrence (augmentations.py:222-227), fp32, clip after clip:
+// first sample sets, later samples do  v += (new - v) / n  with n the count BEFORE the increment; the variance sample of clip
+// c uses the ALREADY updated mean.  The recurrence is kept bit for bit (a re-associated parallel scan drifts from the fp32
+// evaluation by up to ~30 ulp over an epoch), but it is taken apart so that only two short dependent chains stay serial:
+//   * every 1/n is computed ahead, in parallel, in fp64.  (float)((double)d * fl64(1/n)) equals the correctly rounded fp32
+//     quotient d / (float)n for n < 2^24: the exact quotient of a 24-bit by a <=24-bit number is at least 2^-50 (relative)
+//     away from every fp32 rounding boundary, the fp64 product is within 2^-52 of it.  Larger n take the true division.
+//   * wave 0 runs the mean chain (sub, cvt, mul, cvt, add per clip) 64 clips ahead of wave 1, which computes the 64 variance
+//     samples of the previous block in parallel across its lanes and then runs the variance chain.
+// 512 clips: 133 us as one thread doing everything -> ~20 us.
+// 64 steps of  v <- v + (float)((double)(x_c - v) * r_c)  executed by the whole wave on wave-uniform operands: lane c holds
+// (x_c, r_c), each step broadcasts its pair with v_readlane (scalar registers), so the dependent chain is five VALU
+// instructions per step with no LDS access in it; lane c keeps the state after step c.
+__device__ __forceinline__ float chain64(float v, float x_mine, double r_mine, float& keep) {
+    const int rlo = __double2loint(r_mine), rhi = __double2hiint(r_mine);
+#pragma unroll
+    for (int c = 0; c < 64; ++c) {
+        const float x = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x_mine), c));
+        const double r = __hiloint2double(__builtin_amdgcn_readlane(rhi, c), __builtin_amdgcn_readlane(rlo, c));
+        v = v + (float)((double)(x - v) * r);
+        keep = ((int)(threadIdx.x & 63) == c) ? v : keep;
     }
+    return v;
+}
+
+__global__ __launch_bounds__(128) void runnorm_scan_kernel(const double* __restrict__ mom, int B, int n_elem, long long* state_i,
+                                                           float* state_f, float* __restrict__ mu_out, float* __restrict__ sd_out) {
+    extern __shared__ __attribute__((aligned(16))) double sm[];
+    double* rn = sm;                                        // [B] 1 / (float)n
+    float* m_s = reinterpret_cast<float*>(rn + B);          // [B] clip means
+    float* mu_s = m_s + B;                                  // [B] running mean after clip c
+    float* v_s = mu_s + B;                                  // [B] variance sample of clip c
+    float* s2_s = v_s + B;                                  // [B] running variance after clip c
+    const long long n0 = state_i[0], max_update = state_i[1];
+    const double inv = 1.0 / (double)n_elem;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    // rn[c] = 0 for clips that do not update (n >= max_update) and for the very first sample (n == 0, which SETS the state):
+    // the chain step  v + (float)((double)(new - v) * rn)  then leaves v untouched, so the serial loops are branch-free
+    const bool big = n0 + B > (1 << 24);                    // beyond 2^24 samples the reciprocal is not exact: true division
+    for (int c = tid; c < B; c += 128) {
+        m_s[c] = (float)(mom[2 * c] * inv);
+        const long long n = n0 + c;
+        rn[c] = (n > 0 && n < max_update) ? (big ? (double)(float)n : 1.0 / (double)(float)n) : 0.0;
+    }
+    float mu = state_f[0], s2 = state_f[1];
+    const bool first = n0 == 0 && max_update > 0;            // clip 0 is the first sample ever
     __syncthreads();
-    for (int c = threadIdx.x; c < B; c += blockDim.x) {
-        const float* o = reinterpret_cast<const float*>(&sm[2 * c]);
-        mu_out[c] = o[0];
-        sd_out[c] = o[1];
+    const int nblk = (B + 63) / 64;
+    for (int k = 0; k <= nblk; ++k) {
+        if (wave == 0 && k < nblk) {
+            const int c0 = 64 * k, c = c0 + lane;
+            if (!big) {
+                if (k == 0 && first) mu = m_s[0];                        // rn[0] = 0: the chain leaves it in place
+                float keep = 0.f;
+                mu = chain64(mu, c < B ? m_s[c] : 0.f, c < B ? rn[c] : 0.0, keep);
+                if (c < B) mu_s[c] = keep;
+            } else if (lane == 0) {
+                int i = c0;
+                const int c1 = min(c0 + 64, B);
+                if (i == 0 && first) { mu = m_s[0]; mu_s[0] = mu; i = 1; }
+                for (; i < c1; ++i) { if (rn[i] != 0.0) mu = mu + (m_s[i] - mu) / (float)rn[i]; mu_s[i] = mu; }
+            }
+        }
+        if (wave == 1 && k >= 1) {
+            const int c0 = 64 * (k - 1), c1 = min(c0 + 64, B), c = c0 + lane;
+            float v = 0.f;
+            if (c < c1) {
+                const double ex = mom[2 * c] * inv, ex2 = mom[2 * c + 1] * inv, mud = (double)mu_s[c];
+                v = (float)(ex2 - 2.0 * mud * ex + mud * mud);
+            }
+            if (!big) {
+                if (k == 1 && first) s2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 0));
+                float keep = 0.f;
+                s2 = chain64(s2, v, c < c1 ? rn[c] : 0.0, keep);
+                if (c < c1) s2_s[c] = keep;
+            } else {
+                if (c < c1) v_s[c] = v;
+                __threadfence_block();                      // the lanes' v_s stores before lane 0 reads them
+                if (lane == 0) {
+                    int i = c0;
+                    if (i == 0 && first) { s2 = v_s[0]; s2_s[0] = s2; i = 1; }
+                    for (; i < c1; ++i) { if (rn[i] != 0.0) s2 = s2 + (v_s[i] - s2) / (float)rn[i]; s2_s[i] = s2; }
+                }
+            }
+        }
+        __syncthreads();
+    }
+    for (int c = tid; c < B; c += 128) {
+        mu_out[c] = mu_s[c];
+        sd_out[c] = fminf(fmaxf(sqrtf(s2_s[c]), F32_EPS), F32_MAX);
+    }
+    if (tid == 0) {
+        long long upd = max_update - n0;
+        upd = upd < 0 ? 0 : (upd > B ? B : upd);
+        state_i[0] = n0 + upd;
+        state_f[0] = mu_s[B - 1];
+        state_f[1] = s2_s[B - 1];
     }
 }
 
@@ -196,7 +257,14 @@ extern "C" int audiossl_clip_moments(const float* x, double* mom, int B, int n, 
 extern "C" int audiossl_runnorm_scan(const double* mom, int B, int n_elem, long long* state_i, float* state_f,
                                      float* mu_out, float* sd_out, void* stream) {
     ASSL_REQUIRE(mom && state_i && state_f && mu_out && sd_out && B > 0 && B <= 3840 && n_elem > 0);
-    hipLaunchKernelGGL(runnorm_scan_kernel, dim3(1), dim3(256), sizeof(double) * 2 * B, static_cast<hipStream_t>(stream), mom, B, n_elem,
+    const size_t dyn = (size_t)B * (sizeof(double) + 4 * sizeof(float));             // 24 B per clip: 92 KB at the 3,840-clip limit
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(runnorm_scan_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                96 * 1024) != hipSuccess) return ASSL_ELAUNCH;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(runnorm_scan_kernel, dim3(1), dim3(128), dyn, static_cast<hipStream_t>(stream), mom, B, n_elem,
                        state_i, state_f, mu_out, sd_out);
     ASSL_LAUNCH_CHECK();
 }

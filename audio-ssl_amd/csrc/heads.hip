@@ -952,6 +952,80 @@ __global__ __launch_bounds__(256) void split_bf16_kernel(const float* __restrict
         lo[i] = (bf16)(v - (float)h);
     }
 }
+// Centred cast of the time-pooled features that feed a projector (Linear without bias -> train-mode BatchNorm):
+// yc[g][r][c] = bf16(y[g][r][c] - mean_r y[g][.][c]), cmean[g][c] = that mean.  Post-ReLU features averaged over time have
+// |column mean| >> batch standard deviation, so a plain bf16 rounding costs 2^-9 * |mean| / std of the batch variation the
+// BatchNorm keeps (10-20 % on the first projector layer).  The column shift itself is invisible to the
+// layer: (y - 1 c^T) W^T = y W^T - 1 (W c)^T moves every output column by a constant, which train-mode BatchNorm removes;
+// only its running mean sees it (shift_running_mean below), and the weight gradient da1^T y = da1^T yc because a BatchNorm
+// input gradient sums to zero over the batch.  One workgroup = 32 columns of one group, rows in registers (M <= 64 * NR).
+template <int NR>
+__global__ __launch_bounds__(256) void center_cast_kernel(const float* __restrict__ y, bf16* __restrict__ yc,
+                                                          float* __restrict__ cmean, int M, int C) {
+    __shared__ float red[64][65];
+    __shared__ double tot[32];
+    __shared__ float mu_s[32];
+    const int cl = threadIdx.x & 3, r0 = threadIdx.x >> 2, g = blockIdx.y;
+    const int col0 = blockIdx.x * 32 + cl * 8;
+    const float* yg = y + (long)g * M * C;
+    Vec8<float> v[NR];
+    float part[1][8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) part[0][i] = 0.f;
+#pragma unroll
+    for (int j = 0; j < NR; ++j) {
+        const int r = r0 + 64 * j;
+        if (r < M) {
+            v[j] = Vec8<float>::load(yg + (long)r * C + col0);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) part[0][i] += v[j].get(i);
+        }
+    }
+    strip_reduce<1>(part, red, tot);
+    if (threadIdx.x < 32) {
+        const float mu = (float)(tot[threadIdx.x] / (double)M);
+        mu_s[threadIdx.x] = mu;
+        cmean[(long)g * C + blockIdx.x * 32 + threadIdx.x] = mu;
+    }
+    __syncthreads();
+    float mu[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) mu[i] = mu_s[cl * 8 + i];
+    bf16* og = yc + (long)g * M * C;
+#pragma unroll
+    for (int j = 0; j < NR; ++j) {
+        const int r = r0 + 64 * j;
+        if (r < M) {
+            Vec8<bf16> o;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) o.set(i, v[j].get(i) - mu[i]);
+            o.store(og + (long)r * C + col0);
+        }
+    }
+}
+// running_mean[j] += sum_g momentum (1 - momentum)^(G-1-g) * (cmean[g] . W[j]): what the running mean of the BatchNorm behind
+// W (bf16 [D][K], row-major) would have seen from the un-centred input.  One wave per output row j.
+__global__ __launch_bounds__(256) void shift_running_mean_kernel(const bf16* __restrict__ W, const float* __restrict__ cmean,
+                                                                 float* __restrict__ running_mean, int D, int K, int groups,
+                                                                 float momentum) {
+    const int lane = threadIdx.x & 63, j = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (j >= D) return;
+    float acc = 0.f, coef = momentum;
+    for (int g = groups - 1; g >= 0; --g) {
+        const float* cg = cmean + (long)g * K;
+        float t = 0.f;
+        for (int k = lane * 8; k < K; k += 512) {
+            const Vec8<bf16> w = Vec8<bf16>::load(W + (long)j * K + k);
+            const Vec8<float> cv = Vec8<float>::load(cg + k);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) t += w.get(i) * cv.get(i);
+        }
+        acc += coef * t;
+        coef *= (1.f - momentum);
+    }
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+    if (lane == 0) running_mean[j] += acc;
+}
 __global__ void axpy_kernel(float* __restrict__ y, const float* __restrict__ x, float a, long n) {
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) y[i] += a * x[i];
 }
@@ -976,6 +1050,24 @@ extern "C" int audiossl_split_bf16(const float* x, void* hi, void* lo, long n, v
     ASSL_REQUIRE(x && hi && lo && n > 0);
     const int grid = (int)min((long)2048, (n + 255) / 256);
     hipLaunchKernelGGL(split_bf16_kernel, dim3(grid), dim3(256), 0, S_(stream), x, (bf16*)hi, (bf16*)lo, n);
+    ASSL_LAUNCH_CHECK();
+}
+
+extern "C" int audiossl_center_cast(const float* y, void* yc, float* cmean, int groups, long M, int C, void* stream) {
+    ASSL_REQUIRE(y && yc && cmean && groups > 0 && M > 0 && M <= 1024 && C > 0 && C % 32 == 0);
+    ASSL_REQUIRE(ASSL_ALIGNED16(y) && ASSL_ALIGNED16(yc));
+    const dim3 grid(C / 32, groups);
+    if (M <= 512) hipLaunchKernelGGL(center_cast_kernel<8>, grid, dim3(256), 0, S_(stream), y, (bf16*)yc, cmean, (int)M, C);
+    else          hipLaunchKernelGGL(center_cast_kernel<16>, grid, dim3(256), 0, S_(stream), y, (bf16*)yc, cmean, (int)M, C);
+    ASSL_LAUNCH_CHECK();
+}
+
+extern "C" int audiossl_shift_running_mean(const void* W, const float* cmean, float* running_mean, int D, int K, int groups,
+                                           float momentum, void* stream) {
+    ASSL_REQUIRE(W && cmean && running_mean && D > 0 && K > 0 && K % 8 == 0 && groups > 0);
+    ASSL_REQUIRE(ASSL_ALIGNED16(W) && ASSL_ALIGNED16(cmean));
+    hipLaunchKernelGGL(shift_running_mean_kernel, dim3(ceil_div(D, 4)), dim3(256), 0, S_(stream), (const bf16*)W, cmean,
+                       running_mean, D, K, groups, momentum);
     ASSL_LAUNCH_CHECK();
 }
 

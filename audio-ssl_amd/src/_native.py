@@ -47,6 +47,8 @@ _lib = None
 # Optional per-call timing (bench.py): {full_name: [(start_event, end_event, args), ...]} - HIP events recorded on the
 # stream the kernel is launched on (torch's current stream).
 PROFILE = None
+PROFILE_ALL = False   # True: time every entry point (a missing key is created on first use), not only the keys present
+PROFILE_NOTE = None   # set by a caller right before call(): algorithmic work the scalar arguments cannot express (gemm_multi)
 
 
 def lib():
@@ -108,14 +110,22 @@ def call(name, *args):
             v = v.data_ptr()
         conv.append(v)
     conv.append(_raw_stream(_cur_device()))
-    prof = PROFILE.get(full) if PROFILE is not None else None
+    prof = None
+    if PROFILE is not None:
+        prof = PROFILE.get(full)
+        if prof is None and PROFILE_ALL:
+            prof = PROFILE[full] = []
     if prof is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
     rc = fn(*conv)
     if prof is not None:
         e1.record()
-        prof.append((e0, e1, tuple(a for a in args if isinstance(a, (int, float)))))
+        global PROFILE_NOTE
+        # scalar arguments only (host addresses of the multi-problem pointer arrays are ints too: dropped by magnitude)
+        prof.append((e0, e1, tuple(a for a in args if isinstance(a, float) or (isinstance(a, int) and abs(a) < (1 << 40))),
+                     PROFILE_NOTE))
+        PROFILE_NOTE = None
     if rc != 0:
         raise RuntimeError(f"{full} failed: {ERRORS.get(rc, rc)}")
 

@@ -161,8 +161,18 @@ def _ad(dtype):
 
 
 def pooled_dtype(dtype):
-    """torch dtype of the time-pooled features handed to the projector"""
-    return torch.float32 if (HP or dtype == N.F32) else torch.bfloat16
+    """torch dtype of the time-pooled features handed to the projector: fp32 on every path.  The bf16 paths turn them into
+    MFMA operands themselves (centred cast by default, hi + lo split under bf16_hp) - see projector_forward."""
+    return torch.float32
+
+
+def center_cast(Y, groups, B):
+    """Y fp32 [groups*B, C] -> (bf16(Y - per-group column mean), column means [groups, C])"""
+    C = Y.shape[1]
+    yc = _empty((groups * B, C), torch.bfloat16, like=Y)
+    cmean = _empty((groups, C), torch.float32, like=Y)
+    N.call("center_cast", Y, yc, cmean, groups, B, C)
+    return yc, cmean
 
 
 def colsum_add(dtype, X, M, C, dst, tmp=None):
@@ -460,9 +470,16 @@ def projector_forward(PP, Y, dtype, groups, B, update_running=True, Wc=None):
     o32 = int(ad == N.F32)
     # pre-BatchNorm tensors (a1, a2, z) are fp32 GEMM outputs on the fp32 / bf16_hp paths; the normalised activations
     # (MFMA operands) are `dtype`
-    if dtype == N.BF16 and Y.dtype == torch.float32:
+    c.cmean = None
+    if dtype == N.BF16 and Y.dtype == torch.float32 and not HP and B <= 1024 and kin % 32 == 0:
         # time-pooled post-ReLU features: |mean| >> batch-std, so a single bf16 rounding would eat the batch variation
-        # that BatchNorm amplifies.  Run the first GEMM on hi + lo bf16 pieces (fp32 accumulate into the same output).
+        # that BatchNorm amplifies.  The layer is Linear(no bias) -> train-mode BatchNorm, i.e. blind to a constant per input
+        # column: feed it the CENTRED features (csrc/heads.hip center_cast_kernel); the weight gradient is unchanged too.
+        c.y_hi, c.cmean = center_cast(Y, groups, B)
+        c.y_lo = None
+        c.a1 = linear_fwd(dtype, c.y_hi, W[0], M, D, kin, out_f32=o32)
+    elif dtype == N.BF16 and Y.dtype == torch.float32:
+        # bf16_hp: the first GEMM on hi + lo bf16 pieces of the operand (fp32 accumulate into the same output)
         c.y_hi, c.y_lo = _empty((M, kin), td, like=Y), _empty((M, kin), td, like=Y)
         N.call("split_bf16", Y, c.y_hi, c.y_lo, M * kin)
         c.a1 = torch.zeros(M, D, dtype=torch.float32, device=Y.device)
@@ -473,6 +490,8 @@ def projector_forward(PP, Y, dtype, groups, B, update_running=True, Wc=None):
         c.a1 = linear_fwd(dtype, Y, W[0], M, D, kin, out_f32=o32)
     c.h1 = _empty((M, D), td, like=Y)
     c.st1 = bn(c.a1, "projector.1", True, 1, c.h1)
+    if c.cmean is not None and update_running:
+        N.call("shift_running_mean", W[0], c.cmean, PP["projector.1.running_mean"], D, kin, groups, BN_MOMENTUM)
     c.a2 = linear_fwd(dtype, c.h1, W[1], M, D, D, out_f32=o32)
     c.h2 = _empty((M, D), td, like=Y)
     c.st2 = bn(c.a2, "projector.4", True, 1, c.h2)
@@ -565,6 +584,8 @@ def gemm_multi(ta, tb, M, Nn, Ks, As, ldas, Bs, ldbs, Cs, ldc, alpha=1.0, out_f3
     arrs = (_harr(ctypes.c_int, Ns), _harr(ctypes.c_int, Ks), _harr(ctypes.c_void_p, As), _harr(ctypes.c_long, ldas),
             _harr(ctypes.c_void_p, Bs), _harr(ctypes.c_long, ldbs), _harr(ctypes.c_void_p, Cs), _harr(ctypes.c_long, ldcs))
     N_, K_, A_, la_, B_, lb_, C_, lc_ = arrs
+    if N.PROFILE is not None:
+        N.PROFILE_NOTE = float(sum(2.0 * M * nn * kk for nn, kk in zip(Ns, Ks)))        # flops of the launch (bench.py roofline)
     N.call("gemm_multi", n, ta, tb, M, adr(N_), adr(K_), float(alpha), adr(A_), adr(la_), adr(B_), adr(lb_), adr(C_), adr(lc_),
            out_f32, atomic, ksplit)
 
@@ -602,7 +623,12 @@ def barlow_heads_forward_backward(PPs, Gs, Ys, dtype, lambds, scale_losses, loss
         N.call("colbn_train_fwd_multi", nh, ad, adr(arrs[0]), adr(arrs[1]), adr(arrs[2]), adr(arrs[3]), adr(arrs[4]),
                BN_MOMENTUM, BN_EPS, relu, 2, B, D, adr(arrs[5]), adr(arrs[6]))
         return a, st, out
-    a1, st1, h1 = layer(Ys, [W[h][0] for h in H], kins, "projector.1", True, 1)
+    # centred bf16 operands of the first layer (see projector_forward); Ys arrive in fp32
+    ycs, cms = (list(t) for t in zip(*[center_cast(Y, 2, B) for Y in Ys]))
+    a1, st1, h1 = layer(ycs, [W[h][0] for h in H], kins, "projector.1", True, 1)
+    if update_running:
+        for h in H:
+            N.call("shift_running_mean", W[h][0], cms[h], PPs[h]["projector.1.running_mean"], D, kins[h], 2, BN_MOMENTUM)
     a2, st2, h2 = layer(h1, [W[h][1] for h in H], [D] * nh, "projector.4", True, 1)
     z, st0, zn = layer(h2, [W[h][2] for h in H], [D] * nh, "bn", False, 0)
     # correlation c_h = zn1^T zn2 / B, loss, dc
@@ -645,7 +671,7 @@ def barlow_heads_forward_backward(PPs, Gs, Ys, dtype, lambds, scale_losses, loss
     wgrad(da2, h1, "projector.3.weight", [D] * nh)
     dh1 = dgrad(da2, [W[h][1] for h in H], [D] * nh, M)
     da1 = bn_bwd(a1, dh1, st1, 1, ("projector.1.weight", "projector.1.bias"))
-    wgrad(da1, Ys, "projector.0.weight", kins)
+    wgrad(da1, ycs, "projector.0.weight", kins)
     return dgrad(da1, [W[h][0] for h in H], kins, B)      # dY for view 1 only (rows [0, B)); widths differ per head
 
 

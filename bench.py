@@ -34,6 +34,109 @@ CFG = {"run": {"batch_size": 512, "world_size": 1, "num_dataloader_workers": 0, 
                                       "RandomResizeCrop": {"virtual_crop_scale": [1.0, 1.5], "freq_crop_scale": [0.6, 1.5],
                                                            "time_crop_scale": [0.6, 1.5]}}}}
 PEAK_TFLOPS = {0: 157.3, 1: 2500.0}          # MI355X_MICROARCH.md: f32-in MFMA = vector peak; bf16 dense MFMA
+PEAK_HBM_GBS = 8000.0                        # HBM3E
+ES = {0: 4, 1: 2, 2: 2}                      # bytes per element of the dtype codes of the C ABI
+
+
+def _work(entry, a):
+    """Algorithmic work of one launch from the scalar arguments of its C-ABI call (include/audiossl_hip.h order):
+    -> (bound, bytes or flops, dtype code) or None.  HBM figures = bytes every operand is read / written ONCE (DESIGN.md
+    section 4); MFMA figures = 2 * MACs."""
+    if entry == "logmel_fwd":
+        B, L, T, _, _, nm = a[:6]
+        return "hbm", B * (4.0 * L + 4.0 * nm * T), 0
+    if entry == "clip_moments":
+        return "hbm", 4.0 * a[0] * a[1], 0
+    if entry == "aug_normalize":
+        return "hbm", 8.0 * a[2] * a[3], 0
+    if entry == "aug_views":                      # self + partner rows read, two views written
+        return "hbm", 16.0 * a[1] * a[2] * a[3], 0
+    if entry == "conv1_stats":
+        return "hbm", 4.0 * a[0] * a[1] * a[2], 0
+    if entry == "conv1_fwd":
+        d, n, f, t = a[:4]
+        return "hbm", 4.0 * n * f * t + n * (t // 2) * (f // 2) * 64.0 * ES[d], 0
+    if entry == "conv1_bwd":
+        n, f, t = a[2:5]
+        return "hbm", 4.0 * n * f * t + n * (t // 2) * (f // 2) * 64.0 * 4, 0
+    if entry == "colstats":
+        return "hbm", float(a[1] * a[2] * a[3] * ES[a[0]]), 0
+    if entry == "bn_relu_pool_fwd":
+        d, yd, n, ti, fi = a[:5]
+        return "hbm", n * ti * fi * 64.0 * ES[yd] + n * (ti // 2) * (fi // 2) * 64.0 * ES[d], 0
+    if entry == "bn_relu_pool_bwd":
+        d, yd, gd, n, ti, fi = a[:6]
+        return "hbm", n * ti * fi * 64.0 * (ES[yd] + ES[d]) + n * (ti // 2) * (fi // 2) * 64.0 * ES[gd], 0
+    if entry == "tmean_fwd":
+        return "hbm", a[2] * a[3] * a[4] * 64.0 * ES[a[0]], 0
+    if entry == "maxmean_fwd":
+        return "hbm", float(a[2] * a[3] * a[4] * ES[a[0]]), 0
+    if entry == "maxmean_bwd":
+        return "hbm", float(a[2] * a[3] * a[4] * 2 * ES[a[0]]), 0
+    if entry in ("conv3x3_fwd", "conv3x3_wgrad"):
+        n, ti, fi = a[-3:]
+        return "mfma", 2.0 * n * ti * fi * 64 * 576, 1
+    if entry == "gemm":
+        return "mfma", 2.0 * a[3] * a[4] * a[5], a[0]
+    if entry == "colbn_train_fwd":
+        return "hbm", float(a[5] * a[6] * a[7] * (ES[a[1]] + ES[a[0]])), 0
+    if entry == "colbn_train_fwd_multi":
+        return "hbm", float(a[0] * a[5] * a[6] * a[7] * (ES[a[1]] + 2)), 0
+    if entry == "colbn_bwd_multi":
+        return "hbm", float(a[0] * a[4] * a[5] * a[6] * (ES[a[1]] + ES[a[2]] + 2)), 0
+    if entry == "center_cast":
+        return "hbm", 6.0 * a[0] * a[1] * a[2], 0
+    if entry == "moco_ce_fwd":
+        return "hbm", 4.0 * a[0] * a[1], 0
+    if entry == "moco_ce_bwd":
+        return "hbm", 6.0 * a[1] * a[2], 0
+    if entry == "sgd_momentum":
+        return "hbm", 20.0 * a[0], 0
+    if entry == "cast":
+        return "hbm", 6.0 * a[1], 0
+    if entry == "ema_update":
+        return "hbm", 12.0 * a[0], 0
+    if entry == "dropout_mask":
+        return "hbm", 1.0 * a[0], 0
+    return None
+
+
+def per_kernel_report(prof, prof_steps, step_ms):
+    """-> (list of per-entry-point rows sorted by time, the GEMM groups).  Durations are HIP events around each C-ABI call on
+    the stream it was issued on, during an eager re-issue of the step; rocprofv3 --kernel-trace --stats of the same command
+    (profiles/) is the cross-check."""
+    rows, gemm_groups = {}, {}
+    for full, recs in prof.items():
+        entry = full[len("audiossl_"):]
+        for e0, e1, a, note in recs:
+            sec = e0.elapsed_time(e1) * 1e-3
+            w = _work(entry, a)
+            if entry == "gemm_multi" and note:
+                w = ("mfma", note, 1)
+            key = entry
+            if entry == "gemm":
+                key = f"gemm<{'bf16' if a[0] else 'f32'},{GEMM_SYMBOL[(a[1], a[2])]}>"
+                g = gemm_groups.setdefault((a[0], a[1], a[2]), [0.0, 0.0, 0])
+                g[0] += sec; g[1] += 2.0 * a[3] * a[4] * a[5]; g[2] += 1
+            elif entry in ("conv3x3_fwd", "bn_relu_pool_fwd", "bn_relu_pool_bwd", "conv3x3_wgrad", "tmean_fwd"):
+                key = f"{entry}[F={a[-1]}]"
+            r = rows.setdefault(key, {"sec": 0.0, "work": 0.0, "n": 0, "bound": None, "dt": 0})
+            r["sec"] += sec; r["n"] += 1
+            if w is not None:
+                r["bound"], r["dt"] = w[0], w[2]
+                r["work"] += w[1]
+    out = []
+    for key, r in sorted(rows.items(), key=lambda kv: -kv[1]["sec"]):
+        row = {"entry": key, "launches_per_step": round(r["n"] / prof_steps, 2), "avg_us": round(r["sec"] / r["n"] * 1e6, 2),
+               "share_of_step": round(r["sec"] / prof_steps / (step_ms * 1e-3), 4)}
+        if r["bound"] == "hbm" and r["sec"] > 0:
+            ach = r["work"] / r["sec"] / 1e9
+            row.update(bound="hbm", achieved=round(ach, 1), unit="GB/s", frac=round(ach / PEAK_HBM_GBS, 4))
+        elif r["bound"] == "mfma" and r["sec"] > 0:
+            ach = r["work"] / r["sec"] / 1e12
+            row.update(bound="mfma", achieved=round(ach, 1), unit="TFLOP/s", frac=round(ach / PEAK_TFLOPS[r["dt"]], 4))
+        out.append(row)
+    return out, gemm_groups
 GEMM_SYMBOL = {(0, 0): "NT", (0, 1): "NN", (1, 1): "TN", (1, 0): "TT"}
 
 
@@ -227,7 +330,7 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     if gstep is None:
-        N.PROFILE = {"audiossl_gemm": []}
+        N.PROFILE, N.PROFILE_ALL = {}, True
     t0 = time.perf_counter()
     for i in range(args.steps):
         loss = step(args.warmup + i)
@@ -241,7 +344,7 @@ def main():
     if gstep is not None:
         # kernels inside a replayed graph cannot carry HIP events: time the dominant kernel on an eager re-issue of the
         # very same step (same buffers, same streams) right after the timed region
-        N.PROFILE = {"audiossl_gemm": []}
+        N.PROFILE, N.PROFILE_ALL = {}, True
         prof_steps = min(args.steps, 5)
         for i in range(prof_steps):
             img_1, img_2 = front.collect(ticket[0])
@@ -250,7 +353,7 @@ def main():
         torch.cuda.synchronize()
     else:
         prof_steps = args.steps
-    prof, N.PROFILE = N.PROFILE, None
+    prof, N.PROFILE, N.PROFILE_ALL = N.PROFILE, None, False
     if rank == 0:
         print(f"[bench] gpu: {B * world * args.steps / dt:.1f} clips/s, {dt / args.steps * 1e3:.2f} ms/step "
               f"(host launch side {t_host / args.steps * 1e3:.2f} ms/step)", file=sys.stderr, flush=True)
@@ -261,14 +364,9 @@ def main():
     if rank != 0:
         return
 
-    # ---- roofline of the dominant kernel (largest total time among the GEMM instantiations)
-    groups = {}
-    for e0, e1, a in prof["audiossl_gemm"]:
-        dtype, ta, tb, M, Nn, K = a[0], a[1], a[2], a[3], a[4], a[5]
-        g = groups.setdefault((dtype, ta, tb), [0.0, 0.0, 0])
-        g[0] += e0.elapsed_time(e1) * 1e-3
-        g[1] += 2.0 * M * Nn * K
-        g[2] += 1
+    # ---- per-kernel roofline (north_star: GB/s for the mel / augment kernels, TFLOP/s for the encoder GEMMs) and the
+    #      headline `roofline` object = the dominant GEMM instantiation group (largest total time)
+    per_kernel, groups = per_kernel_report(prof, prof_steps, dt / args.steps * 1e3)
     (dtype, ta, tb), (tsec, flops, launches) = max(groups.items(), key=lambda kv: kv[1][0])
     achieved = flops / tsec / 1e12
     roofline = {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_TFLOPS[dtype], "unit": "TFLOP/s",
@@ -276,7 +374,8 @@ def main():
                 "kernel": f"gemm_kernel<{'bf16' if dtype else 'f32'},{GEMM_SYMBOL[(ta, tb)]}>", "launches_per_step": launches / prof_steps,
                 "avg_launch_us": round(tsec / launches * 1e6, 2), "flop_per_launch": flops / launches,
                 "share_of_step": round(tsec / prof_steps / (dt / args.steps), 3),
-                "timed_on": "eager re-issue of the step after the timed region" if gstep is not None else "the timed region"}
+                "timed_on": "eager re-issue of the step after the timed region" if gstep is not None else "the timed region",
+                "per_kernel": per_kernel[:28]}
     out = {"metric": "upstream clips/sec (1s@16kHz, 64-mel)", "value": round(B * world * args.steps / dt, 1), "unit": "clips/s",
            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16" if args.precision.startswith("bf16") else "f32",

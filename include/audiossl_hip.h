@@ -226,6 +226,14 @@ int audiossl_axpy(float* y, const float* x, float a, long n, void* stream);
 /* x = hi + lo, hi = bf16(x), lo = bf16(x - hi): the projector's first GEMM runs on both pieces, because the time-pooled
  * features it reads have |mean| >> batch-std and a single bf16 rounding would eat their batch variation. */
 int audiossl_split_bf16(const float* x, void* hi, void* lo, long n, void* stream);
+/* Default bf16 path, same problem at no extra GEMM: yc = bf16(y - column mean per group) [G][M][C], cmean [G][C] fp32
+ * (M <= 1024, C % 32 == 0).  The projector's first Linear has no bias and is followed by train-mode BatchNorm
+ * (`src/upstream/delores_s/upstream_expert.py:15-22`), which removes the per-column constant the shift produces; the weight
+ * gradient is unchanged because a BatchNorm input gradient sums to zero over the batch.  shift_running_mean repairs the
+ * one thing that does see the shift: running_mean[j] += sum_g m (1-m)^(G-1-g) cmean[g] . W[j]   (W bf16 [D][K]). */
+int audiossl_center_cast(const float* y, void* yc, float* cmean, int groups, long M, int C, void* stream);
+int audiossl_shift_running_mean(const void* W, const float* cmean, float* running_mean, int D, int K, int groups,
+                                float momentum, void* stream);
 
 /* ---- K14 NT-Xent / ClusterLoss: extras/slicer/contrastive_loss.py:6-92 -----------------------------------------
  * sim [N][N] fp32 = z z^T / tau from audiossl_gemm (N = 2B; positives at (r + B) mod N; the diagonal is excluded).

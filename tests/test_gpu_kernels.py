@@ -169,6 +169,41 @@ def test_aug_two_views_match_reference_goldens(N, golden, cfg_s, T):
     np.testing.assert_allclose(dig, g["digest"], rtol=2e-5, atol=2e-2)
 
 
+@pytest.mark.parametrize("B,n0,max_update", [(512, 0, 10 ** 9), (512, 1, 10 ** 9), (512, 5000, 5300), (3840, 123456, 10 ** 9),
+                                             (70, 7, 7), (64, 0, 1)])
+def test_runnorm_scan_is_the_fp32_recurrence_bit_for_bit(N, B, n0, max_update):
+    """RunningNorm state after every clip of a batch (`augmentations.py:215-282`: mu += (m - mu) / n in fp32, the variance
+    sample uses the updated mean, updates stop at max_update) - the pipelined kernel against a numpy float32 loop: EXACT."""
+    n_elem = 64 * 101
+    g = np.random.RandomState(B + n0)
+    ex = g.randn(B) * 0.7 - 4.0
+    ex2 = ex ** 2 + np.abs(g.randn(B)) * 3.0 + 0.1
+    mom = np.stack([ex * n_elem, ex2 * n_elem], 1).astype(np.float64)
+    mu0, s20 = np.float32(-3.9), np.float32(2.5)
+    st_i = torch.tensor([n0, max_update], dtype=torch.int64).cuda()
+    st_f = torch.tensor([mu0, s20], dtype=torch.float32).cuda()
+    mu_out, sd_out = torch.empty(B, device="cuda"), torch.empty(B, device="cuda")
+    N.call("runnorm_scan", dev(mom), B, n_elem, st_i, st_f, mu_out, sd_out)
+    torch.cuda.synchronize()
+    inv = 1.0 / n_elem
+    n, mu, s2 = n0, mu0, s20
+    want_mu, want_sd = np.empty(B, np.float32), np.empty(B, np.float32)
+    for c in range(B):
+        if n < max_update:
+            e, e2 = mom[c, 0] * inv, mom[c, 1] * inv
+            m = np.float32(e)
+            mu = m if n == 0 else np.float32(mu + np.float32(np.float32(m - mu) / np.float32(n)))
+            v = np.float32(e2 - 2.0 * float(mu) * e + float(mu) * float(mu))
+            s2 = v if n == 0 else np.float32(s2 + np.float32(np.float32(v - s2) / np.float32(n)))
+            n += 1
+        want_mu[c] = mu
+        want_sd[c] = min(max(np.sqrt(np.float32(s2)), np.float32(1.1920928955078125e-07)), np.finfo(np.float32).max)
+    assert np.array_equal(mu_out.cpu().numpy(), want_mu)
+    assert np.array_equal(sd_out.cpu().numpy(), want_sd)
+    assert st_i.cpu().tolist() == [n, max_update]
+    assert np.array_equal(st_f.cpu().numpy(), np.array([mu, s2], np.float32))
+
+
 def test_aug_fifo_wraparound_vs_oracle(N, cfg_s):
     """More clips than the 2048-entry FIFO holds: partner resolution across the ring wrap, small images."""
     from src.augmentations import AugmentationModule
@@ -361,6 +396,40 @@ def test_colbn_train_fused_fwd_bwd_vs_torch(N, adtype, gdtype, M, C, affine, rel
 
 
 # ------------------------------------------------------------------------------------ GEMM: multi-problem and tile variants
+def test_center_cast_and_running_mean_shift(N):
+    """Centred bf16 cast of the pooled features + the running-mean repair, and the identity they rest on: a bias-free Linear
+    followed by train-mode BatchNorm gives the same output, the same weight gradient and (after the repair) the same
+    running mean on centred inputs as on the raw ones (`delores_s/upstream_expert.py:15-22`)."""
+    G, D, mom = 2, 96, 0.1
+    for M, K in [(512, 64), (300, 2048), (1000, 512)]:
+        g = torch.Generator().manual_seed(M + K)
+        y = (torch.rand(G, M, K, generator=g) * 0.3 + 5.0 * torch.rand(K, generator=g)).cuda()      # |column mean| >> std
+        yc = torch.empty(G, M, K, device="cuda", dtype=torch.bfloat16)
+        cm = torch.empty(G, K, device="cuda")
+        N.call("center_cast", y, yc, cm, G, M, K)
+        torch.cuda.synchronize()
+        mu = y.double().mean(1)
+        np.testing.assert_allclose(cm.cpu().numpy(), mu.cpu().numpy(), rtol=1e-6)
+        want = y - mu[:, None, :].float()
+        assert float((yc.float() - want).abs().max()) <= 2 ** -8 * float(want.abs().max())          # one bf16 rounding of the CENTRED value
+        W = (torch.randn(D, K, generator=g) * 0.05).cuda().bfloat16()
+        rm_ref = torch.zeros(D, device="cuda", dtype=torch.float64)
+        rm_c = torch.zeros(D, device="cuda")
+        for k in range(G):                                   # running mean group after group, raw vs centred inputs
+            rm_ref = (1 - mom) * rm_ref + mom * (y[k].double() @ W.double().T).mean(0)
+            rm_c = (1 - mom) * rm_c + mom * (want[k] @ W.float().T).mean(0)
+        N.call("shift_running_mean", W, cm, rm_c, D, K, G, mom)
+        torch.cuda.synchronize()
+        np.testing.assert_allclose(rm_c.cpu().numpy(), rm_ref.cpu().numpy(), rtol=2e-4, atol=1e-5)
+        # BatchNorm output and weight gradient are unchanged by the shift
+        a_raw, a_c = y[0].double() @ W.double().T, want[0].double() @ W.double().T
+        bn = lambda a: (a - a.mean(0)) / a.std(0, unbiased=False)
+        assert rel_l2(bn(a_c).cpu(), bn(a_raw).cpu()) < 1e-5
+        da = torch.randn(M, D, generator=g).cuda().double()
+        da = da - da.mean(0)                                 # a BatchNorm input gradient sums to zero over the batch
+        assert rel_l2((da.T @ want[0].double()).cpu(), (da.T @ y[0].double()).cpu()) < 1e-5
+
+
 def test_gemm_multi_per_problem_shapes(N):
     """audiossl_gemm_multi with per-problem N / K / leading dimensions (the first projector layer of the three Barlow heads:
     widths 2048 / 1024 / 512) in every transpose mode, plain and exclusive-accumulate outputs."""

@@ -228,7 +228,72 @@ def test_delores_m_b32_vs_oracle(cfg_m, prec):
               "encoder_q.encoder.features_1.0.weight", "encoder_q.fc.weight"):
         gp = dict(em.named_parameters())[n].grad.float().cpu()
         gr = dict(ref.named_parameters())[n].grad
-        assert rel_l2(gp, gr) < {"fp32": 2e-3, "bf16": 0.25, "bf16_hp": 0.16}[prec], n
+        assert rel_l2(gp, gr) < {"fp32": 2e-3, "bf16": 0.20, "bf16_hp": 0.16}[prec], n
+    if prec != "bf16":
+        return
+    # What "bf16" can mean for this model: the REFERENCE's own modules under torch.autocast(bfloat16) (bf16 matmul / conv
+    # operands, fp32 BatchNorm and loss - PyTorch's AMP recipe, the mode the original DeLoRes runs used) deviate from their
+    # fp32 gradients by 4-24 % per tensor: three train-mode BatchNorm backwards in a row amplify every 2^-9 operand rounding
+    # (tools/bf16_study.py: rounding the weights ALONE gives 4.8 % on the first projector layer).  Bar: EVERY gradient tensor
+    # of the HIP bf16 path is at least as close to the fp32 oracle as the autocast run of the oracle is (10 % slack).
+    amp = OM.DeloresMExpert(copy.deepcopy(cfg_m), num_negatives=K)
+    fill.fill_state_dict_(amp, seed=9)
+    for pq, pk in zip(amp.encoder_q.parameters(), amp.encoder_k.parameters()):
+        pk.data.copy_(pq.data)
+    amp.queue.copy_(closed_queue(128, K))
+    amp.train()
+    with torch.autocast("cpu", dtype=torch.bfloat16):
+        la = amp.training_loss(a, b, mq, mk)
+    la.backward()
+    ours, theirs = dict(em.named_parameters()), dict(amp.named_parameters())
+    worse = []
+    for n, pr in ref.named_parameters():
+        if pr.grad is None or (n.endswith(".0.bias") and "features" in n):
+            continue
+        e_hip = rel_l2(ours[n].grad.float().cpu(), pr.grad)
+        e_amp = rel_l2(theirs[n].grad, pr.grad)
+        if e_hip > 1.1 * e_amp + 5e-3:
+            worse.append((n, round(e_hip, 4), round(e_amp, 4)))
+    assert not worse, worse
+
+
+def test_delores_m_bf16_loss_trajectory_b256_follows_fp32_path(cfg_m):
+    """30 SGD steps at B = 256 (queue 4,096, changing batches, dropout from the device counter): the default bf16 path against
+    the oracle-verified fp32 HIP path.  Per-step gradient noise of bf16 operands (see the autocast comparison above) must
+    not bend the optimisation: every loss term stays within 1 % of the fp32 trajectory at every step, weights within 1 %."""
+    from src.encoder import AudioNTT2020Task6
+    from src.upstream.delores_m.upstream_expert import Upstream_Expert
+    B, T, K, steps = 256, 96, 4096, 30
+    base = [views(B, T, 9700 + i).cuda() for i in range(4)]
+    traj, weights = {}, {}
+    for prec in ("fp32", "bf16"):
+        em = Upstream_Expert(_cfg(cfg_m, prec), base_encoder=AudioNTT2020Task6, num_negatives=K)
+        fill.fill_state_dict_(em, seed=17)
+        for pq, pk in zip(em.encoder_q.parameters(), em.encoder_k.parameters()):
+            pk.data.copy_(pq.data)
+        em.queue.copy_(closed_queue(128, K))
+        em = em.cuda().train()
+        opt = em.configure_optimizers()
+        rows = []
+        for s in range(steps):
+            a = torch.roll(base[s % 4], shifts=s, dims=0) + 0.05 * base[(s + 1) % 4]
+            b = torch.roll(base[(s + 2) % 4], shifts=2 * s + 1, dims=0) + 0.05 * base[(s + 3) % 4]
+            parts = {}
+            em.fused_loss(a, b, True, parts)
+            opt.step()
+            rows.append(parts["losses"].cpu().numpy().copy())
+        torch.cuda.synchronize()
+        traj[prec] = np.stack(rows)
+        weights[prec] = {n: p.detach().float().cpu() for n, p in em.named_parameters()}
+        del em, opt
+        torch.cuda.empty_cache()
+    dev = np.abs(traj["bf16"] - traj["fp32"]) / np.abs(traj["fp32"])
+    print("max relative deviation per loss term [ce, b1, b2, b3]:", dev.max(0), "fp32 first/last:", traj["fp32"][0], traj["fp32"][-1])
+    assert np.isfinite(traj["bf16"]).all()
+    assert traj["fp32"][:, 0].max() > 5.0                              # the InfoNCE term moves: the queue fills with real keys
+    assert dev.max() < 1e-2, dev.max(0)                                # measured 1.6e-3 (ce) / 1.4e-3 (Barlow terms)
+    for n in weights["fp32"]:
+        assert rel_l2(weights["bf16"][n], weights["fp32"][n]) < 1e-2, n
 
 
 def test_delores_m_full_config_b512_k65536_bf16_vs_fp32_path(cfg_m):
