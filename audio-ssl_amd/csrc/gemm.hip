@@ -43,6 +43,13 @@ struct GemmArgs {
     unsigned a_bytes, b_bytes; // extents of A and B for the buffer descriptors (hardware bounds check)
     int vec_epi;              // every epilogue operand allows 8-column vectors (set by epi_vectorisable)
     int xcd_remap;            // grid is a multiple of 8 workgroups: contiguous tile runs per XCD (set by the launchers)
+    // row-softmax epilogues of the MoCo InfoNCE head (audiossl_moco_logits): the [B][K] logits never reach memory
+    int lse_mode;             // 1: part[row][col0/64] = (max, sum exp) of alpha*acc over the wave's 64 columns
+                              // 2: C (bf16) = exp(alpha*acc - lse[row]) * gscale
+    float* part;              // mode 1: [M][nslot][2] fp32
+    const float* lse;         // mode 2: [M]
+    float gscale;
+    int nslot;                // ceil(N / 64)
 };
 
 template <typename T> struct Mma;
@@ -188,9 +195,63 @@ __device__ __forceinline__ void epilogue_vec(const GemmArgs& g, f32x16 (&acc)[MI
     }
 }
 
+// Row-softmax epilogues (MoCo InfoNCE, `delores_m/upstream_expert.py:250-264`): logits = alpha * acc are reduced / transformed
+// in the tile and never stored.  Same parking of the accumulators as above; a lane owns 8 consecutive columns of one of 8 rows.
+template <int MI>
+__device__ __forceinline__ void epilogue_softmax(const GemmArgs& g, f32x16 (&acc)[MI][2], char* smem, int row0, int col0, int lane,
+                                                 int wave) {
+    __syncthreads();
+    float* ct = reinterpret_cast<float*>(smem) + wave * (32 * MI) * EPI_PITCH;
+    const int half = lane >> 5, l31 = lane & 31;
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                ct[(i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half) * EPI_PITCH + j * 32 + l31] = acc[i][j][r];
+    const int c8 = (lane & 7) * 8, rr = lane >> 3;
+    const int col = col0 + c8;
+    if (col0 >= g.N) return;                                   // the whole wave tile is outside (wave-uniform)
+#pragma unroll 2
+    for (int r0 = 0; r0 < 32 * MI; r0 += 8) {
+        const int rl = r0 + rr;
+        const long row = row0 + rl;
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = (col + u < g.N) ? g.alpha * ct[rl * EPI_PITCH + c8 + u] : -3.0e38f;
+        if (g.lse_mode == 1) {
+            float m = v[0];
+#pragma unroll
+            for (int u = 1; u < 8; ++u) m = fmaxf(m, v[u]);
+            float sm = 0.f;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) sm += __expf(v[u] - m);
+#pragma unroll
+            for (int o = 1; o < 8; o <<= 1) {                   // the 8 lanes of a row are consecutive
+                const float m2 = __shfl_xor(m, o, 64), s2 = __shfl_xor(sm, o, 64);
+                const float mm = fmaxf(m, m2);
+                sm = sm * __expf(m - mm) + s2 * __expf(m2 - mm);
+                m = mm;
+            }
+            if ((lane & 7) == 0 && row < g.M) {
+                float* o = g.part + (row * g.nslot + (col0 >> 6)) * 2;
+                o[0] = m; o[1] = sm;
+            }
+        } else if (row < g.M && col < g.N) {
+            const float l = g.lse[row];
+            Vec8<bf16> out;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) out.set(u, __expf(v[u] - l) * g.gscale);
+            out.store(static_cast<bf16*>(g.C) + row * g.ldc + col);
+        }
+    }
+}
+
 template <typename T, int MI>
 __device__ __forceinline__ void epilogue(const GemmArgs& g, f32x16 (&acc)[MI][2], char* smem, int row0, int col0, int lane, int wave) {
     if constexpr (sizeof(T) == 2) {
+        if (g.lse_mode) { epilogue_softmax<MI>(g, acc, smem, row0, col0, lane, wave); return; }
         if (g.vec_epi) { epilogue_vec<MI>(g, acc, smem, row0, col0, lane, wave); return; }
     }
     epilogue_lds<T, MI>(g, acc, smem, row0, col0, lane, wave);
@@ -785,30 +846,9 @@ extern "C" int audiossl_gemm_multi(int count, int trans_a, int trans_b, int M, c
 #undef MULTI
 }
 
-// dtype: 0 = fp32 operands (exact f32 MFMA), 1 = bf16 operands.  See include/audiossl_hip.h.
-extern "C" int audiossl_gemm(int dtype, int trans_a, int trans_b, int M, int N, int K, float alpha,
-                             const void* A, long lda, const void* B, long ldb, void* C, long ldc,
-                             const float* bias, int relu, const uint8_t* keep, long ldk, float keep_scale,
-                             const void* gate, long ldg, int out_f32, int atomic, int ksplit, const float* resid, long ldr,
-                             void* stream) {
-    ASSL_REQUIRE(A && B && C && M > 0 && N > 0 && K > 0 && ksplit >= 1);
-    ASSL_REQUIRE(dtype == 0 || dtype == 1);
-    ASSL_REQUIRE(atomic >= 0 && atomic <= 2);
-    ASSL_REQUIRE(!atomic || out_f32 || dtype == 0);
-    ASSL_REQUIRE(ksplit == 1 || atomic == 1);
-    ASSL_REQUIRE(!resid || (ksplit == 1 && !atomic));
-    // vector (8-element) dimension of each operand must be a multiple of 8 and its rows 16-byte aligned
-    ASSL_REQUIRE((trans_a ? M : K) % 8 == 0 && (trans_b ? N : K) % 8 == 0);
-    if (!ASSL_ALIGNED16(A) || !ASSL_ALIGNED16(B) || lda % 8 || ldb % 8) return ASSL_EALIGN;
-    const long esz = dtype == 0 ? 4 : 2;
-    const long a_ext = (trans_a ? ((long)(K - 1) * lda + M) : ((long)(M - 1) * lda + K)) * esz;
-    const long b_ext = (trans_b ? ((long)(K - 1) * ldb + N) : ((long)(N - 1) * ldb + K)) * esz;
-    ASSL_REQUIRE(a_ext < 0xFFFFFF00L && b_ext < 0xFFFFFF00L);            // 32-bit buffer offsets
-    GemmArgs g{A, B, C, M, N, K, lda, ldb, ldc, alpha, bias, relu, keep, ldk, keep_scale, gate, ldg,
-               (dtype == 0) ? 1 : out_f32, atomic, ksplit, resid, ldr, (unsigned)a_ext, (unsigned)b_ext, 0};
-    g.vec_epi = epi_vectorisable(g, dtype);
-    hipStream_t s = static_cast<hipStream_t>(stream);
-    if (dtype == 0) return dispatch<float, 32, 2>(g, trans_a, trans_b, s);
+// kernel choice for bf16 operands (measured rules, see the comments inside)
+static int run_bf16(const GemmArgs& g, int trans_a, int trans_b, hipStream_t s) {
+    const int M = g.M, N = g.N, K = g.K, ksplit = g.ksplit;
     const long blocks = (long)ceil_div(M, BM) * ceil_div(N, BN) * ksplit;
     // AUDIOSSL_GEMM_RING = 10 * MI + NST forces one ring variant (tools/gemm_shapes.py sweeps them); 0 disables the ring
     static const int ring = getenv("AUDIOSSL_GEMM_RING") ? atoi(getenv("AUDIOSSL_GEMM_RING")) : -1;
@@ -847,4 +887,49 @@ extern "C" int audiossl_gemm(int dtype, int trans_a, int trans_b, int M, int N, 
     // would occupy at most half of the 256 CUs, halve the tile in M and run twice as many workgroups
     if (small_tiles && blocks <= 128 && M > 64) return dispatch<bf16, 64, 1>(g, trans_a, trans_b, s);
     return blocks <= 256 && K >= 512 ? dispatch<bf16, 128, 2>(g, trans_a, trans_b, s) : dispatch<bf16, 64, 2>(g, trans_a, trans_b, s);
+}
+
+// dtype: 0 = fp32 operands (exact f32 MFMA), 1 = bf16 operands.  See include/audiossl_hip.h.
+extern "C" int audiossl_gemm(int dtype, int trans_a, int trans_b, int M, int N, int K, float alpha,
+                             const void* A, long lda, const void* B, long ldb, void* C, long ldc,
+                             const float* bias, int relu, const uint8_t* keep, long ldk, float keep_scale,
+                             const void* gate, long ldg, int out_f32, int atomic, int ksplit, const float* resid, long ldr,
+                             void* stream) {
+    ASSL_REQUIRE(A && B && C && M > 0 && N > 0 && K > 0 && ksplit >= 1);
+    ASSL_REQUIRE(dtype == 0 || dtype == 1);
+    ASSL_REQUIRE(atomic >= 0 && atomic <= 2);
+    ASSL_REQUIRE(!atomic || out_f32 || dtype == 0);
+    ASSL_REQUIRE(ksplit == 1 || atomic == 1);
+    ASSL_REQUIRE(!resid || (ksplit == 1 && !atomic));
+    // vector (8-element) dimension of each operand must be a multiple of 8 and its rows 16-byte aligned
+    ASSL_REQUIRE((trans_a ? M : K) % 8 == 0 && (trans_b ? N : K) % 8 == 0);
+    if (!ASSL_ALIGNED16(A) || !ASSL_ALIGNED16(B) || lda % 8 || ldb % 8) return ASSL_EALIGN;
+    const long esz = dtype == 0 ? 4 : 2;
+    const long a_ext = (trans_a ? ((long)(K - 1) * lda + M) : ((long)(M - 1) * lda + K)) * esz;
+    const long b_ext = (trans_b ? ((long)(K - 1) * ldb + N) : ((long)(N - 1) * ldb + K)) * esz;
+    ASSL_REQUIRE(a_ext < 0xFFFFFF00L && b_ext < 0xFFFFFF00L);            // 32-bit buffer offsets
+    GemmArgs g{A, B, C, M, N, K, lda, ldb, ldc, alpha, bias, relu, keep, ldk, keep_scale, gate, ldg,
+               (dtype == 0) ? 1 : out_f32, atomic, ksplit, resid, ldr, (unsigned)a_ext, (unsigned)b_ext, 0};
+    g.vec_epi = epi_vectorisable(g, dtype);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (dtype == 0) return dispatch<float, 32, 2>(g, trans_a, trans_b, s);
+    return run_bf16(g, trans_a, trans_b, s);
+}
+
+
+// MoCo InfoNCE logits  qn [B][dim] * queue [dim][K] / T  with the row soft-max folded into the GEMM epilogue
+// (`src/upstream/delores_m/upstream_expert.py:250-264`): mode 1 writes per-row (max, sum exp) partials of every 64-column
+// slab (merged by audiossl_moco_lse_merge), mode 2 recomputes the logits and stores P = exp(l - lse) * gscale in bf16, the
+// operand of the dq GEMM.  The [B][K] fp32 logits (134 MB at B = 512, K = 65,536) are never written.
+extern "C" int audiossl_moco_logits(int mode, const void* qn, const void* queue, int B, int K, int dim, float inv_t, float* part,
+                                    const float* lse, float gscale, void* P, void* stream) {
+    ASSL_REQUIRE(qn && queue && B > 0 && K > 0 && dim > 0 && (mode == 1 || mode == 2));
+    ASSL_REQUIRE(mode == 1 ? part != nullptr : (lse != nullptr && P != nullptr));
+    ASSL_REQUIRE(dim % 8 == 0 && K % 8 == 0);
+    if (!ASSL_ALIGNED16(qn) || !ASSL_ALIGNED16(queue) || (P && !ASSL_ALIGNED16(P))) return ASSL_EALIGN;
+    const long a_ext = ((long)(B - 1) * dim + dim) * 2, b_ext = ((long)(dim - 1) * K + K) * 2;
+    ASSL_REQUIRE(a_ext < 0xFFFFFF00L && b_ext < 0xFFFFFF00L);
+    GemmArgs g{qn, queue, P, B, K, dim, dim, K, K, inv_t, nullptr, 0, nullptr, 0, 1.f, nullptr, 0,
+               0, 0, 1, nullptr, 0, (unsigned)a_ext, (unsigned)b_ext, 0, 0, mode, part, lse, gscale, ceil_div(K, 64)};
+    return run_bf16(g, 0, 1, static_cast<hipStream_t>(stream));
 }

@@ -484,6 +484,31 @@ __global__ __launch_bounds__(256) void moco_ce_fwd_kernel(const float* __restric
     }
 }
 
+// Merge of the per-slab (max, sum exp) partials written by the logits GEMM's epilogue (audiossl_moco_logits mode 1) with the
+// positive logit: lse[b], loss += mean_b (lse_b - lpos_b), dlpos[b] = (softmax_pos - 1) * gscale.
+__global__ __launch_bounds__(256) void moco_lse_merge_kernel(const float* __restrict__ lpos, const float* __restrict__ part,
+                                                             int nslot, float inv_B, float gscale, float* __restrict__ lse,
+                                                             float* __restrict__ loss_out, float* __restrict__ dlpos) {
+    __shared__ float shm[4], shs[4];
+    const long b = blockIdx.x;
+    const float* row = part + b * nslot * 2;
+    float m = -3.0e38f, s = 0.f;
+    for (int k = threadIdx.x; k < nslot; k += 256) lse_merge(m, s, row[2 * k], row[2 * k + 1]);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) lse_merge(m, s, __shfl_xor(m, o, 64), __shfl_xor(s, o, 64));
+    if ((threadIdx.x & 63) == 0) { shm[threadIdx.x >> 6] = m; shs[threadIdx.x >> 6] = s; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < 4; ++w) lse_merge(m, s, shm[w], shs[w]);
+        const float lp = lpos[b];
+        lse_merge(m, s, lp, 1.f);
+        const float l = m + logf(s);
+        lse[b] = l;
+        atomicAdd(loss_out, (l - lp) * inv_B);
+        if (dlpos) dlpos[b] = (expf(lp - l) - 1.f) * gscale;
+    }
+}
+
 // P[b][k] = softmax_neg * gscale (T_), dlpos[b] = (softmax_pos - 1) * gscale;  gscale = 1/(B*temp)
 template <typename T_>
 __global__ __launch_bounds__(256) void moco_ce_bwd_kernel(const float* __restrict__ lpos, const float* __restrict__ lneg,
@@ -847,6 +872,14 @@ extern "C" int audiossl_rowdot(const float* a, const float* b, int B, int D, flo
 extern "C" int audiossl_moco_ce_fwd(const float* lpos, const float* lneg, int B, int K, float* lse, float* loss_out, void* stream) {
     ASSL_REQUIRE(lpos && lneg && lse && loss_out && B > 0 && K > 0);
     hipLaunchKernelGGL(moco_ce_fwd_kernel, dim3(B), dim3(256), 0, S_(stream), lpos, lneg, K, 1.f / (float)B, lse, loss_out);
+    ASSL_LAUNCH_CHECK();
+}
+
+extern "C" int audiossl_moco_lse_merge(const float* lpos, const float* part, int B, int nslot, float gscale, float* lse,
+                                       float* loss_out, float* dlpos, void* stream) {
+    ASSL_REQUIRE(lpos && part && lse && loss_out && B > 0 && nslot > 0);
+    hipLaunchKernelGGL(moco_lse_merge_kernel, dim3(B), dim3(256), 0, S_(stream), lpos, part, nslot, 1.f / (float)B, gscale, lse,
+                       loss_out, dlpos);
     ASSL_LAUNCH_CHECK();
 }
 

@@ -194,6 +194,14 @@ int audiossl_rowdot(const float* a, const float* b, int B, int D, float scale, f
 int audiossl_moco_ce_fwd(const float* lpos, const float* lneg, int B, int K, float* lse, float* loss_out, void* stream);
 int audiossl_moco_ce_bwd(int dtype, const float* lpos, const float* lneg, const float* lse, int B, int K, float gscale,
                          void* P, float* dlpos, void* stream);
+/* The same head without the [B][K] logits in memory (bf16 path): the logits GEMM qn [B][dim] x queue [dim][K] / T reduces
+ * its own tile - mode 1: part [B][ceil(K/64)][2] fp32 = (max, sum exp) per 64-column slab; moco_lse_merge folds them with
+ * lpos into lse / loss / dlpos; mode 2: P [B][K] bf16 = exp(logit - lse) * gscale, recomputed for the dq GEMM.
+ * Replaces `logits = cat([l_pos, l_neg]) / T; F.cross_entropy(logits, 0)` (delores_m/upstream_expert.py:250-264, 270). */
+int audiossl_moco_logits(int mode, const void* qn, const void* queue, int B, int K, int dim, float inv_t, float* part,
+                         const float* lse, float gscale, void* P, void* stream);
+int audiossl_moco_lse_merge(const float* lpos, const float* part, int B, int nslot, float gscale, float* lse,
+                            float* loss_out, float* dlpos, void* stream);
 int audiossl_l2norm_bwd(int dtype, const float* dqn, const float* dlpos, const float* kn32, const float* qn32,
                         const float* inv_norm, int B, int D, void* dq, void* stream);
 /* ptr_dev (optional, int64 on the device = the reference's `queue_ptr` buffer): when given, the write position is read

@@ -230,3 +230,33 @@ def test_vectorised_elementwise_kernels_match_scalar_definitions():
         torch.cuda.synchronize()
         np.testing.assert_allclose(P.float().cpu().numpy(), (torch.exp(lneg - lse[:, None]) * 0.25).cpu().numpy(), rtol=1e-2, atol=1e-6)
         np.testing.assert_allclose(dl.cpu().numpy(), ((torch.exp(lpos - lse) - 1) * 0.25).cpu().numpy(), rtol=1e-5, atol=1e-7)
+
+
+@pytest.mark.parametrize("B,K,dim", [(40, 1000, 128), (512, 65536, 128), (33, 136, 64), (130, 4096, 256)])
+def test_moco_fused_softmax_epilogue_vs_materialised_logits(B, K, dim):
+    """InfoNCE with the row soft-max folded into the logits GEMM (moco_logits mode 1 + moco_lse_merge, mode 2) against the
+    same quantities from logits written out in fp32 and torch's log-sum-exp in fp64 (`delores_m/upstream_expert.py:250-264`);
+    K = 65,536 is BASELINE config 2, the odd sizes end inside tiles and slabs."""
+    from src import _native as N
+    g = torch.Generator().manual_seed(B + K)
+    qn = torch.nn.functional.normalize(torch.randn(B, dim, generator=g), dim=1).cuda().bfloat16()
+    queue = torch.nn.functional.normalize(torch.randn(dim, K, generator=g), dim=0).cuda().bfloat16()
+    lpos = (torch.rand(B, generator=g) * 10.0).cuda()
+    T = 0.07
+    gscale = 1.0 / (B * T)
+    nslot = (K + 63) // 64
+    part = torch.full((B, nslot, 2), float("nan"), device="cuda")
+    lse, dlpos, loss = torch.empty(B, device="cuda"), torch.empty(B, device="cuda"), torch.zeros(1, device="cuda")
+    N.call("moco_logits", 1, qn, queue, B, K, dim, 1.0 / T, part, None, 0.0, None)
+    N.call("moco_lse_merge", lpos, part, B, nslot, gscale, lse, loss, dlpos)
+    P = torch.full((B, K), float("nan"), device="cuda", dtype=torch.bfloat16)
+    N.call("moco_logits", 2, qn, queue, B, K, dim, 1.0 / T, None, lse, gscale, P)
+    torch.cuda.synchronize()
+    logits = torch.cat([lpos.double()[:, None], qn.double() @ queue.double() / T], 1)
+    want_lse = torch.logsumexp(logits, 1)
+    assert float((lse.double() - want_lse).abs().max()) < 2e-5 * float(want_lse.abs().max())
+    assert abs(float(loss) - float((want_lse - lpos.double()).mean())) < 1e-5 * float(want_lse.abs().max())
+    sm = torch.softmax(logits, 1)
+    np.testing.assert_allclose(dlpos.cpu().numpy(), ((sm[:, 0] - 1.0) * gscale).cpu().numpy(), rtol=1e-4, atol=1e-7)
+    assert rel_l2(P.float().cpu(), (sm[:, 1:] * gscale).cpu()) < 4e-3          # one bf16 rounding
+    assert bool(torch.isfinite(P.float()).all())
