@@ -751,6 +751,301 @@ int dispatch_ring(const GemmArgs& g, int ta, int tb, hipStream_t s) {
     return launch_ring<true, false, MI, NST>(g, s);
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// 256 x 256 output tile, 8 waves (2 x 4, wave tile 128 x 64), K-tile 64, eight phases per pair of K-tiles: the
+// hand-scheduled main loop.  What bounded the kernels above was the loop SHAPE (one fat k-step: issue loads, read fragments,
+// MFMA, wait for everything, barrier): 31 % MFMA-busy on 6144 x 2048 x 2048, waves parked at s_waitcnt / the barrier.
+// Here
+//   * a K-tile is staged as FOUR 16 KB parts - A(r0), B(c0), B(c1), A(r1): the 64-row halves of every wave's 128 rows and
+//     the 32-column halves of every wave's 64 columns - by direct-to-LDS DMA, two 1 KB instructions per wave and part;
+//   * a phase = one quadrant (64 x 32 x K 64 = 8 MFMA 32x32x16) of every wave's tile; it issues ONE part of a later K-tile,
+//     reads only the fragments that are new for its quadrant (A(r0) + B(c0), then B(c1), then A(r1), then nothing), runs
+//     its MFMAs under s_setprio, waits with a COUNTED vmcnt that leaves five parts (80 KB) in flight, and meets the other
+//     waves at ONE raw s_barrier;
+//   * a part is re-staged no earlier than the phase after the barrier that followed its last fragment read (WAR), and is read
+//     no earlier than the phase after the barrier that followed the wait that retired it (RAW): with the issue order
+//     A(r0) B(c0) B(c1) A(r1) per K-tile and the consumption order the same, "everything but the five youngest parts has
+//     landed" is exactly what each phase needs, so the wait is the same vmcnt(10) in every steady-state phase.
+// Two buffers x four parts = 128 KB of LDS; accumulators 128 VGPRs + 64 of fragments.  Operand layouts as the ring kernel
+// (K-contiguous: [row][64 k] image, 16-byte chunk ^= (row >> 1) & 7; row-contiguous: [64 k][128 rows] image read with
+// ds_read_b64_tr_b16, 64-byte group ^= k & 3), the swizzle applied to the DMA's source address.  K % 64 == 0.
+template <bool TRANS, bool IS_A>
+struct PartOp {
+    static constexpr int NBLK = IS_A ? 2 : 1;                // 32-row fragment blocks of this wave inside a part
+    // DMA = buffer_load_dwordx4 ... lds: 32-bit per-lane byte offsets (two instructions per part), everything that is uniform -
+    // tile origin, K-tile, part - in the scalar offset; rows / columns past the matrix read zeros or other valid elements of the
+    // buffer (the descriptor bounds the access), their results are never stored
+    __amdgpu_buffer_rsrc_t rsrc;
+    int voff[2];
+    int kstride, part_delta, base_off;                       // bytes; wave-uniform
+    int foff[NBLK], fsw[NBLK];
+    __device__ __forceinline__ void init(const void* base_, unsigned bytes, long ld, int r0, int k0, int wave, int lane, int wsel) {
+        rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base_), 0, bytes, 0x00020000);
+        const int w0 = wsel * (IS_A ? 64 : 32);              // this wave's first part-row
+        // part-row p of part X <-> row of the 256-row tile: A: (p >> 6) * 128 + X * 64 + (p & 63); B: (p >> 5) * 64 + X * 32 + (p & 31)
+        if (!TRANS) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int p = wave * 16 + i * 8 + (lane >> 3);
+                const int sc = (lane & 7) ^ ((p >> 1) & 7);
+                const int row = IS_A ? (p >> 6) * 128 + (p & 63) : (p >> 5) * 64 + (p & 31);
+                voff[i] = (int)(((long)row * ld + sc * 8) * 2);
+            }
+            kstride = GBK * 2;
+            part_delta = (int)((IS_A ? 64 : 32) * ld * 2);
+            base_off = (int)(((long)r0 * ld + k0) * 2);
+#pragma unroll
+            for (int b = 0; b < NBLK; ++b) {
+                const int p = w0 + b * 32 + (lane & 31);
+                foff[b] = p * 128; fsw[b] = (p >> 1) & 7;
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int kl = wave * 8 + i * 4 + (lane >> 4), pc = lane & 15;
+                const int roff = ((((pc >> 2) ^ (kl & 3)) << 2) + (pc & 3)) * 8;
+                const int row = IS_A ? (roff >> 6) * 128 + (roff & 63) : (roff >> 5) * 64 + (roff & 31);
+                voff[i] = (int)(((long)kl * ld + row) * 2);
+            }
+            kstride = (int)(GBK * ld * 2);
+            part_delta = (IS_A ? 64 : 32) * 2;
+            base_off = (int)(((long)k0 * ld + r0) * 2);
+            const int q = (lane & 15) >> 2, pp = lane & 3, h4 = (lane >> 4) & 1, half = lane >> 5;
+#pragma unroll
+            for (int b = 0; b < NBLK; ++b) {
+                const int grp = ((w0 + b * 32) >> 5) ^ q;
+                foff[b] = (8 * half + q) * 256 + grp * 64 + 32 * h4 + 8 * pp; fsw[b] = 0;
+            }
+        }
+    }
+    __device__ __forceinline__ void issue(int part, int st, char* dst, bool live) const {
+        typedef __attribute__((address_space(3))) void* lptr_t;
+        const int so = live ? base_off + st * kstride + part * part_delta : 0x7FFFFF00;        // past the buffer: zeros, no traffic
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lptr_t)dst, 16, voff[0], so, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lptr_t)(dst + 1024), 16, voff[1], so, 0, 0);
+    }
+    __device__ __forceinline__ Vec8<bf16> frag(const char* img, int b, int kk, int half) const {
+        if (!TRANS) return Vec8<bf16>::load(reinterpret_cast<const bf16*>(img + foff[b] + (((kk * 2 + half) ^ fsw[b]) << 4)));
+        // The transposing reads go through inline asm: behind an LDS-DMA in flight hipcc waits vmcnt(0) before a
+        // ds_read_b64_tr_b16 BUILTIN (it treats the DMA as a store the read may alias), which drained the pipeline in every
+        // phase.  The caller's s_waitcnt lgkmcnt(0) + sched_barrier after the section's barrier covers these reads.
+        typedef __attribute__((address_space(3))) const char* lds_t;
+        const unsigned a = (unsigned)(size_t)(lds_t)(img + foff[b] + kk * 16 * 256);
+        bf16x4 lo, hi;
+        asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(lo) : "v"(a) : "memory");
+        asm volatile("ds_read_b64_tr_b16 %0, %1 offset:1024" : "=v"(hi) : "v"(a) : "memory");
+        Vec8<bf16> f;
+        f.v = bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        return f;
+    }
+};
+
+constexpr int P8_PART = 16384, P8_BUF = 4 * P8_PART;         // slot order inside a buffer: A(r0) B(c0) B(c1) A(r1)
+
+template <bool TA, bool TB, int DBG = 0>
+__device__ __forceinline__ void p8_body(const GemmArgs& g, char* smem) {
+    const int tiles_n = (g.N + 255) / 256;
+    const int nwg = gridDim.x, xcd = blockIdx.x & 7, q8 = nwg >> 3, r8 = nwg & 7;
+    const int wg = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (blockIdx.x >> 3);
+    if (wg >= tiles_n * ((g.M + 255) / 256)) return;         // multi-problem launches: the grid is sized for the widest problem
+    const int bm = (wg / tiles_n) * 256, bn = (wg % tiles_n) * 256;
+    const int ksteps = g.K / GBK;
+    const int per = (ksteps + g.ksplit - 1) / g.ksplit;
+    const int ks0 = blockIdx.z * per, ks1 = min(ksteps, ks0 + per);
+    if (ks0 >= ks1) return;
+    const int nk = ks1 - ks0;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, half = lane >> 5;
+    const int wr = wave >> 2, wc = wave & 3;
+
+    PartOp<TA, true> oa; PartOp<TB, false> ob;
+    oa.init(g.A, g.a_bytes, g.lda, bm, ks0 * GBK, wave, lane, wr);
+    ob.init(g.B, g.b_bytes, g.ldb, bn, ks0 * GBK, wave, lane, wc);
+    char* const wdst = smem + wave * 2048;                   // this wave's 2 KB slice of every part image
+
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    // slot: 0 A(r0), 1 B(c0), 2 B(c1), 3 A(r1).  A part of a K-tile past the end is still "issued" (branch-free, the counted
+    // waits stay uniform) but with a scalar offset past the buffer: the descriptor turns it into a no-traffic load of zeros
+    auto issue = [&](int slot, int t, int buf) {
+        char* d = wdst + buf * P8_BUF + slot * P8_PART;
+        const bool live = t < nk && !((DBG & 2) && t >= 2);
+        if (slot == 0) oa.issue(0, t, d, live); else if (slot == 3) oa.issue(1, t, d, live);
+        else ob.issue(slot - 1, t, d, live);
+    };
+    // A phase has two sections, each closed by a raw s_barrier: LOAD (issue one part, read this quadrant's new fragments, wait
+    // until everything but the five youngest parts has landed and the fragment reads have returned) and MFMA.  The two waves
+    // of a SIMD (wave rows wr = 0 / 1) run ONE SECTION APART - wr = 1 passes an extra barrier up front, wr = 0 one at the end -
+    // so while one of them issues MFMAs the other issues its DMA and LDS reads instead of both doing the same thing at once
+    // (in lockstep the MFMA pipe idled during every load section: 67.7 us on 6144 x 2048 x 2048 against 45 us of MFMA sections alone).
+    // RAW / WAR as above: a part read in phase p + 1 was retired by every wave's wait in its LOAD section of phase p, and the
+    // later of those sections is followed by a barrier before the earlier reader starts; a part is re-staged at least one phase
+    // after its last read, i.e. after a barrier that follows the later group's (completed: lgkmcnt(0)) reads.
+    auto load_end = [&]() {
+        wait_vm<8>();                                        // all but the four youngest parts have landed
+        __builtin_amdgcn_s_barrier();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this section's fragment reads (they returned while waiting at the barrier)
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    auto sync = [&]() {                                      // end of the MFMA section
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    Vec8<bf16> fa[2][4], fb0[4], fb1[4];
+    if (DBG & 4) {
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) { fa[0][kk] = Vec8<bf16>::zero(); fa[1][kk] = Vec8<bf16>::zero(); fb0[kk] = Vec8<bf16>::zero(); fb1[kk] = Vec8<bf16>::zero(); }
+    }
+    auto loadA = [&](const char* img) {
+        if ((DBG & 4) && nk > 0) return;
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) fa[b][kk] = oa.frag(img, b, kk, half);
+    };
+    auto loadB = [&](const char* img, Vec8<bf16> (&fb)[4]) {
+        if ((DBG & 4) && nk > 0) return;
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) fb[kk] = ob.frag(img, 0, kk, half);
+    };
+    auto quad = [&](int X, int Y, const Vec8<bf16> (&fb)[4]) {
+        if (DBG & 1) return;
+        if (!(DBG & 8)) __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+            for (int b = 0; b < 2; ++b) Mma<bf16>::run(acc[2 * X + b][Y], fa[b][kk], fb[kk]);
+        if (!(DBG & 8)) __builtin_amdgcn_s_setprio(0);
+    };
+
+    // Issue order = consumption order (per K-tile A(r0) B(c0) B(c1) A(r1)), one part per phase, each part re-staged TWO phases
+    // after its last fragment read (those reads are only known complete after the barrier that closes their LOAD section) and five
+    // to six phases before its first: "all but the four youngest parts landed" (vmcnt(8)) is what every phase needs.
+    // prologue: the first K-tile whole, two parts of the second
+    issue(0, 0, 0); issue(1, 0, 0); issue(2, 0, 0); issue(3, 0, 0);
+    issue(0, 1, 1); issue(1, 1, 1);
+    wait_vm<8>();
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    if (wr == 1) { __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); }      // the second wave of every SIMD: one section behind
+    const char* const E = smem;
+    const char* const O = smem + P8_BUF;
+    for (int t = 0; t < nk; t += 2) {
+        // ---- K-tile t (buffer E)
+        loadA(E); loadB(E + P8_PART, fb0);
+        issue(2, t + 1, 1);                                  // B(c1) of the odd tile of this pair
+        load_end();
+        quad(0, 0, fb0);
+        sync();
+        loadB(E + 2 * P8_PART, fb1);
+        issue(3, t + 1, 1);                                  // A(r1) of the odd tile
+        load_end();
+        quad(0, 1, fb1);
+        sync();
+        loadA(E + 3 * P8_PART);
+        issue(0, t + 2, 0);
+        load_end();
+        quad(1, 1, fb1);
+        sync();
+        issue(1, t + 2, 0);
+        load_end();
+        quad(1, 0, fb0);
+        sync();
+        // ---- K-tile t + 1 (buffer O); past the end its parts are zeros: the MFMAs add nothing
+        loadA(O); loadB(O + P8_PART, fb0);
+        issue(2, t + 2, 0);
+        load_end();
+        quad(0, 0, fb0);
+        sync();
+        loadB(O + 2 * P8_PART, fb1);
+        issue(3, t + 2, 0);
+        load_end();
+        quad(0, 1, fb1);
+        sync();
+        loadA(O + 3 * P8_PART);
+        issue(0, t + 3, 1);
+        load_end();
+        quad(1, 1, fb1);
+        sync();
+        issue(1, t + 3, 1);
+        load_end();
+        quad(1, 0, fb0);
+        sync();
+    }
+    if (wr == 0) { __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); }
+    wait_vm<0>();
+    epilogue<bf16, 2>(g, *reinterpret_cast<f32x16 (*)[2][2]>(&acc[0]), smem, bm + wr * 128, bn + wc * 64, lane, wave);
+    epilogue<bf16, 2>(g, *reinterpret_cast<f32x16 (*)[2][2]>(&acc[2]), smem, bm + wr * 128 + 64, bn + wc * 64, lane, wave);
+}
+
+template <bool TA, bool TB, int DBG = 0>
+__global__ __launch_bounds__(512) void gemm_p8_kernel(GemmArgs g) {
+    extern __shared__ __attribute__((aligned(1024))) char smem[];
+    p8_body<TA, TB, DBG>(g, smem);
+}
+
+template <bool TA, bool TB, int DBG = 0>
+int launch_p8(const GemmArgs& g, hipStream_t s) {
+    const size_t lds = max((size_t)2 * P8_BUF, EPI_LDS * 2);
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_p8_kernel<TA, TB, DBG>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)lds) != hipSuccess) return ASSL_ELAUNCH;
+        attr_set = true;
+    }
+    const int tiles = ceil_div(g.M, 256) * ceil_div(g.N, 256);
+    hipLaunchKernelGGL((gemm_p8_kernel<TA, TB, DBG>), dim3(tiles, 1, g.ksplit), dim3(512), lds, s, g);
+    ASSL_LAUNCH_CHECK();
+}
+template <bool TA, bool TB>
+__global__ __launch_bounds__(512) void gemm_p8_multi_kernel(GemmMulti gm) {
+    extern __shared__ __attribute__((aligned(1024))) char smem[];
+    p8_body<TA, TB, 0>(gm.p[blockIdx.y], smem);
+}
+template <bool TA, bool TB>
+int launch_p8_multi(const GemmMulti& gm, int count, int max_tiles, int ksplit, hipStream_t s) {
+    const size_t lds = max((size_t)2 * P8_BUF, EPI_LDS * 2);
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_p8_multi_kernel<TA, TB>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)lds) != hipSuccess) return ASSL_ELAUNCH;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((gemm_p8_multi_kernel<TA, TB>), dim3(max_tiles, count, ksplit), dim3(512), lds, s, gm);
+    ASSL_LAUNCH_CHECK();
+}
+int dispatch_p8_multi(const GemmMulti& gm, int count, int max_tiles, int ksplit, int ta, int tb, hipStream_t s) {
+    if (!ta && !tb) return launch_p8_multi<false, false>(gm, count, max_tiles, ksplit, s);
+    if (!ta && tb) return launch_p8_multi<false, true>(gm, count, max_tiles, ksplit, s);
+    if (ta && tb) return launch_p8_multi<true, true>(gm, count, max_tiles, ksplit, s);
+    return launch_p8_multi<true, false>(gm, count, max_tiles, ksplit, s);
+}
+
+int dispatch_p8(const GemmArgs& g, int ta, int tb, hipStream_t s) {
+    static const int dbg = getenv("AUDIOSSL_GEMM_P8_DBG") ? atoi(getenv("AUDIOSSL_GEMM_P8_DBG")) : 0;   // ablation (wrong results)
+    if (!ta && !tb && dbg) {
+        switch (dbg) {
+            case 1: return launch_p8<false, false, 1>(g, s);      // no MFMA
+            case 2: return launch_p8<false, false, 2>(g, s);      // no DMA after the first two K-tiles
+            case 4: return launch_p8<false, false, 4>(g, s);      // no fragment reads
+            case 6: return launch_p8<false, false, 6>(g, s);      // MFMA + barriers only
+            case 8: return launch_p8<false, false, 8>(g, s);      // no s_setprio
+            default: break;
+        }
+    }
+    if (!ta && !tb) return launch_p8<false, false>(g, s);
+    if (!ta && tb) return launch_p8<false, true>(g, s);
+    if (ta && tb) return launch_p8<true, true>(g, s);
+    return launch_p8<true, false>(g, s);
+}
+
 // BK = 32 with a register budget for THREE workgroups per CU (41 KB of LDS each; the epilogue runs on half-height tiles so
 // that it fits the same 41 KB); AUDIOSSL_GEMM_BK32=0 disables, =2 also uses it for transposed-A problems.
 template <bool TA, bool TB>
@@ -838,6 +1133,13 @@ extern "C" int audiossl_gemm_multi(int count, int trans_a, int trans_b, int M, c
         if (trans_a && trans_b) return launch_multi<bf16, true, true, BK_, MI_, NW_>(gm, count, TILES, ksplit, s);     \
         return launch_multi<bf16, true, false, BK_, MI_, NW_>(gm, count, TILES, ksplit, s);                            \
     } while (0)
+    static const int p8 = getenv("AUDIOSSL_GEMM_P8") ? atoi(getenv("AUDIOSSL_GEMM_P8")) : -1;
+    bool p8_ok = M >= 256 && N >= 256 && (!trans_a || M % 8 == 0);
+    for (int i = 0; i < count; ++i) p8_ok = p8_ok && K[i] % GBK == 0 && (!trans_b || Nv[i] % 8 == 0);
+    // multi-problem launches: measured wins for the transposed-A weight gradients of the three heads (2048 x 2048 x 1024:
+    // 50.9 -> 43.9 us, x 512: 31.3 -> 29.0 us); NT / NN at M = 1024 stay on the 128-row kernels (44.5 vs 46.7 us)
+    if (p8 != 0 && p8_ok && (p8 == 1 || (trans_a && (long)ceil_div(M, 256) * ceil_div(N, 256) * count * ksplit >= 128 && kmin >= 512)))
+        return dispatch_p8_multi(gm, count, ceil_div(M, 256) * ceil_div(N, 256), ksplit, trans_a, trans_b, s);
     static const int w8 = getenv("AUDIOSSL_GEMM_W8") ? atoi(getenv("AUDIOSSL_GEMM_W8")) : 0;
     if (w8 && M >= 256) MULTI(64, 2, 8, ceil_div(M, 256) * ceil_div(N, BN));
     if (small) MULTI(64, 1, 4, max_tiles);
@@ -855,6 +1157,23 @@ static int run_bf16(const GemmArgs& g, int trans_a, int trans_b, hipStream_t s) 
     const bool ring_ok = K % GBK == 0 && M >= 8 && N >= 8;
     static const int w8 = getenv("AUDIOSSL_GEMM_W8") ? atoi(getenv("AUDIOSSL_GEMM_W8")) : 0;
     if (w8 && M >= 256) return dispatch<bf16, 64, 2, 8>(g, trans_a, trans_b, s);
+    // the hand-scheduled 256 x 256 kernel: AUDIOSSL_GEMM_P8 = 1 forces it wherever it is legal, 0 disables it
+    static const int p8 = getenv("AUDIOSSL_GEMM_P8") ? atoi(getenv("AUDIOSSL_GEMM_P8")) : -1;
+    const bool p8_ok = K % GBK == 0 && M >= 8 && N >= 8 && (!trans_a || M % 8 == 0) && (!trans_b || N % 8 == 0);
+    if (p8 != 0 && p8_ok && M >= 256 && N >= 256) {
+        // measured (tools/gemm_shapes.py, gemm_one.py): it wins once the 256 x 256 tiles occupy at least half of the CUs and every
+        // workgroup walks >= 16 K-tiles (6144 x 2048 x 2048 NT 83.9 -> 63.0 us with the bias / ReLU / dropout epilogue, NN 71.0 ->
+        // 60.4; 4096^3 214 -> 127 us, 8192^3 1.30 PFLOP/s); with few K-tiles its one-workgroup-per-CU epilogue is exposed
+        // (6144 x 2048 x 512: 30.8 vs 27.2 us) and on small grids the 128-row kernels spread over more CUs.
+        const long t256 = (long)ceil_div(M, 256) * ceil_div(N, 256);
+        GemmArgs ga = g;
+        if (g.atomic == 1 && t256 * ksplit < 192) {                  // accumulating outputs: split K until the chip is full
+            int ks = ksplit;
+            while (t256 * ks * 2 <= 256 && K / (ks * 2) >= 1024) ks *= 2;
+            ga.ksplit = ks;
+        }
+        if (p8 == 1 || (t256 * ga.ksplit >= 128 && K / ga.ksplit >= 1024)) return dispatch_p8(ga, trans_a, trans_b, s);
+    }
     // grids of >= 2 workgroups per CU with a K-contiguous A operand: K-step 32 and THREE co-resident workgroups per CU (41 KB
     // of LDS each, 126 VGPRs) - 12 waves per CU hide the staged-load and barrier waits better than two workgroups at K-step
     // 64 (6144x2048x2048 NT 80.9 -> 71.5 us, NN 90.2 -> 76.8 us; with a transposed A operand it measured slower)

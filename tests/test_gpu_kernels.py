@@ -479,6 +479,10 @@ print("WORST", worst)
     ({"AUDIOSSL_GEMM_T256": "1"}, [("NT", 1100, 520, 128), ("NN", 1100, 520, 128), ("TN", 1096, 520, 128)]),
     ({"AUDIOSSL_GEMM_W8": "1"}, [("NT", 300, 264, 128), ("NN", 300, 264, 128), ("TN", 296, 264, 128)]),
     ({"AUDIOSSL_GEMM_BK32": "2"}, [("NT", 2048, 4096, 96), ("NN", 2048, 4096, 96), ("TN", 2048, 4096, 96)]),
+    # hand-scheduled 256 x 256 kernel: one K-tile, an odd and an even number of K-tiles, partial tiles in M and N
+    ({"AUDIOSSL_GEMM_P8": "1"}, [("NT", 1100, 520, 64), ("NT", 1100, 520, 192), ("NT", 700, 264, 512), ("NN", 1100, 520, 192),
+                                 ("NN", 700, 264, 512), ("TN", 1096, 520, 192), ("TN", 696, 264, 512), ("NT", 6144, 2048, 2048),
+                                 ("NN", 1024, 2048, 1024), ("TN", 2048, 520, 1024)]),
 ])
 def test_gemm_tile_variants_in_subprocess(env, shapes):
     """The tile variants that the default dispatch does not pick for these shapes (ring of every layout, 256x256 and 256x128
