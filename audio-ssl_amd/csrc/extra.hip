@@ -210,6 +210,46 @@ __global__ __launch_bounds__(256) void lars_update_kernel(float* __restrict__ p,
     }
 }
 
+// apex LARC (extras/decar-v2/main.py:111: LARC(SGD(momentum .9, wd), trust_coefficient, clip=False)) over the same segments:
+// per tensor, when |p| and |g| are both non-zero:  alr = tc |p| / (|g| + wd |p| + eps)  [clip: min(alr / lr, 1)],
+// g' = (g + wd p) alr;  otherwise g' = g (no decay: apex zeroes the group's weight_decay and re-applies it only in that
+// branch); then torch.optim.SGD with weight_decay 0: buf = m buf + g', p -= lr buf.
+__global__ __launch_bounds__(256) void larc_norms_kernel(const float* __restrict__ p, const float* __restrict__ g,
+                                                         const LarsSeg* __restrict__ seg, float gscale, double* __restrict__ norms) {
+    __shared__ double sh[16];
+    const LarsSeg s = seg[blockIdx.y];
+    double a = 0.0, b = 0.0;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < s.numel; i += (long long)gridDim.x * 256) {
+        const float pv = p[s.offset + i], gv = g[s.offset + i] * gscale;
+        a += (double)pv * pv;
+        b += (double)gv * gv;
+    }
+    a = block_sum(a, sh);
+    b = block_sum(b, sh);
+    if (threadIdx.x == 0 && (a != 0.0 || b != 0.0)) { atomicAdd(&norms[2 * blockIdx.y], a); atomicAdd(&norms[2 * blockIdx.y + 1], b); }
+}
+__global__ __launch_bounds__(256) void larc_update_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ mu,
+                                                          const LarsSeg* __restrict__ seg, const double* __restrict__ norms, float lr,
+                                                          float wd, float momentum, float tc, float eps, int clip, float gscale) {
+    const LarsSeg s = seg[blockIdx.y];
+    if (s.flags & 4) return;                                 // tensor without a gradient this step (frozen prototypes): untouched
+    const float pn = (float)sqrt(norms[2 * blockIdx.y]), gn = (float)sqrt(norms[2 * blockIdx.y + 1]);
+    float alr = 1.f, w = 0.f;
+    if (pn != 0.f && gn != 0.f) {
+        alr = tc * pn / (gn + pn * wd + eps);
+        if (clip) alr = fminf(alr / lr, 1.f);
+        w = wd;
+    }
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < s.numel; i += (long long)gridDim.x * 256) {
+        const long long o = s.offset + i;
+        const float pv = p[o];
+        const float dp = (g[o] * gscale + w * pv) * alr;
+        const float m = momentum * mu[o] + dp;
+        mu[o] = m;
+        p[o] = pv - lr * m;
+    }
+}
+
 }  // namespace
 
 #define S_(stream) static_cast<hipStream_t>(stream)
@@ -287,5 +327,19 @@ extern "C" int audiossl_lars_step(float* p, const float* g, float* mu, const voi
     hipLaunchKernelGGL(lars_norms_kernel, dim3(64, n_seg), dim3(256), 0, s, p, g, sg, weight_decay, grad_scale, norms);
     hipLaunchKernelGGL(lars_update_kernel, dim3(64, n_seg), dim3(256), 0, s, p, g, mu, sg, norms, lr, weight_decay, momentum, eta,
                        grad_scale);
+    ASSL_LAUNCH_CHECK();
+}
+
+// seg as for lars_step; flag bit 2 (value 4) marks a tensor that has no gradient this step.  mu must start at zero.
+extern "C" int audiossl_larc_step(float* p, const float* g, float* mu, const void* seg, int n_seg, float lr, float weight_decay,
+                                  float momentum, float trust_coefficient, float eps, int clip, float grad_scale, double* norms,
+                                  void* stream) {
+    ASSL_REQUIRE(p && g && mu && seg && norms && n_seg > 0);
+    hipStream_t s = S_(stream);
+    ASSL_ZERO_ALWAYS(norms, sizeof(double) * 2 * n_seg, s);
+    const LarsSeg* sg = static_cast<const LarsSeg*>(seg);
+    hipLaunchKernelGGL(larc_norms_kernel, dim3(64, n_seg), dim3(256), 0, s, p, g, sg, grad_scale, norms);
+    hipLaunchKernelGGL(larc_update_kernel, dim3(64, n_seg), dim3(256), 0, s, p, g, mu, sg, norms, lr, weight_decay, momentum,
+                       trust_coefficient, eps, clip, grad_scale);
     ASSL_LAUNCH_CHECK();
 }

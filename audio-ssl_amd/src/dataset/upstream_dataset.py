@@ -12,6 +12,8 @@ audio ingest is a "next" row of SURVEY 8f, not part of the parity-checked hot pa
 import numpy as np
 import pandas as pd
 import torch
+
+from src import _native as N
 import torch.nn.functional as F
 from torch.utils.data import DataLoader, Dataset
 
@@ -54,10 +56,19 @@ class UpstreamFrontEnd:
     def __call__(self, waves, plan=None):
         if not waves.is_cuda:
             waves = waves.cuda(non_blocking=True)
+        return self.tfms.augment_batch(self.log_mel(waves), plan=plan)
+
+    @torch.no_grad()
+    def log_mel(self, waves):
+        """[B, L] device waveforms -> [B, 1, n_mels, T] log-mel; `normalization: l2` first scales every clip to unit L2 norm
+        (`F.normalize(waveform, dim=-1, p=2)`, src/dataset/upstream_dataset.py:61-62 of the reference) - one wave per clip."""
         if self.l2:
-            waves = F.normalize(waves, dim=-1, p=2)
-        lms = extract_log_mel_spectrogram(waves, self.to_mel_spec)
-        return self.tfms.augment_batch(lms, plan=plan)
+            waves = waves.float().contiguous()
+            out = torch.empty_like(waves)
+            inv = torch.empty(waves.shape[0], dtype=torch.float32, device=waves.device)
+            N.call("l2norm_fwd", N.F32, waves, waves.shape[0], waves.shape[1], out, out, inv)
+            waves = out
+        return extract_log_mel_spectrogram(waves, self.to_mel_spec)
 
     # ---- one-batch-ahead pipelining: the front end of batch i+1 (log-mel, running norm, mixup, crops: ~0.4 ms of small
     #      launches, the running-norm scan being a one-workgroup recurrence) runs on its own stream underneath the training
@@ -170,6 +181,29 @@ class BaselineDataModule:
     def train_dataloader(self, sampler=None):
         unit = self.train_dataset.unit_length
         collate = WindowCollate(self.transformation, unit, self.config["pretrain"]["input"]["n_mels"])
-        # planning is stateful (one sequential stream): it runs in the main process, decoding may use workers
-        return DataLoader(self.train_dataset, shuffle=sampler is None, sampler=sampler, batch_size=self.batch_size,
-                          num_workers=0, drop_last=True, pin_memory=True, collate_fn=collate)
+        # decoding / resampling runs in `run.num_dataloader_workers` worker processes (they return the raw clips of a batch);
+        # cropping + augmentation planning is stateful (ONE sequential random stream, as a reference run with num_workers=0
+        # consumes it) and stays in the main process, applied to each batch as it arrives
+        loader = DataLoader(self.train_dataset, shuffle=sampler is None, sampler=sampler, batch_size=self.batch_size,
+                            num_workers=int(self.num_workers or 0), drop_last=True, collate_fn=_identity_collate,
+                            persistent_workers=bool(self.num_workers))
+        return _CollatedLoader(loader, collate)
+
+
+def _identity_collate(items):
+    return items
+
+
+class _CollatedLoader:
+    """Iterates a DataLoader of raw clip lists and applies the (stateful, main-process) window / plan collate to each batch."""
+
+    def __init__(self, loader, collate):
+        self.loader, self.collate = loader, collate
+
+    def __len__(self):
+        return len(self.loader)
+
+    def __iter__(self):
+        for items in self.loader:
+            waves, plan = self.collate(items)
+            yield waves.pin_memory() if torch.cuda.is_available() else waves, plan

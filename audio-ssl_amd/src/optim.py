@@ -124,6 +124,95 @@ class HipLARS(torch.optim.Optimizer):
                 p.grad = None
 
 
+class HipLARC(torch.optim.Optimizer):
+    """apex `LARC(torch.optim.SGD(params, lr, momentum=0.9, weight_decay=wd), trust_coefficient=0.001, clip=False)` -
+    the optimiser of `extras/decar-v2/main.py:92-97, 111` - on flat parameter groups: two launches per group (per-tensor
+    norms, fused adaptive-rate / decay / momentum / update).  `skip` = indices of tensors without a gradient this step (the
+    reference sets `p.grad = None` for the prototypes while they are frozen: neither LARC nor SGD touches them)."""
+
+    def __init__(self, flat_groups, params, lr, momentum=0.9, weight_decay=0.0, trust_coefficient=0.001, eps=1e-8, clip=False):
+        super().__init__(params, dict(lr=lr, momentum=momentum, weight_decay=weight_decay, trust_coefficient=trust_coefficient,
+                                      eps=eps, clip=clip))
+        self.flat_groups = list(flat_groups)
+        self.grad_scale = 1.0
+        self._tables = {}
+        self.steps = 0
+
+    def _table(self, fg, skip):
+        import numpy as np
+        key = (id(fg), tuple(sorted(skip)))
+        if key not in self._tables:
+            seg = np.zeros(len(fg.params), dtype=[("off", "<i8"), ("n", "<i8"), ("flags", "<i4"), ("pad", "<i4")])
+            for i, (p, o) in enumerate(zip(fg.params, fg.offsets)):
+                seg[i] = (o, p.numel(), 4 if i in skip else 0, 0)
+            dev = fg.data.device
+            self._tables[key] = (torch.from_numpy(seg.view(np.uint8)).to(dev),
+                                 torch.empty(2 * len(fg.params), dtype=torch.float64, device=dev))
+        return self._tables[key]
+
+    @torch.no_grad()
+    def step(self, closure=None, skip=()):
+        g0 = self.param_groups[0]
+        for fg in self.flat_groups:
+            if fg.momentum is None:
+                fg.momentum = torch.zeros_like(fg.data)
+            seg, norms = self._table(fg, set(skip))
+            N.call("larc_step", fg.data, fg.grad, fg.momentum, seg, len(fg.params), float(g0["lr"]), float(g0["weight_decay"]),
+                   float(g0["momentum"]), float(g0["trust_coefficient"]), float(g0["eps"]), int(bool(g0["clip"])),
+                   float(self.grad_scale), norms)
+        self.steps += 1
+
+    def zero_grad(self, set_to_none=True):
+        for fg in self.flat_groups:
+            for p in fg.params:
+                p.grad = None
+
+
+# ---- learning-rate schedules of the extras trainers ------------------------------------------------------------------------
+def lars_adjust_learning_rate(optimizer, step, epochs, steps_per_epoch, batch_size):
+    """`adjust_learning_rate` of `extras/delores-s/multi_proc.py:45-57` (the reference forgets to import math): linear warm-up
+    over 10 epochs to batch_size / 256, cosine to 0.1 % of it; weights get 0.2 x, biases 0.0048 x.  -> (lr_weights, lr_biases),
+    also applied to a HipLARS optimiser."""
+    import math
+    max_steps = epochs * steps_per_epoch
+    warmup_steps = 10 * steps_per_epoch
+    base_lr = batch_size / 256
+    if step < warmup_steps:
+        lr = base_lr * step / warmup_steps
+    else:
+        s, m = step - warmup_steps, max_steps - warmup_steps
+        q = 0.5 * (1 + math.cos(math.pi * s / m))
+        lr = base_lr * q + base_lr * 0.001 * (1 - q)
+    if optimizer is not None:
+        if hasattr(optimizer, "set_lr"):
+            optimizer.set_lr(lr * 0.2, lr * 0.0048)
+        else:
+            optimizer.param_groups[0]["lr"] = lr * 0.2
+            if len(optimizer.param_groups) > 1:
+                optimizer.param_groups[1]["lr"] = lr * 0.0048
+    return lr * 0.2, lr * 0.0048
+
+
+def cosine_scheduler(base_value, final_value, epochs, niter_per_ep, warmup_epochs=0, start_warmup_value=0):
+    """`extras/decar-v2/multi_proc.py:61-72`: per-iteration values, linear warm-up then half a cosine."""
+    import numpy as np
+    warmup_iters = warmup_epochs * niter_per_ep
+    warmup = np.linspace(start_warmup_value, base_value, warmup_iters) if warmup_epochs > 0 else np.array([])
+    iters = np.arange(epochs * niter_per_ep - warmup_iters)
+    schedule = np.concatenate((warmup, final_value + 0.5 * (base_value - final_value) * (1 + np.cos(np.pi * iters / len(iters)))))
+    assert len(schedule) == epochs * niter_per_ep
+    return schedule
+
+
+def dcv2_lr_schedule(base_lr, final_lr, epochs, niter_per_ep, warmup_epochs=10):
+    """The schedule `extras/decar-v2/main.py:118-122` builds: linear 0 -> base_lr over 10 epochs, cosine to final_lr."""
+    import numpy as np
+    warm = np.linspace(0, base_lr, niter_per_ep * warmup_epochs)
+    t = np.arange(niter_per_ep * (epochs - warmup_epochs))
+    cos = final_lr + 0.5 * (base_lr - final_lr) * (1 + np.cos(np.pi * t / (niter_per_ep * (epochs - warmup_epochs))))
+    return np.concatenate((warm, cos))
+
+
 class HipAdamW(torch.optim.Optimizer):
     """torch.optim.AdamW (`extras/mast_new/mast/moco_model.py:373-379`) as one launch per flat parameter group.  The step
     count lives in device memory and is advanced by a device op, so the optimiser step can sit inside a captured hipGraph."""

@@ -45,7 +45,9 @@ class AudioNTT2020(nn.Module):
         self.projection_head = nn.Sequential(nn.Linear(d, 2048), nn.BatchNorm1d(2048), nn.ReLU(inplace=True),
                                              nn.Linear(2048, out_dim))
         if isinstance(args.nmb_prototypes, list):
-            self.prototypes = MultiPrototypes(out_dim, [1024])
+            # the reference hard-codes one head of 1,024 prototypes here whatever the list says; `prototype_sizes` (not in
+            # the reference) lets small test banks use fewer
+            self.prototypes = MultiPrototypes(out_dim, list(getattr(args, "prototype_sizes", None) or [1024]))
         elif args.nmb_prototypes > 0:
             self.prototypes = nn.Linear(out_dim, 1024, bias=False)
         self.precision = default_precision()

@@ -72,17 +72,24 @@ def train_step(state, idx, inputs, assignments, start_idx, nmb_crops=(1,), crops
         loss = loss + prototype_cross_entropy(output[h], targets)           # the reference divides the scores by 1.0
     loss = loss / len(output)
     loss.backward()
-    frozen = []
-    if state.iteration < freeze_prototypes_niters:    # "cancel some gradients": the reference sets p.grad = None, so the
-        for i, n in enumerate(flat.names):            # optimiser skips these tensors entirely (no decay, no momentum)
-            if "prototypes" in n:
-                frozen.append((i, flat.params[i].data.clone()))
-    state.optimizer.step()
-    for i, saved in frozen:
-        p, o = flat.params[i], flat.offsets[i]
-        p.data.copy_(saved)
-        if flat.momentum is not None:
-            flat.momentum[o:o + p.numel()].zero_()
+    # data parallel (`nn.parallel.DistributedDataParallel`, main.py:84): ONE all-reduce of the flat gradient over RCCL; the
+    # 1/world of DDP's averaging is folded into the optimiser launch
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        dist.all_reduce(flat.grad)
+        state.optimizer.grad_scale = 1.0 / dist.get_world_size()
+    # "cancel some gradients": the reference sets p.grad = None for the prototypes, so neither LARC nor SGD touches them
+    skip = [i for i, n in enumerate(flat.names) if "prototypes" in n] if state.iteration < freeze_prototypes_niters else []
+    if hasattr(state.optimizer, "step") and "skip" in state.optimizer.step.__code__.co_varnames:
+        state.optimizer.step(skip=skip)
+    else:
+        frozen = [(i, flat.params[i].data.clone()) for i in skip]
+        state.optimizer.step()
+        for i, saved in frozen:
+            p, o = flat.params[i], flat.offsets[i]
+            p.data.copy_(saved)
+            if flat.momentum is not None:
+                flat.momentum[o:o + p.numel()].zero_()
     state.local_memory_index[start_idx:start_idx + bs] = idx.to(emb.device)
     for i, crop_idx in enumerate(crops_for_assign):
         state.local_memory_embeddings[i][start_idx:start_idx + bs] = emb[crop_idx * bs:(crop_idx + 1) * bs].float()

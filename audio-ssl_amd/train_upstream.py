@@ -67,11 +67,17 @@ class HipTrainer:
         if self.world > 1:
             sampler = torch.utils.data.distributed.DistributedSampler(dm.train_dataset, self.world, self.rank, shuffle=True)
         loader = dm.train_dataloader(sampler=sampler)
-        opt = model.configure_optimizers()
+        opt = self.optimizer = model.configure_optimizers()
         if self.resume:
             ck = torch.load(self.resume, map_location=dev, weights_only=True)
             model.load_state_dict(ck["state_dict"], strict=False)
             self.epoch, self.global_step = ck.get("epoch", 0), ck.get("global_step", 0)
+            # Lightning's resume_from_checkpoint restores the optimiser too (SGD momentum lives in FlatGroup.momentum here)
+            states = ck.get("optimizer_states")
+            if states and hasattr(opt, "load_state_dict"):
+                if hasattr(model, "ensure_flat"):
+                    model.ensure_flat()
+                opt.load_state_dict(states[0])
         best = float("inf")
         # one rank: the step is a single hipGraph replay; data-parallel: one graph per collective-free phase
         gstep = None
@@ -115,7 +121,7 @@ class HipTrainer:
                 self.save_checkpoint(os.path.join(self.save_dir, f"epoch={epoch}.ckpt"), model)
             if self.max_steps and self.global_step >= self.max_steps:
                 break
-        self.model = model
+        self.model, self.optimizer = model, opt
         return model
 
     def save_checkpoint(self, path, model=None):
@@ -127,6 +133,9 @@ class HipTrainer:
         ck["hyper_parameters"] = {k: v for k, v in ck["hyper_parameters"].items()}
         ck["hyper_parameters"]["config"] = model.config
         ck["hyper_parameters"]["base_encoder"] = model.config["pretrain"]["base_encoder"]["type"]
+        opt = getattr(self, "optimizer", None)
+        if opt is not None and hasattr(opt, "state_dict"):
+            ck["optimizer_states"] = [opt.state_dict()]          # Lightning's key; a list with one entry per optimiser
         torch.save(ck, path)
 
 

@@ -296,6 +296,13 @@ int audiossl_adamw(float* p, const float* g, float* m, float* v, long n, float l
  * lr: per-segment learning rate (device); norms: 2*n_seg doubles of scratch. */
 int audiossl_lars_step(float* p, const float* g, float* mu, const void* seg, int n_seg, const float* lr, float weight_decay,
                        float momentum, float eta, float grad_scale, double* norms, void* stream);
+/* apex LARC around torch.optim.SGD (`extras/decar-v2/main.py:92-97, 111`: SGD(momentum 0.9, wd 1e-6) wrapped in
+ * LARC(trust_coefficient 0.001, clip False)): per tensor alr = tc |p| / (|g| + wd |p| + eps) when both norms are non-zero,
+ * g' = (g + wd p) alr, else g' = g; then buf = m buf + g', p -= lr buf.  seg as lars_step; flags & 4 = no gradient this step
+ * (the reference sets p.grad = None for frozen prototypes: the tensor and its momentum are left untouched). */
+int audiossl_larc_step(float* p, const float* g, float* mu, const void* seg, int n_seg, float lr, float weight_decay,
+                       float momentum, float trust_coefficient, float eps, int clip, float grad_scale, double* norms,
+                       void* stream);
 
 #ifdef __cplusplus
 }

@@ -420,6 +420,53 @@ def lars_lr(step, epochs, steps_per_epoch, batch_size):
     return lr * 0.2, lr * 0.0048
 
 
+@torch.no_grad()
+def larc_sgd_step(params, bufs, lr, weight_decay=1e-6, momentum=0.9, trust_coefficient=0.001, eps=1e-8, clip=False):
+    """apex.parallel.LARC.step around torch.optim.SGD, as `extras/decar-v2/main.py:92-97, 111` builds it.  apex is a third-party
+    dependency that is not in the reference tree or this image: restated from its published LARC.py (parity unpinned) -
+    per parameter with a gradient: if |p| != 0 and |g| != 0: alr = tc |p| / (|g| + |p| wd + eps) [clip: min(alr / lr, 1)],
+    g <- (g + wd p) alr; then SGD(momentum, weight_decay = 0)."""
+    for p in params:
+        if p.grad is None:
+            continue
+        g = p.grad
+        pn, gn = torch.norm(p), torch.norm(g)
+        if pn != 0 and gn != 0:
+            alr = trust_coefficient * pn / (gn + pn * weight_decay + eps)
+            if clip:
+                alr = min(alr / lr, 1)
+            g = (g + weight_decay * p) * alr
+        key = id(p)
+        if key not in bufs:
+            bufs[key] = g.clone()
+        else:
+            bufs[key].mul_(momentum).add_(g)
+        p.add_(bufs[key], alpha=-lr)
+
+
+def cosine_scheduler(base_value, final_value, epochs, niter_per_ep, warmup_epochs=0, start_warmup_value=0):
+    """`extras/decar-v2/multi_proc.py:61-72`."""
+    import numpy as np
+    warmup_schedule = np.array([])
+    warmup_iters = warmup_epochs * niter_per_ep
+    if warmup_epochs > 0:
+        warmup_schedule = np.linspace(start_warmup_value, base_value, warmup_iters)
+    iters = np.arange(epochs * niter_per_ep - warmup_iters)
+    schedule = final_value + 0.5 * (base_value - final_value) * (1 + np.cos(np.pi * iters / len(iters)))
+    schedule = np.concatenate((warmup_schedule, schedule))
+    assert len(schedule) == epochs * niter_per_ep
+    return schedule
+
+
+def dcv2_lr_schedule(base_lr, final_lr, epochs, niter_per_ep):
+    """`extras/decar-v2/main.py:118-122`: 10 warm-up epochs (linear from 0) then cosine to final_lr."""
+    import numpy as np
+    warm = np.linspace(0, base_lr, niter_per_ep * 10)
+    iters = np.arange(niter_per_ep * (epochs - 10))
+    cos = np.array([final_lr + 0.5 * (base_lr - final_lr) * (1 + math.cos(math.pi * t / (niter_per_ep * (epochs - 10)))) for t in iters])
+    return np.concatenate((warm, cos))
+
+
 def train_steps(expert, batches, masks=None):
     """Run fwd/bwd/SGD over a list of (img_1, img_2); returns per-step losses."""
     bufs, losses = {}, []

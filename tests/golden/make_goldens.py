@@ -395,6 +395,28 @@ def g10_lars(MP):
     save("lars", p0=t2n(ps[0]), p1=t2n(ps[1]), p2=t2n(ps[2]))
 
 
+def g13_schedules(MP):
+    """LR schedules of the extras trainers, from the reference's own functions: `adjust_learning_rate`
+    (extras/delores-s/multi_proc.py:45-57; it uses `math` without importing it - the name is supplied here) and
+    `cosine_scheduler` (extras/decar-v2/multi_proc.py:61-72)."""
+    import math
+    import types
+    MP.math = math
+    steps_per_epoch, epochs, bs = 7, 30, 512
+    opt = types.SimpleNamespace(param_groups=[{"lr": 0.0}, {"lr": 0.0}])
+    args = types.SimpleNamespace(epochs=epochs, batch_size=bs)
+    loader = [None] * steps_per_epoch
+    lw, lb = [], []
+    for step in range(epochs * steps_per_epoch):
+        MP.adjust_learning_rate(args, opt, loader, step)
+        lw.append(opt.param_groups[0]["lr"])
+        lb.append(opt.param_groups[1]["lr"])
+    MP2 = _load_by_path("ref_multiproc_dc", os.path.join(REF, "extras/decar-v2/multi_proc.py"))
+    cs = MP2.cosine_scheduler(4.8, 0.0048, 25, 9, warmup_epochs=10, start_warmup_value=0.3)
+    cs0 = MP2.cosine_scheduler(1.0, 0.1, 6, 5)
+    save("schedules", lars_lr_weights=np.array(lw), lars_lr_biases=np.array(lb), cosine_warm=cs, cosine_plain=cs0)
+
+
 CFG_SL = {"pretrain": dict(CFG_S["pretrain"], instance_contrastive_dim=128, cluster_contrastive_dim=128)}
 
 
@@ -504,6 +526,9 @@ def main():
     if len(sys.argv) > 1 and sys.argv[1] == "decar":
         g12_decar(ENC)
         return
+    if len(sys.argv) > 1 and sys.argv[1] == "schedules":
+        g13_schedules(MP)
+        return
     g1_window(U)
     g2_runnorm(A)
     g3_aug(A_pkg)
@@ -516,6 +541,7 @@ def main():
     g7_g9_steps(XS, XM, ENC)
     g11_slicer(CL, ENC)
     g12_decar(ENC)
+    g13_schedules(MP)
 
 
 if __name__ == "__main__":

@@ -111,3 +111,53 @@ def test_two_rank_graph_phases_match_eager(which):
     if which == "delores_m":
         assert g0["ptr"] == e0["ptr"]
         assert rel_l2(torch.from_numpy(g0["queue"]), torch.from_numpy(e0["queue"])) < 2e-2
+
+
+def _worker_decar(rank, world, port, ret):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import random
+        from oracle import fill
+        from src.augmentations import AugmentationModule
+        from src.dataset import UpstreamFrontEnd
+        from src.upstream.decar_v2 import main as DC
+        cfg = copy.deepcopy(CFG_S)
+        cfg["pretrain"]["input"]["length_wave"] = 0.95
+        n_items, K = 128, 16
+        np.random.seed(31 + rank)
+        random.seed(31 + rank)
+        tf = AugmentationModule(cfg, n_items, max_batch=16)
+        front = UpstreamFrontEnd(cfg, tf)
+        args = DC.default_args(epochs=1, batch_size=32, nmb_prototypes=[K], prototype_sizes=[K], nmb_kmeans_iters=3, d=2048,
+                               base_lr=0.3, apply_lr_schedule=True)
+        wave = lambda i: torch.from_numpy(fill.uniform((15200,), 700 + i, -0.3, 0.3) +
+                                          0.2 * np.sin(2 * np.pi * (150 + 25 * i) * np.arange(15200) / 16000).astype(np.float32))
+        state, hist = DC.run(args, n_items, wave, front, max_iters=3, log=lambda *_: None)
+        torch.cuda.synchronize()
+        ret[rank] = {"losses": [l for _, l in hist], "w": {n: p.detach().float().cpu().numpy() for n, p in state.model.named_parameters()},
+                     "lr": state.optimizer.param_groups[0]["lr"], "bank": int((state.local_memory_index >= 0).sum()),
+                     "shard": state.local_memory_index.cpu().numpy()}
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_deepcluster_v2_harness_keeps_replicas_identical():
+    """BASELINE config 3 plumbing at world size 2 (`extras/decar-v2/main.py:57-292`): contiguous shards, distributed k-means
+    (centroids broadcast, counts / sums all-reduced), prototype cross-entropy, ONE flat-gradient all-reduce, LARC, the
+    warm-up learning-rate schedule - the two replicas end bit-identical, local losses differ, prototypes stay the centroids."""
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker_decar, args=(2, port, ret), nprocs=2, join=True)
+    r0, r1 = ret[0], ret[1]
+    assert len(r0["losses"]) == 3 and all(np.isfinite(r0["losses"])) and all(np.isfinite(r1["losses"]))
+    assert r0["losses"] != r1["losses"]
+    for n in r0["w"]:
+        np.testing.assert_array_equal(r0["w"][n], r1["w"][n], err_msg=n)
+    assert r0["shard"].tolist()[:48] == list(range(48)) and r1["shard"].tolist()[:48] == list(range(64, 112))   # 3 x 16 clips each
+    assert 0 < r0["lr"] < 0.3                                       # warm-up value of iteration 2, not base_lr
+    np.testing.assert_allclose(np.linalg.norm(r0["w"]["prototypes.prototypes0.weight"], axis=1), 1.0, rtol=1e-4)

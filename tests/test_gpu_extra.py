@@ -260,3 +260,30 @@ def test_moco_fused_softmax_epilogue_vs_materialised_logits(B, K, dim):
     np.testing.assert_allclose(dlpos.cpu().numpy(), ((sm[:, 0] - 1.0) * gscale).cpu().numpy(), rtol=1e-4, atol=1e-7)
     assert rel_l2(P.float().cpu(), (sm[:, 1:] * gscale).cpu()) < 4e-3          # one bf16 rounding
     assert bool(torch.isfinite(P.float()).all())
+
+
+def test_larc_sgd_vs_oracle():
+    """HipLARC (apex LARC(clip=False) around SGD, extras/decar-v2/main.py:92-97, 111) on a flat group: 4 steps against the
+    oracle's restatement of apex's published algorithm (apex itself is absent: parity unpinned), incl. a zero-gradient tensor
+    (no adaptive rate, no decay), a tensor skipped as "no gradient" (frozen prototypes) and the clip=True form."""
+    from src.flat import FlatGroup
+    from src.optim import HipLARC
+    shapes = [(16, 8), (16,), (4, 4, 3, 3), (8, 8), (5,)]
+    for clip in (False, True):
+        ref = [torch.nn.Parameter(torch.from_numpy(fill.uniform(s, 9300 + i))) for i, s in enumerate(shapes)]
+        ps = [torch.nn.Parameter(p.detach().clone().cuda()) for p in ref]
+        fg = FlatGroup([(f"p{i}", p) for i, p in enumerate(ps)])
+        opt = HipLARC([fg], ps, lr=0.6, momentum=0.9, weight_decay=1e-3, trust_coefficient=0.02, clip=clip)
+        bufs = {}
+        for s in range(4):
+            fg.zero_grad()
+            for i, p in enumerate(ref):
+                g = torch.from_numpy(fill.uniform(tuple(p.shape), 9400 + 10 * s + i))
+                if i == 3:
+                    g = torch.zeros_like(g)                      # |g| = 0: plain SGD on a zero gradient
+                p.grad = None if i == 4 else g                   # tensor 4: no gradient at all
+                fg.grad_view(i).copy_(g)
+            opt.step(skip=(4,))
+            OM.larc_sgd_step(ref, bufs, 0.6, weight_decay=1e-3, momentum=0.9, trust_coefficient=0.02, clip=clip)
+        for i, (p, r) in enumerate(zip(ps, ref)):
+            np.testing.assert_allclose(p.detach().cpu().numpy(), r.detach().numpy(), rtol=3e-6, atol=3e-7, err_msg=f"tensor {i} clip {clip}")

@@ -135,6 +135,30 @@ def test_logmel_matches_oracle(N, L):
     assert rel_l2(p, FE.MelSpectrogram()(w[0])) < 1e-5
 
 
+def test_l2_waveform_normalisation_front_end(cfg_s):
+    """`normalization: l2` (src/dataset/upstream_dataset.py:61-62: F.normalize(waveform, dim=-1, p=2) before the log-mel, no
+    RunningNorm): the batched HIP front end against torch's F.normalize + the oracle log-mel, incl. an all-zero clip (the
+    1e-12 clamp) and a full-scale clip."""
+    import copy
+    from src.augmentations import AugmentationModule
+    from src.dataset import UpstreamFrontEnd
+    cfg = copy.deepcopy(cfg_s)
+    cfg["pretrain"]["normalization"] = "l2"
+    tf = AugmentationModule(cfg, 1000, max_batch=6)
+    assert tf.pre_norm is None                                   # SURVEY 2.4: l2 replaces the running mean/var normalisation
+    front = UpstreamFrontEnd(cfg, tf)
+    w = fill.uniform((6, 16000), 91, -0.4, 0.4)
+    w[4] = 0.0
+    w[5] = 1.0
+    got = front.log_mel(torch.from_numpy(w).cuda()).cpu()
+    wn = torch.nn.functional.normalize(torch.from_numpy(w), dim=-1, p=2)
+    ref = FE.log_mel_batch(wn)
+    assert got.shape == (6, 1, 64, 101)
+    assert float((got[:, 0].exp() - ref.exp()).abs().max()) <= 1e-5 * float(ref.exp().max()) + 1e-7
+    v1, v2 = front(torch.from_numpy(w).cuda())
+    assert v1.shape == v2.shape == (6, 1, 64, 101) and bool(torch.isfinite(v1).all()) and bool(torch.isfinite(v2).all())
+
+
 def test_logmel_tables_match_oracle():
     from src.utils.utils import slaney_mel_filterbank, pack_filterbank
     fb = slaney_mel_filterbank(16000, 1024, 64, 60, 7800)

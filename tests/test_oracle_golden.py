@@ -324,3 +324,22 @@ def test_decar_v2_model_and_loss(golden):
     sd = m.state_dict()
     np.testing.assert_allclose(sd["projection_head.1.running_mean"][:64].numpy(), g["bn_rm"], rtol=1e-4, atol=1e-6)
     np.testing.assert_allclose(sd["projection_head.1.running_var"][:64].numpy(), g["bn_rv"], rtol=1e-4, atol=1e-6)
+
+
+def test_lr_schedules_vs_reference_golden(golden):
+    """`adjust_learning_rate` (extras/delores-s/multi_proc.py:45-57) and `cosine_scheduler` (extras/decar-v2/multi_proc.py:61-72):
+    the oracle's restatements and the product's (`src.optim`, host logic) against values produced by the reference's functions."""
+    from src import optim as P
+    g = golden("schedules")
+    steps_per_epoch, epochs, bs = 7, 30, 512
+    for fn in (lambda s: OM.lars_lr(s, epochs, steps_per_epoch, bs), lambda s: P.lars_adjust_learning_rate(None, s, epochs, steps_per_epoch, bs)):
+        got = np.array([fn(s) for s in range(epochs * steps_per_epoch)])
+        np.testing.assert_allclose(got[:, 0], g["lars_lr_weights"], rtol=1e-12, atol=0)
+        np.testing.assert_allclose(got[:, 1], g["lars_lr_biases"], rtol=1e-12, atol=0)
+    for mod in (OM, P):
+        np.testing.assert_allclose(mod.cosine_scheduler(4.8, 0.0048, 25, 9, warmup_epochs=10, start_warmup_value=0.3), g["cosine_warm"], rtol=1e-12)
+        np.testing.assert_allclose(mod.cosine_scheduler(1.0, 0.1, 6, 5), g["cosine_plain"], rtol=1e-12)
+    # the schedule main.py:118-122 builds inline (no function to import): product == oracle restatement, endpoints as written
+    a, b = OM.dcv2_lr_schedule(4.8, 0.0048, 15, 7), P.dcv2_lr_schedule(4.8, 0.0048, 15, 7)
+    np.testing.assert_allclose(a, b, rtol=1e-12)
+    assert a[0] == 0.0 and abs(a[69] - 4.8) < 1e-12 and abs(a[70] - 4.8) < 1e-12 and a[-1] > 0.0048
