@@ -60,7 +60,7 @@ class UpstreamFrontEnd:
 
     @torch.no_grad()
     def log_mel(self, waves):
-        """[B, L] device waveforms -> [B, 1, n_mels, T] log-mel; `normalization: l2` first scales every clip to unit L2 norm
+        """[B, L] device waveforms -> [B, n_mels, T] log-mel; `normalization: l2` first scales every clip to unit L2 norm
         (`F.normalize(waveform, dim=-1, p=2)`, src/dataset/upstream_dataset.py:61-62 of the reference) - one wave per clip."""
         if self.l2:
             waves = waves.float().contiguous()

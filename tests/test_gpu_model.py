@@ -553,3 +553,90 @@ def test_train_upstream_end_to_end_and_downstream_probe(tmp_path, cfg_m):
     model.train()
     model(x).float().sum().backward()
     assert model.final.weight.grad is not None and all(p.grad is None for p in model.encoder.parameters())
+
+
+# ------------------------------------------------------------------------------------------------ downstream probe (config 5)
+def _labelled_csvs(tmp_path, n_classes=5, per_class=(8, 4)):
+    import pandas as pd
+    from scipy.io import wavfile
+    rows = {"train": [], "test": []}
+    for c in range(n_classes):
+        for split, n in zip(("train", "test"), per_class):
+            for i in range(n):
+                L = 16000 + 1000 * (i % 3)
+                t = np.arange(L) / 16000.0
+                w = 0.3 * np.sin(2 * np.pi * (250 + 330 * c) * t) + fill.uniform((L,), 1000 * c + 10 * i + (split == "test"), -0.05, 0.05)
+                p = str(tmp_path / f"{split}_{c}_{i}.wav")
+                wavfile.write(p, 16000, (w * 32767).astype(np.int16))
+                rows[split].append({"wav": p, "label": f"tone{c}"})
+    out = {}
+    for split in rows:
+        out[split] = str(tmp_path / f"{split}.csv")
+        pd.DataFrame(rows[split]).to_csv(out[split], index=False)
+    return out
+
+
+def test_train_downstream_probe_steps_vs_oracle_and_harness(tmp_path):
+    """`train_downstream.py:126-184`: (a) three optimisation steps of the frozen-encoder probe - train() mode encoder (batch
+    statistics, dropout), mean over time, Linear, CrossEntropy, Adam - against torch-CPU with the oracle encoder on the same
+    log-mels and dropout masks (fp32 path: tight); (b) the harness end to end on a synthetic 5-class tone task: stats file,
+    accuracy above chance after a few epochs, encoder untouched, head trained."""
+    import importlib.util, json, os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("train_downstream_hip", os.path.join(root, "audio-ssl_amd", "train_downstream.py"))
+    td = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(td)
+    from src import _native as N
+    from src.downstream import DownstreamEncoder
+    from src.encoder import AudioNTT2020Task6
+    from src.utils import freeze_encoder
+    # ---- (a) steps vs oracle
+    dcfg = {"downstream": {"finetune_layer": -1, "base_encoder": {"return_all_layers": False, "output_dim": 2048},
+                           "input": {"n_mels": 64}}}
+    B, T, C = 16, 96, 7
+    model = DownstreamEncoder(dcfg, None, AudioNTT2020Task6, C)
+    fill.fill_state_dict_(model, seed=23)
+    ref_enc = OM.AudioNTT2020Task6(64, 2048, False)
+    ref_enc.load_state_dict({k: v.clone() for k, v in model.encoder.state_dict().items()})
+    ref_fin = torch.nn.Linear(2048, C)
+    ref_fin.load_state_dict({k: v.clone() for k, v in model.final.state_dict().items()})
+    model = model.cuda()
+    model.encoder.precision = N.F32
+    freeze_encoder(model)
+    for p in ref_enc.parameters():
+        p.requires_grad = False
+    tr = td.ProbeTrainer(model, lr=1e-2)
+    ropt = torch.optim.Adam(ref_fin.parameters(), lr=1e-2)
+    ref_enc.train()
+    model.train()
+    for s in range(3):
+        x = views(B, T, 9800 + s)
+        y = torch.from_numpy((fill.uniform01((B,), 9810 + s) * C).astype(np.int64))
+        mask = drop_mask((B, T // 8, 2048), 9820 + s)
+        model.encoder.dropout_masks.queue = [mask]
+        loss = tr.step(x.cuda(), y.cuda())
+        ropt.zero_grad()
+        want = torch.nn.functional.cross_entropy(ref_fin(ref_enc(x, mask).mean(1)), y)
+        want.backward()
+        ropt.step()
+        assert abs(float(loss) - float(want)) <= 2e-4 * abs(float(want)), (s, float(loss), float(want))
+    assert rel_l2(model.final.weight.detach().cpu(), ref_fin.weight.detach()) < 2e-3
+    np.testing.assert_allclose(model.encoder.features_1[1].running_mean.cpu().numpy(), ref_enc.features_1[1].running_mean.numpy(),
+                               rtol=1e-3, atol=1e-5)                 # train() mode: running statistics move even when frozen
+    assert all(p.grad is None for p in model.encoder.parameters())
+    # ---- (b) the harness
+    csvs = _labelled_csvs(tmp_path)
+    cfg_path = str(tmp_path / "down.yaml")
+    import yaml
+    cfg = yaml.safe_load(open(os.path.join(root, "audio-ssl_amd", "src", "downstream", "downstream_config.yaml")))
+    cfg["run"].update(batch_size=8, epochs=4, lr=3e-3, duration=1)
+    yaml.safe_dump(cfg, open(cfg_path, "w"))
+    args = td.get_args(["--task", "tones", "--train_csv", csvs["train"], "--test_csv", csvs["test"], "--exp_dir", str(tmp_path / "exp"),
+                        "-c", cfg_path])
+    torch.manual_seed(0)
+    trainer, hist = td.main(args)
+    lines = [json.loads(l) for l in open(tmp_path / "exp" / "tones" / "downstream_stats.txt")]
+    assert len(lines) == 4 and set(lines[0]) == {"epoch", "Train_loss", "Test_Loss", "Test_Accuracy", "Best_Test_Acc"}
+    assert all(np.isfinite(l["Train_loss"]) and np.isfinite(l["Test_Loss"]) for l in lines)
+    assert lines[-1]["Best_Test_Acc"] > 0.35                         # 5 classes: chance 0.2
+    assert trainer.model.final.weight.requires_grad and not any(p.requires_grad for p in trainer.model.encoder.parameters())
