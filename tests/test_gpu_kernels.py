@@ -135,6 +135,25 @@ def test_logmel_matches_oracle(N, L):
     assert rel_l2(p, FE.MelSpectrogram()(w[0])) < 1e-5
 
 
+@pytest.mark.parametrize("n_mels,L,B", [(128, 16000, 5), (64, 16000, 600), (64, 2240, 3), (40, 15200, 2)])
+def test_logmel_persistent_kernel_shapes(N, n_mels, L, B):
+    """The persistent log-mel kernel on the shapes the main test does not reach: 128 mel rows (two per lane: the SS-MAST
+    front end), more frames than waves can take one each (B = 600: 60,600 frames over 2,048 waves), clips so short that every
+    frame touches the reflected border, a row count that is not a multiple of the wave.  Against the oracle."""
+    from src.utils import MelSpectrogramLibrosa
+    mel = MelSpectrogramLibrosa(n_mels=n_mels)
+    ref_mel = FE.MelSpectrogram(n_mels=n_mels)
+    w = fill.uniform((B, L), 95 + n_mels, -0.4, 0.4)
+    w[:, ::7] *= 0.1
+    got = mel.logmel(torch.from_numpy(w).cuda()).cpu()
+    pick = list(range(B)) if B <= 8 else [0, 1, B // 2, B - 2, B - 1]
+    ref = FE.log_mel_batch(torch.from_numpy(w[pick]), ref_mel)
+    assert got.shape == (B, n_mels, 1 + L // 160)
+    for i, b in enumerate(pick):
+        e_got, e_ref = got[b].exp(), ref[i].exp()
+        assert float((e_got - e_ref).abs().max()) <= 1e-5 * float(e_ref.max()) + 1e-7, b
+
+
 def test_l2_waveform_normalisation_front_end(cfg_s):
     """`normalization: l2` (src/dataset/upstream_dataset.py:61-62: F.normalize(waveform, dim=-1, p=2) before the log-mel, no
     RunningNorm): the batched HIP front end against torch's F.normalize + the oracle log-mel, incl. an all-zero clip (the
