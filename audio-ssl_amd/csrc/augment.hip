@@ -246,6 +246,61 @@ __global__ __launch_bounds__(256) void mask_fill_kernel(float* __restrict__ x, c
     }
 }
 
+// ---- Kmix (`src/augmentations/augmentations.py:119-189`): cluster-guided mixup applied to the finished views.
+// kmix_cluster: cluster[v] = argmin_c || mean_T(view_v) - centroid_c ||  (centroids pre-normalised to unit rows, as get_index
+//   does; for unit rows the nearest centroid of the raw mean and of the normalised mean coincide, so one id serves both the
+//   `point_cluster` of a view and its `memory_centroid_dist` once it is in the bank).  First minimum wins (torch.argmin).
+// kmix_apply : out_v = log(cs e^x + cp e^z + eps) (or cs x + cp z), z = ring slot plan[v]; slot < 0: out = x.
+__global__ __launch_bounds__(256) void kmix_cluster_kernel(const float* __restrict__ views, const float* __restrict__ cent, int F, int T,
+                                                           int K, int* __restrict__ cluster) {
+    __shared__ float m[128];
+    __shared__ float best_d[256];
+    __shared__ int best_i[256];
+    const float* x = views + (long)blockIdx.x * F * T;
+    for (int f = threadIdx.x >> 2; f < F; f += 64) {                 // four lanes per mel row
+        float s = 0.f;
+        for (int t = threadIdx.x & 3; t < T; t += 4) s += x[f * T + t];
+        s += __shfl_xor(s, 1, 64);
+        s += __shfl_xor(s, 2, 64);
+        if ((threadIdx.x & 3) == 0) m[f] = s / (float)T;
+    }
+    __syncthreads();
+    float bd = 3.0e38f;
+    int bi = 0x7fffffff;
+    for (int c = threadIdx.x; c < K; c += 256) {
+        float d = 0.f;
+        for (int f = 0; f < F; ++f) { const float e = m[f] - cent[c * F + f]; d += e * e; }
+        if (d < bd) { bd = d; bi = c; }
+    }
+    best_d[threadIdx.x] = bd; best_i[threadIdx.x] = bi;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (threadIdx.x < o) {
+            const float d2 = best_d[threadIdx.x + o];
+            const int i2 = best_i[threadIdx.x + o];
+            if (d2 < best_d[threadIdx.x] || (d2 == best_d[threadIdx.x] && i2 < best_i[threadIdx.x])) { best_d[threadIdx.x] = d2; best_i[threadIdx.x] = i2; }
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) cluster[blockIdx.x] = best_i[0];
+}
+
+__global__ __launch_bounds__(256) void kmix_apply_kernel(const float* __restrict__ views, const float* __restrict__ ring,
+                                                         const int* __restrict__ slot, const float* __restrict__ coef, int n,
+                                                         int log_mix, float* __restrict__ out) {
+    const int v = blockIdx.y;
+    const int z = slot[v];
+    const float cs = coef[2 * v], cp = coef[2 * v + 1];
+    const float* x = views + (long)v * n;
+    const float* zs = ring + (long)(z < 0 ? 0 : z) * n;
+    float* o = out + (long)v * n;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+        const float xv = x[i];
+        if (z < 0) o[i] = xv;
+        else o[i] = log_mix ? logf(cs * expf(xv) + cp * expf(zs[i]) + F32_EPS) : cp * zs[i] + cs * xv;
+    }
+}
+
 }  // namespace
 
 extern "C" int audiossl_clip_moments(const float* x, double* mom, int B, int n, void* stream) {
@@ -291,5 +346,21 @@ extern "C" int audiossl_mask_fill(float* x, const int* tab, int n_img, int max_m
     ASSL_REQUIRE(x && tab && n_img > 0 && max_masks > 0 && F > 0 && T > 0);
     hipLaunchKernelGGL(mask_fill_kernel, dim3(n_img), dim3(256), 0, static_cast<hipStream_t>(stream), x, tab, max_masks,
                        F, T, zero_fill);
+    ASSL_LAUNCH_CHECK();
+}
+
+extern "C" int audiossl_kmix_cluster(const float* views, const float* centroids, int n_views, int F, int T, int K, int* cluster,
+                                     void* stream) {
+    ASSL_REQUIRE(views && centroids && cluster && n_views > 0 && F > 0 && F <= 128 && T > 0 && K > 0);
+    hipLaunchKernelGGL(kmix_cluster_kernel, dim3(n_views), dim3(256), 0, static_cast<hipStream_t>(stream), views, centroids, F, T, K,
+                       cluster);
+    ASSL_LAUNCH_CHECK();
+}
+
+extern "C" int audiossl_kmix_apply(const float* views, const float* ring, const int* slot, const float* coef, int n_views, int n,
+                                   int log_mix, float* out, void* stream) {
+    ASSL_REQUIRE(views && ring && slot && coef && out && n_views > 0 && n > 0);
+    hipLaunchKernelGGL(kmix_apply_kernel, dim3(ceil_div(n, 1024), n_views), dim3(256), 0, static_cast<hipStream_t>(stream), views,
+                       ring, slot, coef, n, log_mix, out);
     ASSL_LAUNCH_CHECK();
 }

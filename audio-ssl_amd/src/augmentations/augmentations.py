@@ -100,6 +100,116 @@ class RandomResizeCrop(nn.Module):
         return s + ", freq_scale={0})".format(tuple(round(v, 4) for v in self.freq_scale))
 
 
+class Kmix(nn.Module):
+    """K-mix (`src/augmentations/augmentations.py:119-189` of the reference): mixup whose partner comes from the memory-bank
+    entries of the centroid cluster FARTHEST from the view's own cluster (first non-empty cluster in descending centroid
+    distance, first 128 entries of it, one drawn with np.random.randint).  Same constructor; `forward(x[1, F, T])` is the
+    reference's per-call form, `mix_batch(views[n, F, T])` the same n calls with ONE cluster launch, one device->host copy of
+    the n cluster ids and one mixing launch.
+    Device side: the bank is a ring of views (HBM), cluster ids come from `kmix_cluster`, the mixing from `kmix_apply`.
+    Host side (numpy-stream exact): alpha = ratio * np.random.random(), then np.random.randint(len(l)) - or randint(len(bank))
+    while the bank holds fewer than 128 entries - per call, the FIFO of cluster ids, the far-to-near centroid order
+    (torch.topk(torch.cdist(c, c), k=K).indices, computed once with the same torch ops the reference runs per call)."""
+
+    def __init__(self, ratio=0.4, n_memory=2048, log_mixup_exp=True, top_k=None, centroid_path=None, centroids=None):
+        super().__init__()
+        self.ratio, self.n, self.log_mixup_exp, self.top_k = ratio, n_memory, log_mixup_exp, top_k
+        c = centroids if centroids is not None else torch.load(centroid_path, map_location="cpu", weights_only=True)
+        self.centroids = torch.as_tensor(c, dtype=torch.float32).cpu()
+        cn = self.centroids / self.centroids.norm(dim=-1, keepdim=True)
+        self.far_order = torch.topk(torch.cdist(cn, cn, p=2), k=len(cn), dim=1).indices.numpy()
+        self._cn = cn.contiguous()
+        self.bank_ids = []            # cluster id of every entry of the reference's FIFO (oldest first)
+        self.entries = 0              # entries appended so far; FIFO position j <-> ring slot (entries - len + j) % R
+        self.ring = self.R = None
+        self.last_choice = None       # FIFO position chosen by the last call (None: no mixing)
+        self.draws = []               # (randint argument, value) of every index draw - what the parity test compares
+
+    def __repr__(self):
+        return self.__class__.__name__ + f"(ratio={self.ratio},n={self.n},log_mixup_exp={self.log_mixup_exp})"
+
+    def _ensure(self, n_new, numel, dev):
+        need = self.n + max(n_new, 2)
+        if self.ring is None or self.ring.device != dev or self.ring.shape[1] != numel or need > self.R:
+            old, old_R = self.ring, self.R
+            self.R = max(need, self.R or 0)
+            self.ring = torch.zeros(self.R, numel, dtype=torch.float32, device=dev)
+            if old is not None and old.shape[1] == numel:
+                for g in range(max(0, self.entries - len(self.bank_ids)), self.entries):
+                    self.ring[g % self.R].copy_(old[g % old_R])
+            self._cn_dev = self._cn.to(dev)
+
+    def _select(self, cx):
+        """FIFO position of the partner for a view of cluster cx (`get_index` + the small-bank branch of `forward`)."""
+        nb = len(self.bank_ids)
+        if nb >= 128:
+            if nb < self.top_k:
+                raise TypeError("list indices must be integers or slices, not NoneType")     # get_index returned None
+            ids = np.asarray(self.bank_ids)
+            for cid in self.far_order[cx]:
+                l = np.nonzero(ids == cid)[0]
+                if len(l):
+                    break
+            l = l[:128]
+            k = int(np.random.randint(len(l)))
+            self.draws.append((len(l), k))
+            return int(l[k])
+        k = int(np.random.randint(nb))
+        self.draws.append((nb, k))
+        return k
+
+    def _plan_call(self, cx, slot_out, coef_out, i):
+        alpha = self.ratio * np.random.random()
+        nb = len(self.bank_ids)
+        if nb:
+            j = self._select(cx)
+            slot_out[i] = (self.entries - nb + j) % self.R
+            a1 = 1.0 - alpha
+            coef_out[i] = (_F32(a1), _F32(1.0 - a1))
+            self.last_choice = j
+        else:
+            slot_out[i] = -1
+            self.last_choice = None
+        self.bank_ids.append(int(cx))
+        if len(self.bank_ids) > self.n:
+            self.bank_ids.pop(0)
+        self.entries += 1
+
+    @torch.no_grad()
+    def mix_batch(self, views):
+        """views [n, F, T] (device, in call order) -> the n results of consecutive `forward` calls, [n, F, T] float32."""
+        if not views.is_cuda:
+            raise RuntimeError("Kmix runs on the GPU only (no CPU fallback)")
+        views = views.contiguous().float()
+        n, F, T = views.shape
+        dev = views.device
+        self._ensure(n, F * T, dev)
+        ids_d = torch.empty(n, dtype=torch.int32, device=dev)
+        N.call("kmix_cluster", views, self._cn_dev, n, F, T, self._cn.shape[0], ids_d)
+        g0 = self.entries
+        flat = views.view(n, F * T)
+        first = g0 % self.R                                          # this batch's views enter the ring before anybody reads them
+        k = min(n, self.R - first)
+        self.ring[first:first + k].copy_(flat[:k])
+        if k < n:
+            self.ring[:n - k].copy_(flat[k:])
+        ids = ids_d.cpu().numpy()                                    # the one device -> host round trip
+        slot = np.full(n, -1, np.int32)
+        coef = np.zeros((n, 2), _F32)
+        for i in range(n):
+            self._plan_call(ids[i], slot, coef, i)
+        out = torch.empty_like(views)
+        N.call("kmix_apply", views, self.ring, torch.from_numpy(slot).to(dev), torch.from_numpy(coef).to(dev), n, F * T,
+               int(bool(self.log_mixup_exp)), out)
+        return out
+
+    def forward(self, x):
+        """x [1, F, T] -> mixed [1, F, T] (float32), as the reference's per-call form."""
+        src = x.device
+        out = self.mix_batch((x if x.is_cuda else x.cuda()).reshape(1, x.shape[-2], x.shape[-1]))
+        return out if src.type == "cuda" else out.to(src)
+
+
 class SpecAugment(nn.Module):
     """Frequency / time band masks of `extras/delores-s/specaugment.py:68-122` (time_warp excluded: it calls the
     removed torch.solve).  Draw order per view: all frequency masks, then all time masks."""
@@ -161,10 +271,14 @@ class AugmentationModule:
                                         time_scale=r["time_crop_scale"])
         if "SpecAugment" in aug:
             self.spec = SpecAugment(**aug["SpecAugment"])
-        for unsupported in ("Kmix", "PatchDrop"):
-            if unsupported in aug:
-                raise NotImplementedError(f"{unsupported} is not part of the HIP two-view path (SURVEY 2.4); drop the key")
-        self.train_transform = nn.Sequential(*[m for m in (self.mix, self.rrc, self.spec) if m is not None])
+        self.kmix = None
+        if "Kmix" in aug:
+            k = aug["Kmix"]
+            self.kmix = Kmix(ratio=k["ratio"], log_mixup_exp=k["log_mixup_exp"], top_k=k["top_k"], centroid_path=k.get("centroid_path"),
+                             centroids=k.get("centroids"))
+        if "PatchDrop" in aug:
+            raise NotImplementedError("PatchDrop is not part of the HIP two-view path (SURVEY 2.4); drop the key")
+        self.train_transform = nn.Sequential(*[m for m in (self.mix, self.rrc, self.kmix, self.spec) if m is not None])
         self.pre_norm = None
         if config["pretrain"]["normalization"] == "mean_var":
             self.pre_norm = RunningNorm(epoch_samples=2 * len_of_files)
@@ -329,6 +443,15 @@ class AugmentationModule:
         v2 = torch.empty(B, 1, F, T, dtype=torch.float32, device=dev)
         log_mix = 1 if (self.mix is None or self.mix.log_mixup_exp) else 0
         N.call("aug_views", self.bank, self.R, ip_d, fp_d, v1, v2, B, F, T, max(ch, F), max(cw, T), log_mix)
+        if self.kmix is not None:
+            # Kmix closes the reference's Sequential (MixupBYOLA, RandomResizeCrop, Kmix): its calls come in the order clip 0
+            # view 1, clip 0 view 2, clip 1 view 1, ...  Batched: the 2B views are clustered in one launch and mixed in one;
+            # the numpy draws of these calls are made AFTER the batch's MixupBYOLA / RandomResizeCrop draws (the reference
+            # interleaves them view by view; its len(l)-dependent randint makes the interleaved stream depend on device results,
+            # i.e. one host <-> device round trip per view - `Kmix.forward` used view by view keeps that order exactly)
+            both = torch.stack([v1[:, 0], v2[:, 0]], dim=1).reshape(2 * B, F, T)
+            mixed = self.kmix.mix_batch(both).view(B, 2, F, T)
+            v1, v2 = mixed[:, 0:1].contiguous(), mixed[:, 1:2].contiguous()
         if self.spec is not None:
             K = self.spec.max_masks
             tab = np.full((B, 2, K, 4), -1, np.int32)

@@ -72,6 +72,15 @@ int audiossl_aug_plan_host(uint32_t* np_key, int* np_pos, uint32_t* py_key, int*
 
 /* ---- K5 SpecAugment band masks: extras/delores-s/specaugment.py:68-122 ---------------------------------
  * tab [n_img][max_masks][4] = {axis (0 time, 1 freq, -1 stop), start, end, 0}; in place on x [n_img][F][T]. */
+/* ---- a10 Kmix: src/augmentations/augmentations.py:119-189 (cluster-guided mixup of the finished views) -------------------
+ * kmix_cluster: cluster[v] = first argmin_c ||mean_T(views[v]) - centroids[c]|| (centroids [K][F] with unit rows: what
+ *   `get_index` computes for the view itself and, once it sits in the memory bank, for the bank entry).
+ * kmix_apply: out[v] = log(coef[v][0] e^x + coef[v][1] e^z + eps) with z = ring[slot[v]] (log_mix 0: linear mix; slot < 0:
+ *   copy).  Partner choice, the alpha / index draws and the FIFO live on the host (they are numpy-stream exact). */
+int audiossl_kmix_cluster(const float* views, const float* centroids, int n_views, int F, int T, int K, int* cluster,
+                          void* stream);
+int audiossl_kmix_apply(const float* views, const float* ring, const int* slot, const float* coef, int n_views, int n,
+                        int log_mix, float* out, void* stream);
 int audiossl_mask_fill(float* x, const int* tab, int n_img, int max_masks, int F, int T, int zero_fill, void* stream);
 
 /* ---- K6 stem: src/encoder/audiontt.py:46-50 (features_1) ------------------------------------------------

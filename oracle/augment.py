@@ -91,6 +91,55 @@ class MixupBYOLA:
 CUBIC_A = -0.75   # PyTorch's bicubic coefficient
 
 
+class Kmix:
+    """`src/augmentations/augmentations.py:119-189`: mixup with a partner from the farthest non-empty centroid cluster.
+    Per call: alpha = ratio * np.random.random(); with a non-empty bank the partner index is np.random.randint(len(bank))
+    below 128 entries, else `get_index`: clusters = nearest (unit-row) centroid of the time-averaged spectrum of every bank
+    entry / of x, centroids visited from the farthest to the nearest to x's own, first cluster with members wins, its first
+    128 members (bank order) are the candidates, one drawn with np.random.randint; then the log-domain mix and the FIFO
+    append of x (the INPUT, not the mix)."""
+
+    def __init__(self, ratio=0.4, n_memory=2048, log_mixup_exp=True, top_k=None, centroids=None):
+        self.ratio, self.n, self.lme, self.top_k = ratio, n_memory, log_mixup_exp, top_k
+        self.centroids = torch.as_tensor(centroids, dtype=torch.float32)
+        self.memory_bank = []
+        self.draws = []
+
+    def get_index(self, x):
+        if len(self.memory_bank) < self.top_k:
+            return None
+        c = self.centroids / self.centroids.norm(dim=-1, keepdim=True)
+        avg = torch.stack([z.squeeze(0).T.mean(dim=0) for z in self.memory_bank])
+        avg = avg / avg.norm(dim=-1, keepdim=True)
+        far_first = torch.topk(torch.cdist(c, c, p=2), k=len(c), dim=1).indices
+        bank_cluster = torch.argmin(torch.cdist(avg, c, p=2), dim=1)
+        own = int(torch.argmin(torch.cdist(x.squeeze(0).T.mean(dim=0).unsqueeze(0), c, p=2), dim=1))
+        members = []
+        for cid in far_first[own].tolist():
+            members = (bank_cluster == cid).nonzero().flatten().tolist()
+            if members:
+                break
+        members = members[:128]
+        k = np.random.randint(len(members))
+        self.draws.append((len(members), int(k)))
+        return members[k]
+
+    def __call__(self, x):
+        alpha = self.ratio * np.random.random()
+        if self.memory_bank:
+            if len(self.memory_bank) >= 128:
+                j = self.get_index(x)
+            else:
+                j = np.random.randint(len(self.memory_bank))
+                self.draws.append((len(self.memory_bank), int(j)))
+            z = self.memory_bank[j]
+            mixed = log_mixup_exp(x, z, 1.0 - alpha) if self.lme else alpha * z + (1.0 - alpha) * x
+        else:
+            mixed = x
+        self.memory_bank = (self.memory_bank + [x])[-self.n:]
+        return mixed.to(torch.float)
+
+
 def cubic_coeffs(t):
     """PyTorch get_cubic_upsample_coefficients (A=-0.75) for fraction t."""
     A = CUBIC_A

@@ -417,6 +417,42 @@ def g13_schedules(MP):
     save("schedules", lars_lr_weights=np.array(lw), lars_lr_biases=np.array(lb), cosine_warm=cs, cosine_plain=cs0)
 
 
+def g14_kmix(A):
+    """The reference's `Kmix` (src/augmentations/augmentations.py:119-189) run call by call on closed-form inputs with a
+    closed-form centroid tensor: 170 calls, memory bank capped at 140 entries, so the random-index branch (< 128 entries), the
+    cluster-guided branch (`get_index`) and the FIFO trimming all occur.  Recorded: the chosen bank index of every call (by
+    wrapping get_index / np.random.randint from outside - the class itself is untouched), a few outputs, the stream position."""
+    import tempfile
+    F, T, K, calls = 64, 24, 12, 170
+    cent = torch.from_numpy(fill.normalish((K, F), 4242)) + 0.3
+    with tempfile.TemporaryDirectory() as d:
+        path = os.path.join(d, "centroids.pt")
+        torch.save(cent, path)
+        km = A.Kmix(ratio=0.4, n_memory=140, log_mixup_exp=True, top_k=16, centroid_path=path)
+    np.random.seed(77)
+    chosen, outs = [], {}
+    orig_randint = np.random.randint
+    picks = []
+
+    def spy_randint(*a, **k):
+        v = orig_randint(*a, **k)
+        picks.append((int(a[0]), int(v)))
+        return v
+    np.random.randint = spy_randint
+    try:
+        for c in range(calls):
+            x = torch.from_numpy(fill.normalish((1, F, T), 5000 + c)) * (0.5 + 0.1 * (c % 7)) + 0.2 * (c % 5)
+            n_before = len(picks)
+            y = km(x)
+            chosen.append(picks[-1] if len(picks) > n_before else (0, -1))       # (randint argument = len(l) or len(bank), value)
+            if c in (0, 1, 5, 127, 128, 129, 141, 169):
+                outs[f"y{c}"] = t2n(y)
+    finally:
+        np.random.randint = orig_randint
+    tail = np.random.random()
+    save("kmix", centroids=t2n(cent), picks=np.array(chosen, np.int64), tail=np.float64(tail), **outs)
+
+
 CFG_SL = {"pretrain": dict(CFG_S["pretrain"], instance_contrastive_dim=128, cluster_contrastive_dim=128)}
 
 
@@ -529,6 +565,9 @@ def main():
     if len(sys.argv) > 1 and sys.argv[1] == "schedules":
         g13_schedules(MP)
         return
+    if len(sys.argv) > 1 and sys.argv[1] == "kmix":
+        g14_kmix(A)
+        return
     g1_window(U)
     g2_runnorm(A)
     g3_aug(A_pkg)
@@ -542,6 +581,7 @@ def main():
     g11_slicer(CL, ENC)
     g12_decar(ENC)
     g13_schedules(MP)
+    g14_kmix(A)
 
 
 if __name__ == "__main__":

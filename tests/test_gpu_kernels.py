@@ -247,6 +247,53 @@ def test_runnorm_scan_is_the_fp32_recurrence_bit_for_bit(N, B, n0, max_update):
     assert np.array_equal(st_f.cpu().numpy(), np.array([mu, s2], np.float32))
 
 
+def test_kmix_vs_reference_golden(N, golden):
+    """Kmix (`src/augmentations/augmentations.py:119-189`) against the reference class run on the same 170 closed-form views:
+    every index draw - randint(len(bank)) below 128 entries, randint(len(l)) of the farthest non-empty cluster above - with its
+    argument AND value (bit-exact: the arguments depend on the cluster ids computed on the GPU), outputs <= 2e-5, the numpy
+    stream position afterwards; once call by call (`forward`), once as two batches (`mix_batch`: one cluster launch, one
+    device->host copy, one mixing launch per batch)."""
+    from src.augmentations.augmentations import Kmix
+    g = golden("kmix")
+    F, T, calls = 64, 24, 170
+    xs = [torch.from_numpy(fill.normalish((1, F, T), 5000 + c)) * (0.5 + 0.1 * (c % 7)) + 0.2 * (c % 5) for c in range(calls)]
+    want = [tuple(p) for p in g["picks"].tolist() if p[1] >= 0]
+    for mode in ("calls", "batches"):
+        km = Kmix(ratio=0.4, n_memory=140, log_mixup_exp=True, top_k=16, centroids=torch.from_numpy(g["centroids"]))
+        np.random.seed(77)
+        if mode == "calls":
+            ys = [km(x.cuda()).cpu() for x in xs]
+        else:
+            a = km.mix_batch(torch.cat(xs[:50]).cuda()).cpu()
+            b = km.mix_batch(torch.cat(xs[50:]).cuda()).cpu()
+            ys = [y[None] for y in torch.cat([a, b])]
+        assert km.draws == want, (mode, [i for i, (p, q) in enumerate(zip(km.draws, want)) if p != q][:5])
+        assert np.random.random() == float(g["tail"])
+        for c in (0, 1, 5, 127, 128, 129, 141, 169):
+            assert float((ys[c] - torch.from_numpy(g[f"y{c}"])).abs().max()) <= 2e-5, (mode, c)
+        assert len(km.bank_ids) == 140 and km.entries == calls
+
+
+def test_kmix_inside_the_augmentation_module(N, cfg_s):
+    """`Kmix` as the third stage of the two-view pipeline (`src/augmentations/__init__.py:18-30`): views stay finite, the bank
+    fills with 2 entries per clip in call order, PatchDrop is still refused."""
+    import copy
+    from src.augmentations import AugmentationModule
+    cfg = copy.deepcopy(cfg_s)
+    cent = torch.from_numpy(fill.normalish((16, 64), 4243)) + 0.2
+    cfg["pretrain"]["augmentations"]["Kmix"] = {"ratio": 0.4, "log_mixup_exp": True, "top_k": 16, "centroids": cent}
+    tf = AugmentationModule(cfg, 1000, max_batch=96)
+    np.random.seed(5); random.seed(5)
+    lms = torch.from_numpy(fill.normalish((96, 64, 101), 31) * 2.0 - 4.0).cuda()
+    v1, v2 = tf.augment_batch(lms)
+    assert v1.shape == v2.shape == (96, 1, 64, 101) and bool(torch.isfinite(v1).all()) and bool(torch.isfinite(v2).all())
+    assert tf.kmix.entries == 192 and len(tf.kmix.draws) == 191            # every call but the very first mixes
+    assert tf.kmix.draws[126][0] == 127 and tf.kmix.draws[127][0] < 128    # call 128 is the first cluster-guided one
+    cfg["pretrain"]["augmentations"]["PatchDrop"] = {"ratio": 0.1}
+    with pytest.raises(NotImplementedError):
+        AugmentationModule(cfg, 1000)
+
+
 def test_aug_fifo_wraparound_vs_oracle(N, cfg_s):
     """More clips than the 2048-entry FIFO holds: partner resolution across the ring wrap, small images."""
     from src.augmentations import AugmentationModule

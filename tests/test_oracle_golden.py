@@ -343,3 +343,20 @@ def test_lr_schedules_vs_reference_golden(golden):
     a, b = OM.dcv2_lr_schedule(4.8, 0.0048, 15, 7), P.dcv2_lr_schedule(4.8, 0.0048, 15, 7)
     np.testing.assert_allclose(a, b, rtol=1e-12)
     assert a[0] == 0.0 and abs(a[69] - 4.8) < 1e-12 and abs(a[70] - 4.8) < 1e-12 and a[-1] > 0.0048
+
+
+def test_kmix_oracle_vs_reference_golden(golden):
+    """oracle.augment.Kmix against the reference's class (tests/golden/make_goldens.py g14): every index draw (argument and
+    value), eight outputs, the numpy stream position."""
+    g = golden("kmix")
+    F, T, calls = 64, 24, 170
+    km = OA.Kmix(ratio=0.4, n_memory=140, log_mixup_exp=True, top_k=16, centroids=torch.from_numpy(g["centroids"]))
+    np.random.seed(77)
+    ys = []
+    for c in range(calls):
+        x = torch.from_numpy(fill.normalish((1, F, T), 5000 + c)) * (0.5 + 0.1 * (c % 7)) + 0.2 * (c % 5)
+        ys.append(km(x))
+    assert km.draws == [tuple(p) for p in g["picks"].tolist() if p[1] >= 0]
+    assert np.random.random() == float(g["tail"])
+    for c in (0, 1, 5, 127, 128, 129, 141, 169):
+        np.testing.assert_allclose(ys[c].numpy(), g[f"y{c}"], rtol=1e-6, atol=1e-6)
