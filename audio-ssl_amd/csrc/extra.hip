@@ -100,6 +100,23 @@ __global__ __launch_bounds__(64) void kmeans_update_kernel(const float* __restri
     }
 }
 
+// Lloyd (Euclidean) M step of the offline labeler (faiss.Clustering in extras/decar-v2/clustering.py:46-85): plain mean, empty
+// clusters keep their centroid.  out[k] = scale * |x_k|^2 is the bias of the E step's argmin |x - c|^2 = argmax (x.c - |c|^2 / 2).
+__global__ __launch_bounds__(64) void kmeans_update_mean_kernel(const float* __restrict__ sums, const int* __restrict__ counts, int D,
+                                                                float* __restrict__ centroids) {
+    const long k = blockIdx.x;
+    const int cnt = counts[k];
+    if (cnt <= 0) return;
+    for (int d = threadIdx.x; d < D; d += 64) centroids[k * D + d] = sums[k * D + d] / (float)cnt;
+}
+__global__ __launch_bounds__(64) void row_sqnorm_kernel(const float* __restrict__ x, int D, float scale, float* __restrict__ out) {
+    const long k = blockIdx.x;
+    float ss = 0.f;
+    for (int d = threadIdx.x; d < D; d += 64) { const float v = x[k * D + d]; ss += v * v; }
+    ss = wave_sum(ss);
+    if (threadIdx.x == 0) out[k] = scale * ss;
+}
+
 // nn.CrossEntropyLoss(ignore_index): loss += sum_{valid r} (lse_r - logit[r][t_r]) / n_valid ; dlogits = (softmax - onehot)/n_valid
 // n_valid is counted by a first tiny launch into cnt[0].
 __global__ void count_valid_kernel(const long long* __restrict__ target, int B, int ignore_index, int* cnt) {
@@ -289,6 +306,18 @@ extern "C" int audiossl_kmeans_accumulate(const float* x, const long long* assig
 extern "C" int audiossl_kmeans_update(const float* sums, const int* counts, int K, int D, float* centroids, void* stream) {
     ASSL_REQUIRE(sums && counts && centroids && K > 0 && D > 0);
     hipLaunchKernelGGL(kmeans_update_kernel, dim3(K), dim3(64), 0, S_(stream), sums, counts, D, centroids);
+    ASSL_LAUNCH_CHECK();
+}
+
+extern "C" int audiossl_kmeans_update_mean(const float* sums, const int* counts, int K, int D, float* centroids, void* stream) {
+    ASSL_REQUIRE(sums && counts && centroids && K > 0 && D > 0);
+    hipLaunchKernelGGL(kmeans_update_mean_kernel, dim3(K), dim3(64), 0, S_(stream), sums, counts, D, centroids);
+    ASSL_LAUNCH_CHECK();
+}
+
+extern "C" int audiossl_row_sqnorm(const float* x, int rows, int D, float scale, float* out, void* stream) {
+    ASSL_REQUIRE(x && out && rows > 0 && D > 0);
+    hipLaunchKernelGGL(row_sqnorm_kernel, dim3(rows), dim3(64), 0, S_(stream), x, D, scale, out);
     ASSL_LAUNCH_CHECK();
 }
 

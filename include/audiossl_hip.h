@@ -266,6 +266,11 @@ int audiossl_row_argmax(const float* dot, long N, int K, long long* assign, void
 int audiossl_kmeans_accumulate(const float* x, const long long* assign, long N, int K, int D, float* sums, int* counts,
                                void* stream);
 int audiossl_kmeans_update(const float* sums, const int* counts, int K, int D, float* centroids, void* stream);
+/* Offline pseudo-labeler (extras/decar-v2/clustering.py:19-115: faiss PCA-whitening + k-means): the Lloyd M step with plain
+ * means (empty clusters keep their centroid) and out[r] = scale * |x_r|^2, the bias that turns the dot-product GEMM + row_argmax
+ * into the Euclidean E step. */
+int audiossl_kmeans_update_mean(const float* sums, const int* counts, int K, int D, float* centroids, void* stream);
+int audiossl_row_sqnorm(const float* x, int rows, int D, float scale, float* out, void* stream);
 int audiossl_ce_rows(int dtype, const float* logits, const long long* target, int B, int K, int ignore_index, int* cnt,
                      float* loss_out, void* dlogits, void* stream);
 

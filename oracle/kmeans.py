@@ -31,3 +31,32 @@ def cluster_memory(mem, centroids, n_iters=10, all_reduce=None):
         centroids[mask] = sums[mask] / counts[mask].unsqueeze(1)
         centroids = F.normalize(centroids, dim=1, p=2)
     return centroids, assign
+
+
+def pca_whiten_l2(x, pca=128):
+    """faiss.PCAMatrix(d, pca, eigen_power=-0.5) + row L2 normalisation as `extras/decar-v2/clustering.py:19-42` uses them
+    (faiss absent: restated from its documented behaviour - centre, covariance eigenvectors, eigenvalue^-0.5 scaling)."""
+    import numpy as np
+    x = np.asarray(x, np.float64)
+    xc = x - x.mean(0, keepdims=True)
+    lam, vec = np.linalg.eigh(xc.T @ xc / len(x))
+    order = np.argsort(lam)[::-1][:pca]
+    y = xc @ (vec[:, order] * np.power(np.maximum(lam[order], 1e-20), -0.5))
+    return y / np.linalg.norm(y, axis=1, keepdims=True)
+
+
+def lloyd(x, init, niter=20):
+    """Euclidean k-means from given initial centroids: nearest centroid, plain means, empty clusters keep theirs."""
+    import numpy as np
+    x = np.asarray(x, np.float64)
+    c = np.array(init, np.float64)
+    for it in range(niter + 1):
+        d2 = (x * x).sum(1)[:, None] - 2.0 * x @ c.T + (c * c).sum(1)[None]
+        a = d2.argmin(1)
+        if it == niter:
+            break
+        for k in range(len(c)):
+            m = a == k
+            if m.any():
+                c[k] = x[m].mean(0)
+    return a, float(np.maximum(d2[np.arange(len(x)), a], 0).sum()), c

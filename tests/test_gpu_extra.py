@@ -287,3 +287,30 @@ def test_larc_sgd_vs_oracle():
             OM.larc_sgd_step(ref, bufs, 0.6, weight_decay=1e-3, momentum=0.9, trust_coefficient=0.02, clip=clip)
         for i, (p, r) in enumerate(zip(ps, ref)):
             np.testing.assert_allclose(p.detach().cpu().numpy(), r.detach().numpy(), rtol=3e-6, atol=3e-7, err_msg=f"tensor {i} clip {clip}")
+
+
+def test_offline_pseudolabeler_vs_oracle(tmp_path):
+    """`extras/decar-v2/clustering.py` Kmeans(k).cluster(features) + the label CSV of store_clusters.py: PCA-whitening and Lloyd's
+    k-means on the GPU against the numpy restatement from the same initial points (faiss absent: parity unpinned)."""
+    from src.upstream.decar_v2 import clustering as CL
+    n, d, k = 3000, 512, 24
+    g = np.random.RandomState(3)
+    blobs = g.randn(k, d) * 2.0
+    x = (blobs[g.randint(k, size=n)] + g.randn(n, d) * 0.7).astype(np.float32)
+    xb = CL.preprocess_features(x, pca=128)
+    want = OK.pca_whiten_l2(x, 128)
+    # eigenvectors are defined up to sign: compare the Gram matrices (what every distance depends on)
+    assert rel_l2((xb @ xb.T).cpu()[:200, :200], torch.from_numpy(want @ want.T)[:200, :200]) < 2e-3
+    np.testing.assert_allclose(xb.norm(dim=1).cpu().numpy(), 1.0, rtol=1e-5)
+    ids, loss = CL.run_kmeans(xb, k, seed=11)
+    init = xb[torch.from_numpy(np.random.RandomState(11).permutation(n)[:k]).cuda()].cpu().numpy()
+    a_ref, loss_ref, _ = OK.lloyd(xb.cpu().numpy(), init, 20)
+    assert float((np.array(ids) == a_ref).mean()) >= 0.999
+    assert abs(loss - loss_ref) <= 1e-3 * loss_ref
+    km = CL.Kmeans(k)
+    np.random.seed(4)
+    km.cluster(x)
+    assert sum(len(l) for l in km.images_lists) == n
+    labels = CL.write_pseudolabel_csv([f"clip{i}.wav" for i in range(n)], km, str(tmp_path / "labels.csv"))
+    lines = open(tmp_path / "labels.csv").read().split()
+    assert len(lines) == n and lines[5] == f"clip5.wav,{int(labels[5])}" and labels[km.images_lists[3][0]] == 3
