@@ -23,24 +23,24 @@ AUDIO_SR = 16000
 
 
 def load_audio(path, sr=AUDIO_SR):
-    """-> float32 mono numpy array at `sr`."""
-    if str(path).endswith(".npy"):
-        return np.load(path, allow_pickle=False).astype(np.float32)
-    from scipy.io import wavfile
-    rate, data = wavfile.read(path)
-    if data.dtype.kind == "i":
-        data = data.astype(np.float32) / float(np.iinfo(data.dtype).max + 1)
-    elif data.dtype.kind == "u":
-        data = (data.astype(np.float32) - 128.0) / 128.0
-    data = data.astype(np.float32)
-    if data.ndim > 1:
-        data = data.mean(axis=1)
-    if rate != sr:
-        from math import gcd
-        from scipy.signal import resample_poly
-        g = gcd(int(rate), int(sr))
-        data = resample_poly(data, sr // g, rate // g).astype(np.float32)
-    return data
+    """-> float32 mono numpy array at `sr`: host decode (`ingest.decode`), then the windowed-sinc resampler on the GPU
+    (`ingest.resample`, resampy kaiser_best as librosa.core.load uses it).  Inside a DataLoader worker process (no GPU context
+    there) the clip is returned at its native rate wrapped in `NativeRate`; the main-process collate resamples it."""
+    from src.dataset import ingest
+    data, rate = ingest.decode(path)
+    if rate == sr:
+        return data
+    import torch.utils.data as tud
+    if tud.get_worker_info() is not None:
+        return NativeRate(data, rate)
+    return ingest.resample(torch.from_numpy(data), rate, sr).cpu().numpy()
+
+
+class NativeRate:
+    """A decoded clip that still has its file's sample rate (produced in loader workers, consumed by `WindowCollate`)."""
+
+    def __init__(self, data, rate):
+        self.data, self.rate = data, rate
 
 
 class UpstreamFrontEnd:
@@ -119,7 +119,10 @@ class BaseDataset(Dataset):
         return int(self.length * 16000)
 
     def __getitem__(self, idx):
-        wave = torch.from_numpy(load_audio(self.data["files"][idx], self.sampling_rate))
+        wave = load_audio(self.data["files"][idx], self.sampling_rate)
+        if isinstance(wave, NativeRate):
+            return wave                      # resampled on the GPU by the main-process collate
+        wave = torch.from_numpy(wave)
         if not self.per_sample:
             return wave                      # cropped at collate time, with the draws in the reference's order
         # reference-shaped per-sample path (one clip through the same kernels; slow, for API parity)
@@ -144,6 +147,8 @@ class WindowCollate:
         self.tfms, self.unit, self.n_mels, self.hop = tfms, unit_length, n_mels, hop
 
     def __call__(self, waves):
+        from src.dataset import ingest
+        waves = [ingest.resample(torch.from_numpy(w.data), w.rate, AUDIO_SR).cpu() if isinstance(w, NativeRate) else w for w in waves]
         B = len(waves)
         lens = np.array([len(w) for w in waves], np.int32)
         T = 1 + self.unit // self.hop

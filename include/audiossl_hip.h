@@ -72,6 +72,15 @@ int audiossl_aug_plan_host(uint32_t* np_key, int* np_pos, uint32_t* py_key, int*
 
 /* ---- K5 SpecAugment band masks: extras/delores-s/specaugment.py:68-122 ---------------------------------
  * tab [n_img][max_masks][4] = {axis (0 time, 1 freq, -1 stop), start, end, 0}; in place on x [n_img][F][T]. */
+/* ---- f2 audio ingest: the resampling of `librosa.core.load(path, sr=16000)` (src/dataset/upstream_dataset.py:55; librosa 0.8.1
+ * -> resampy 0.2.2, filter kaiser_best).  y[c][t] = sum_i (win[off_l[t] + i s] + eta_l[t] delta[...]) x[c][n[t] - i]
+ *                                              + sum_k (win[off_r[t] + k s] + eta_r[t] delta[...]) x[c][n[t] + 1 + k],  s = index_step,
+ * wings cut at the clip ends and the table end, products in fp64 added into an fp32 running sum in resampy's order.  The
+ * position tables come from the host (src/dataset/ingest.py), which keeps resampy's float64 time register. */
+int audiossl_resample_sinc(const float* x, float* y, int clips, int n_orig, int n_out, const int* n, const int* off_l,
+                           const int* off_r, const double* eta_l, const double* eta_r, const double* win, const double* delta,
+                           int nwin, int index_step, void* stream);
+
 /* ---- a10 Kmix: src/augmentations/augmentations.py:119-189 (cluster-guided mixup of the finished views) -------------------
  * kmix_cluster: cluster[v] = first argmin_c ||mean_T(views[v]) - centroids[c]|| (centroids [K][F] with unit rows: what
  *   `get_index` computes for the view itself and, once it sits in the memory bank, for the bank entry).

@@ -153,3 +153,47 @@ def n_frames(n_samples, hop=160):
 def l2_normalize_wave(w):
     """upstream_dataset.py:61-62 (F.normalize(p=2, dim=-1), eps 1e-12)."""
     return w / w.norm(p=2, dim=-1, keepdim=True).clamp_min(1e-12)
+
+
+# ------------------------------------------------------------------ f2 audio ingest: resampy 0.2.2 kaiser_best (librosa.core.load)
+def resample_kaiser_best(x, sr_orig, sr_new):
+    """`resampy.resample(x, sr_orig, sr_new, filter='kaiser_best')` as `librosa.core.load(path, sr=16000)` calls it
+    (src/dataset/upstream_dataset.py:55), followed by librosa's fix_length to ceil(n * ratio).  resampy / librosa are absent:
+    restated from the published algorithm (interpn.resample_f: sequential float64 time register, table + linear interpolation,
+    float32 output accumulated product by product) and filter parameters - parity unpinned."""
+    import math
+    x = np.asarray(x, np.float32)
+    ratio = float(sr_new) / sr_orig
+    num_zeros, num_table, beta, rolloff = 64, 512, 14.769656459379492, 0.9475937167399596
+    n = num_table * num_zeros
+    win = np.kaiser(2 * n + 1, beta)[n:] * (rolloff * np.sinc(rolloff * np.linspace(0, num_zeros, num=n + 1, endpoint=True)))
+    if ratio < 1:
+        win = win * ratio
+    delta = np.zeros_like(win)
+    delta[:-1] = np.diff(win)
+    n_out = int(len(x) * ratio)
+    y = np.zeros(n_out, np.float32)
+    scale = min(1.0, ratio)
+    inc = 1.0 / ratio
+    step = int(scale * num_table)
+    nwin, n_orig = len(win), len(x)
+    t_reg = 0.0
+    for t in range(n_out):
+        nn = int(t_reg)
+        frac = scale * (t_reg - nn)
+        idx = frac * num_table
+        off = int(idx)
+        eta = idx - off
+        acc = np.float32(0)
+        for i in range(min(nn + 1, (nwin - off) // step)):
+            acc = np.float32(acc + (win[off + i * step] + eta * delta[off + i * step]) * x[nn - i])
+        frac = scale - frac
+        idx = frac * num_table
+        off = int(idx)
+        eta = idx - off
+        for k in range(min(n_orig - nn - 1, (nwin - off) // step)):
+            acc = np.float32(acc + (win[off + k * step] + eta * delta[off + k * step]) * x[nn + k + 1])
+        y[t] = acc
+        t_reg += inc
+    want = int(math.ceil(len(x) * ratio))
+    return np.pad(y, (0, want - n_out)) if want > n_out else y[:want]

@@ -36,3 +36,19 @@ def test_log_mel_edge_cases():
     assert torch.isfinite(full).all()
     b = FE.log_mel_batch(torch.from_numpy(fill.uniform((3, 16000), 5, -0.5, 0.5)))
     assert b.shape == (3, 64, 101)
+
+
+def test_resample_oracle_sanity():
+    """oracle.frontend.resample_kaiser_best (resampy 0.2.2 restated, parity unpinned): length = ceil(n * ratio) as
+    librosa.resample fixes it, a tone keeps its frequency and (roll-off 0.95, pass band) its amplitude, energy above the new
+    Nyquist frequency is removed."""
+    import numpy as np
+    from oracle import frontend as FE
+    sr, n = 44100, 4410
+    t = np.arange(n) / sr
+    y = FE.resample_kaiser_best((0.5 * np.sin(2 * np.pi * 1000 * t)).astype(np.float32), sr, 16000)
+    assert y.shape == (1600,)
+    mid = y[200:-200]
+    assert abs(np.abs(mid).max() - 0.5) < 5e-3
+    hi = FE.resample_kaiser_best((0.5 * np.sin(2 * np.pi * 12000 * t)).astype(np.float32), sr, 16000)
+    assert np.abs(hi[200:-200]).max() < 5e-3
