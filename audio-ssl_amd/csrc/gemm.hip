@@ -1138,7 +1138,7 @@ extern "C" int audiossl_gemm_multi(int count, int trans_a, int trans_b, int M, c
     for (int i = 0; i < count; ++i) p8_ok = p8_ok && K[i] % GBK == 0 && (!trans_b || Nv[i] % 8 == 0);
     // multi-problem launches: measured wins for the transposed-A weight gradients of the three heads (2048 x 2048 x 1024:
     // 50.9 -> 43.9 us, x 512: 31.3 -> 29.0 us); NT / NN at M = 1024 stay on the 128-row kernels (44.5 vs 46.7 us)
-    if (p8 != 0 && p8_ok && (p8 == 1 || (trans_a && (long)ceil_div(M, 256) * ceil_div(N, 256) * count * ksplit >= 128 && kmin >= 512)))
+    if (p8 != 0 && p8 != 2 && p8_ok && (p8 == 1 || (trans_a && (long)ceil_div(M, 256) * ceil_div(N, 256) * count * ksplit >= 128 && kmin >= 512)))
         return dispatch_p8_multi(gm, count, ceil_div(M, 256) * ceil_div(N, 256), ksplit, trans_a, trans_b, s);
     static const int w8 = getenv("AUDIOSSL_GEMM_W8") ? atoi(getenv("AUDIOSSL_GEMM_W8")) : 0;
     if (w8 && M >= 256) MULTI(64, 2, 8, ceil_div(M, 256) * ceil_div(N, BN));
@@ -1172,7 +1172,8 @@ static int run_bf16(const GemmArgs& g, int trans_a, int trans_b, hipStream_t s) 
             while (t256 * ks * 2 <= 256 && K / (ks * 2) >= 1024) ks *= 2;
             ga.ksplit = ks;
         }
-        if (p8 == 1 || (t256 * ga.ksplit >= 128 && K / ga.ksplit >= 1024)) return dispatch_p8(ga, trans_a, trans_b, s);
+        const bool layout_ok = p8 != 2 || (!trans_a && !trans_b);            // AUDIOSSL_GEMM_P8=2: K-contiguous operands only
+        if (p8 == 1 || (layout_ok && t256 * ga.ksplit >= 128 && K / ga.ksplit >= 1024)) return dispatch_p8(ga, trans_a, trans_b, s);
     }
     // grids of >= 2 workgroups per CU with a K-contiguous A operand: K-step 32 and THREE co-resident workgroups per CU (41 KB
     // of LDS each, 126 VGPRs) - 12 waves per CU hide the staged-load and barrier waits better than two workgroups at K-step

@@ -142,17 +142,19 @@ GEMM_SYMBOL = {(0, 0): "NT", (0, 1): "NN", (1, 1): "TN", (1, 0): "TT"}
 
 def pmc_traffic(ta, tb):
     """HBM bytes per launch of the bf16 GEMM instantiations with these transposes, from the committed PMC passes
-    (profiles/r01_pmc_traffic.json, made by tools/pmc_summary.py; counters cannot be read live from inside the process)."""
+    (profiles/r02_pmc_traffic.json, made by tools/pmc_summary.py; counters cannot be read live from inside the process)."""
     import re
-    path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+    path = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
+    if not os.path.exists(path):
+        path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
     if not os.path.exists(path):
         return None
     tot, n = 0.0, 0
     for name, v in json.load(open(path))["kernels"].items():
-        if not any(k in name for k in ("gemm_kernel", "gemm_ring_kernel", "gemm_bk32_kernel")) or v["read_bytes_per_launch"] is None:
+        if not any(k in name for k in ("gemm_kernel", "gemm_ring_kernel", "gemm_bk32_kernel", "gemm_p8_kernel")) or v["read_bytes_per_launch"] is None:
             continue
         m = (re.search(r"gemm_kernelIDF16bLb(\d)ELb(\d)ELi\d+E", name) or re.search(r"gemm_ring_kernelILb(\d)ELb(\d)ELi\d+E", name)
-             or re.search(r"gemm_bk32_kernelILb(\d)ELb(\d)E", name))
+             or re.search(r"gemm_bk32_kernelILb(\d)ELb(\d)E", name) or re.search(r"gemm_p8_kernelILb(\d)ELb(\d)E", name))
         key = (int(m.group(1)), int(m.group(2))) if m else ((1, 1) if re.search(r"E, true, \d+(, \d+)*>", name) else None)
         d = re.search(r"gemm_(?:ring|bk32)_kernel<(false|true), (false|true)", name)    # demangled form of the ring / BK=32 kernels
         if d:

@@ -1,9 +1,9 @@
 #!/bin/bash
-# GPU box: the three rocprofv3 passes behind profiles/r01_* (kernel trace + stats; PMC FETCH_SIZE; PMC WRITE_SIZE - counters in
+# GPU box: the three rocprofv3 passes behind profiles/rNN_* (ROUND=r02 by default) (kernel trace + stats; PMC FETCH_SIZE; PMC WRITE_SIZE - counters in
 # their own runs, never combined with trace domains).  Run from the repo root: bash tools/collect_profiles.sh
 set -e
 R=${GRAFT_REPO_ROOT:-$(pwd)}
-O=$R/gpurun_out/prof_final
+O=$R/gpurun_out/prof_${ROUND:-r02}
 rm -rf $O; mkdir -p $O
 cd /tmp; export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -- python3 $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline > $O/trace.json 2> $O/trace.err
