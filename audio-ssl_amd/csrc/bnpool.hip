@@ -361,23 +361,29 @@ __global__ void add_stat_kernel(const float* __restrict__ stat, float* dgamma, f
 }
 }  // namespace
 
-extern "C" int audiossl_bn_relu_pool_bwd(int dtype, int ydtype, int gdtype, const void* Y, const void* dP, const void* dxl, const float* scale,
-                                         const float* shift, const float* mean, const float* rstd, float* stat, void* dY,
-                                         float* dgamma, float* dbeta, int N, int Ti, int Fi, void* stream) {
-    ASSL_REQUIRE(Y && dP && scale && shift && mean && rstd && stat && dY && dgamma && dbeta);
+// phase: 0 = everything (statistics, fold, apply, parameter gradients); 1 = statistics + fold only (stat[0..127] = this rank's
+// sum g / sum g xhat); 2 = apply with the sums in `gstat` over `count` elements (the all-reduced sums of SyncBatchNorm) and add
+// this rank's own sums (stat) to dgamma / dbeta
+static int bn_relu_pool_bwd_run(int phase, int dtype, int ydtype, int gdtype, const void* Y, const void* dP, const void* dxl,
+                                const float* scale, const float* shift, const float* mean, const float* rstd, float* stat,
+                                const float* gstat, double count, void* dY, float* dgamma, float* dbeta, int N, int Ti, int Fi,
+                                void* stream) {
+    ASSL_REQUIRE(Y && dP && scale && shift && mean && rstd && stat);
     ASSL_REQUIRE(N > 0 && Ti >= 2 && Fi >= 2 && (Fi % 2) == 0 && (dtype == 0 || dtype == 1) && (gdtype == 0 || gdtype == dtype));
     ASSL_REQUIRE(ydtype == 0 || ydtype == dtype);
+    ASSL_REQUIRE(phase == 1 || (dY && dgamma && dbeta));
     hipStream_t s = static_cast<hipStream_t>(stream);
-    ASSL_ZERO(stat, sizeof(float) * 128 * 33, s);
+    if (phase != 2) ASSL_ZERO(stat, sizeof(float) * 128 * 33, s);
     const long total = (long)N * ((Ti + 1) / 2) * (Fi / 2) * 8;
     const int grid = ceil_div(total, 256);
     const float inv_To = 1.f / (float)(Ti / 2);
-    const float inv_count = (float)(1.0 / ((double)N * Ti * Fi));
-#define BW(TY, AP, TG, TO) hipLaunchKernelGGL((bn_relu_pool_bwd_kernel<TY, AP, TG, TO>), dim3(grid), dim3(256), 0, s,              \
-        static_cast<const TY*>(Y), static_cast<const TG*>(dP), static_cast<const TG*>(dxl), inv_To, scale, shift, mean, rstd, stat, \
+    const float inv_count = (float)(1.0 / (phase == 2 ? count : (double)N * Ti * Fi));
+    float* apply_stat = phase == 2 ? const_cast<float*>(gstat) : stat;
+#define BW(TY, AP, TG, TO, ST) hipLaunchKernelGGL((bn_relu_pool_bwd_kernel<TY, AP, TG, TO>), dim3(grid), dim3(256), 0, s,              \
+        static_cast<const TY*>(Y), static_cast<const TG*>(dP), static_cast<const TG*>(dxl), inv_To, scale, shift, mean, rstd, ST, \
         inv_count, static_cast<TO*>(dY), N, Ti, Fi)
-#define BW2(TY, TG, TO) do { BW(TY, false, TG, TO); hipLaunchKernelGGL(stat_reduce_kernel, dim3(1), dim3(128), 0, s, stat); \
-                             BW(TY, true, TG, TO); } while (0)
+#define BW2(TY, TG, TO) do { if (phase != 2) { BW(TY, false, TG, TO, stat); hipLaunchKernelGGL(stat_reduce_kernel, dim3(1), dim3(128), 0, s, stat); } \
+                             if (phase != 1) BW(TY, true, TG, TO, apply_stat); } while (0)
     if (dtype == 0) BW2(float, float, float);
     else if (ydtype == 0 && gdtype == 0) BW2(float, float, bf16);
     else if (ydtype == 0) BW2(float, bf16, bf16);
@@ -385,8 +391,29 @@ extern "C" int audiossl_bn_relu_pool_bwd(int dtype, int ydtype, int gdtype, cons
     else BW2(bf16, bf16, bf16);
 #undef BW2
 #undef BW
-    hipLaunchKernelGGL(add_stat_kernel, dim3(1), dim3(64), 0, s, stat, dgamma, dbeta);
+    if (phase != 1) hipLaunchKernelGGL(add_stat_kernel, dim3(1), dim3(64), 0, s, stat, dgamma, dbeta);
     ASSL_LAUNCH_CHECK();
+}
+
+extern "C" int audiossl_bn_relu_pool_bwd(int dtype, int ydtype, int gdtype, const void* Y, const void* dP, const void* dxl, const float* scale,
+                                         const float* shift, const float* mean, const float* rstd, float* stat, void* dY,
+                                         float* dgamma, float* dbeta, int N, int Ti, int Fi, void* stream) {
+    return bn_relu_pool_bwd_run(0, dtype, ydtype, gdtype, Y, dP, dxl, scale, shift, mean, rstd, stat, nullptr, 0.0, dY, dgamma, dbeta, N,
+                                Ti, Fi, stream);
+}
+extern "C" int audiossl_bn_relu_pool_bwd_stats(int dtype, int ydtype, int gdtype, const void* Y, const void* dP, const void* dxl,
+                                               const float* scale, const float* shift, const float* mean, const float* rstd,
+                                               float* stat, int N, int Ti, int Fi, void* stream) {
+    return bn_relu_pool_bwd_run(1, dtype, ydtype, gdtype, Y, dP, dxl, scale, shift, mean, rstd, stat, nullptr, 0.0, nullptr, nullptr,
+                                nullptr, N, Ti, Fi, stream);
+}
+extern "C" int audiossl_bn_relu_pool_bwd_apply(int dtype, int ydtype, int gdtype, const void* Y, const void* dP, const void* dxl,
+                                               const float* scale, const float* shift, const float* mean, const float* rstd,
+                                               float* stat, const float* gstat, double count_global, void* dY, float* dgamma,
+                                               float* dbeta, int N, int Ti, int Fi, void* stream) {
+    ASSL_REQUIRE(gstat && count_global > 1.0);
+    return bn_relu_pool_bwd_run(2, dtype, ydtype, gdtype, Y, dP, dxl, scale, shift, mean, rstd, stat, gstat, count_global, dY, dgamma,
+                                dbeta, N, Ti, Fi, stream);
 }
 
 extern "C" int audiossl_im2col3x3(int dtype, const void* X, void* col, int N, int Ti, int Fi, void* stream) {

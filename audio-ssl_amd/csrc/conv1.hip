@@ -71,14 +71,14 @@ __global__ void conv1_finalize_kernel(double* __restrict__ momr, const float* __
                                       const float* __restrict__ bias, const float* __restrict__ gamma,
                                       const float* __restrict__ beta, float* running_mean, float* running_var,
                                       float momentum, float eps, double count, float* scale, float* shift,
-                                      float* save_mean, float* save_rstd) {
+                                      float* save_mean, float* save_rstd, int repl) {
     const int c = threadIdx.x;
     if (c >= 64) return;
     // fold the replicas into mom[0..53] (kept for the backward), then every channel reads the totals
     __shared__ double tot[NMOM];
     if (c < NMOM) {
         double t = 0.0;
-        for (int r = 0; r < MOM_REPL; ++r) t += momr[r * NMOM + c];
+        for (int r = 0; r < repl; ++r) t += momr[r * NMOM + c];
         tot[c] = t;
     }
     __syncthreads();
@@ -524,7 +524,7 @@ __global__ void conv1_bwd_finalize_kernel(const float* __restrict__ acc, const d
                                           const float* __restrict__ w, const float* __restrict__ bias,
                                           const float* __restrict__ gamma, const float* __restrict__ mean,
                                           const float* __restrict__ rstd, double count, float* dW, float* dbias,
-                                          float* dgamma, float* dbeta) {
+                                          float* dgamma, float* dbeta, const float* __restrict__ gstat, float* lstat) {
     const int c = threadIdx.x;
     if (c >= 64) return;
     double a11[11];
@@ -533,7 +533,10 @@ __global__ void conv1_bwd_finalize_kernel(const float* __restrict__ acc, const d
         for (int r = 0; r < 32; ++r) t += (double)acc[r * 704 + c * 11 + k];
         a11[k] = t;
     }
-    const double db = a11[9], dg = a11[10];
+    if (lstat) { lstat[c] = (float)a11[9]; lstat[64 + c] = (float)a11[10]; return; }     // sums only: this rank's (dbeta, dgamma)
+    // SyncBatchNorm: the two means of the BatchNorm backward are over the GLOBAL batch (gstat = all-reduced sums, count global);
+    // the parameter gradients and the tap sums stay this rank's own
+    const double db = gstat ? (double)gstat[c] : a11[9], dg = gstat ? (double)gstat[64 + c] : a11[10];
     const double rs = rstd[c], mu = mean[c], gm = gamma[c];
     for (int t = 0; t < 9; ++t) {
         double wS2 = 0.0;
@@ -542,8 +545,8 @@ __global__ void conv1_bwd_finalize_kernel(const float* __restrict__ acc, const d
         const double v = gm * rs * (a11[t] - db / count * mom[t] - dg / count * yhat_x);
         dW[c * 9 + t] += (float)v;
     }
-    dgamma[c] += (float)dg;
-    dbeta[c] += (float)db;
+    dgamma[c] += (float)a11[10];
+    dbeta[c] += (float)a11[9];
     (void)dbias;            // d(conv bias) is identically zero under train-mode BN
 }
 
@@ -564,7 +567,40 @@ extern "C" int audiossl_conv1_stats(const float* img, int N, int F, int T, const
     const int grid = (int)min((long)mom_grid, (total + 255) / 256);
     hipLaunchKernelGGL(conv1_moments_kernel, dim3(grid), dim3(256), 0, s, img, mom, N, F, T);
     hipLaunchKernelGGL(conv1_finalize_kernel, dim3(1), dim3(64), 0, s, mom, w, bias, gamma, beta, running_mean,
-                       running_var, momentum, eps, (double)total, scale, shift, save_mean, save_rstd);
+                       running_var, momentum, eps, (double)total, scale, shift, save_mean, save_rstd, MOM_REPL);
+    ASSL_LAUNCH_CHECK();
+}
+
+// ---- the same in two halves, for statistics that are exchanged between ranks in between (SyncBatchNorm of the
+// DeepCluster-v2 trainer, extras/decar-v2/main.py:82): conv1_moments leaves this rank's 54 tap-moment totals in mom[0..53];
+// conv1_finalize turns (all-reduced) totals and the GLOBAL element count into scale / shift / mean / rstd + running buffers.
+__global__ void conv1_fold_kernel(double* __restrict__ momr) {
+    __shared__ double tot[NMOM];
+    const int c = threadIdx.x;
+    if (c < NMOM) {
+        double t = 0.0;
+        for (int r = 0; r < MOM_REPL; ++r) t += momr[r * NMOM + c];
+        tot[c] = t;
+    }
+    __syncthreads();
+    if (c < NMOM) momr[c] = tot[c];
+}
+extern "C" int audiossl_conv1_moments(const float* img, int N, int F, int T, double* mom, void* stream) {
+    ASSL_REQUIRE(img && mom && N > 0 && F >= 2 && T >= 2 && (long)N * F * T < 0x7FFFFFFFL - 0x1000000L);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    ASSL_ZERO(mom, sizeof(double) * NMOM * MOM_REPL, s);
+    const long total = (long)N * F * T;
+    const int grid = (int)min((long)1024, (total + 255) / 256);
+    hipLaunchKernelGGL(conv1_moments_kernel, dim3(grid), dim3(256), 0, s, img, mom, N, F, T);
+    hipLaunchKernelGGL(conv1_fold_kernel, dim3(1), dim3(64), 0, s, mom);
+    ASSL_LAUNCH_CHECK();
+}
+extern "C" int audiossl_conv1_finalize(double* mom_totals, const float* w, const float* bias, const float* gamma, const float* beta,
+                                       float* running_mean, float* running_var, float momentum, float eps, double count,
+                                       float* scale, float* shift, float* save_mean, float* save_rstd, void* stream) {
+    ASSL_REQUIRE(mom_totals && w && bias && gamma && beta && scale && shift && save_mean && save_rstd && count > 1.0);
+    hipLaunchKernelGGL(conv1_finalize_kernel, dim3(1), dim3(64), 0, static_cast<hipStream_t>(stream), mom_totals, w, bias, gamma, beta,
+                       running_mean, running_var, momentum, eps, count, scale, shift, save_mean, save_rstd, 1);
     ASSL_LAUNCH_CHECK();
 }
 
@@ -588,11 +624,11 @@ extern "C" int audiossl_conv1_fwd(int dtype, const float* img, int N, int F, int
 }
 
 // acc: 32*64*11 floats of scratch (zeroed here).  dxl may be null.  Grad outputs are accumulated (+=).
-extern "C" int audiossl_conv1_bwd(int dtype, int conv_dtype, const float* img, int N, int F, int T, const float* w, const float* bias,
+static int conv1_bwd_main(int dtype, int conv_dtype, const float* img, int N, int F, int T, const float* w, const float* bias,
                                   const float* gamma, const float* scale, const float* shift, const float* mean,
                                   const float* rstd, const double* mom, const void* dP, const void* dxl, float* acc,
-                                  float* dW, float* dbias, float* dgamma, float* dbeta, void* stream) {
-    ASSL_REQUIRE(img && w && bias && gamma && scale && shift && mean && rstd && mom && dP && acc && dW && dgamma && dbeta);
+                                  void* stream) {
+    ASSL_REQUIRE(img && w && bias && gamma && scale && shift && mean && rstd && mom && dP && acc);
     ASSL_REQUIRE(N > 0 && F >= 2 && F <= 64 && T >= 2 && (F % 2) == 0 && (dtype == 0 || dtype == 1));
     ASSL_REQUIRE(conv_dtype == 0 || (conv_dtype == 1 && dtype == 0));     // the MFMA recompute takes fp32 gradients
     hipStream_t s = static_cast<hipStream_t>(stream);
@@ -613,7 +649,39 @@ extern "C" int audiossl_conv1_bwd(int dtype, int conv_dtype, const float* img, i
     else
         hipLaunchKernelGGL(conv1_bwd_kernel<bf16>, dim3(grid), dim3(256), lds, s, img, w, bias, scale, shift, mean, rstd,
                            static_cast<const bf16*>(dP), static_cast<const bf16*>(dxl), inv_To, acc, N, F, T);
-    hipLaunchKernelGGL(conv1_bwd_finalize_kernel, dim3(1), dim3(64), 0, s, acc, mom, w, bias, gamma, mean, rstd,
-                       (double)N * F * T, dW, dbias, dgamma, dbeta);
+    return ASSL_OK;
+}
+
+extern "C" int audiossl_conv1_bwd(int dtype, int conv_dtype, const float* img, int N, int F, int T, const float* w, const float* bias,
+                                  const float* gamma, const float* scale, const float* shift, const float* mean,
+                                  const float* rstd, const double* mom, const void* dP, const void* dxl, float* acc,
+                                  float* dW, float* dbias, float* dgamma, float* dbeta, void* stream) {
+    ASSL_REQUIRE(dW && dgamma && dbeta);
+    const int rc = conv1_bwd_main(dtype, conv_dtype, img, N, F, T, w, bias, gamma, scale, shift, mean, rstd, mom, dP, dxl, acc, stream);
+    if (rc != ASSL_OK) return rc;
+    hipLaunchKernelGGL(conv1_bwd_finalize_kernel, dim3(1), dim3(64), 0, static_cast<hipStream_t>(stream), acc, mom, w, bias, gamma, mean,
+                       rstd, (double)N * F * T, dW, dbias, dgamma, dbeta, (const float*)nullptr, (float*)nullptr);
+    ASSL_LAUNCH_CHECK();
+}
+
+// SyncBatchNorm halves: conv1_bwd_sums = the gradient kernel + this rank's (sum g, sum g xhat) per channel in lstat [2][64];
+// conv1_bwd_finalize = weight / BatchNorm gradients from the rank's own sums with the GLOBAL means (gstat = all-reduced lstat).
+extern "C" int audiossl_conv1_bwd_sums(int dtype, int conv_dtype, const float* img, int N, int F, int T, const float* w,
+                                       const float* bias, const float* gamma, const float* scale, const float* shift,
+                                       const float* mean, const float* rstd, const double* mom, const void* dP, const void* dxl,
+                                       float* acc, float* lstat, void* stream) {
+    ASSL_REQUIRE(lstat);
+    const int rc = conv1_bwd_main(dtype, conv_dtype, img, N, F, T, w, bias, gamma, scale, shift, mean, rstd, mom, dP, dxl, acc, stream);
+    if (rc != ASSL_OK) return rc;
+    hipLaunchKernelGGL(conv1_bwd_finalize_kernel, dim3(1), dim3(64), 0, static_cast<hipStream_t>(stream), acc, mom, w, bias, gamma, mean,
+                       rstd, 1.0, (float*)nullptr, (float*)nullptr, (float*)nullptr, (float*)nullptr, (const float*)nullptr, lstat);
+    ASSL_LAUNCH_CHECK();
+}
+extern "C" int audiossl_conv1_bwd_finalize(const float* acc, const double* mom, const float* w, const float* bias, const float* gamma,
+                                           const float* mean, const float* rstd, double count_global, const float* gstat, float* dW,
+                                           float* dbias, float* dgamma, float* dbeta, void* stream) {
+    ASSL_REQUIRE(acc && mom && w && bias && gamma && mean && rstd && gstat && dW && dgamma && dbeta && count_global > 1.0);
+    hipLaunchKernelGGL(conv1_bwd_finalize_kernel, dim3(1), dim3(64), 0, static_cast<hipStream_t>(stream), acc, mom, w, bias, gamma, mean,
+                       rstd, count_global, dW, dbias, dgamma, dbeta, gstat, (float*)nullptr);
     ASSL_LAUNCH_CHECK();
 }

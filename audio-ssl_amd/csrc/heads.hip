@@ -136,7 +136,7 @@ __global__ __launch_bounds__(256) void colbn_bwd_apply_kernel(const TA* __restri
                                                               const float* __restrict__ mean, const float* __restrict__ rstd,
                                                               int relu, long M, int C, int groups, const double* __restrict__ sg,
                                                               const double* __restrict__ sgx, T_* __restrict__ da,
-                                                              float* dgamma, float* dbeta) {
+                                                              float* dgamma, float* dbeta, float invM) {
     const long idx = (long)blockIdx.x * 256 + threadIdx.x;
     const int C8 = C / 8;
     if (idx >= (long)groups * M * C8) return;
@@ -160,7 +160,6 @@ __global__ __launch_bounds__(256) void colbn_bwd_apply_kernel(const TA* __restri
         dsg[i] = p.x; dsg[i + 1] = p.y; dsx[i] = q.x; dsx[i + 1] = q.y;
     }
     Vec8<T_> o;
-    const float invM = 1.f / (float)M;
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
         const int c = c8 * 8 + i;
@@ -765,13 +764,56 @@ extern "C" int audiossl_colbn_bwd(int dtype, int adtype, int gdtype, const void*
     hipLaunchKernelGGL((colbn_bwd_stats_kernel<TA, TG>), grid, dim3(256), 0, s, (const TA*)a, (const TG*)dh, scale, shift, mean, rstd,  \
                        relu, M, C, rpb, tmp, tmp + GC);                                                                               \
     hipLaunchKernelGGL((colbn_bwd_apply_kernel<TA, TG, TO>), GRID1(total), dim3(256), 0, s, (const TA*)a, (const TG*)dh, scale, shift,  \
-                       mean, rstd, relu, M, C, groups, tmp, tmp + GC, (TO*)da, dgamma, dbeta); } while (0)
+                       mean, rstd, relu, M, C, groups, tmp, tmp + GC, (TO*)da, dgamma, dbeta, 1.f / (float)M); } while (0)
     if (dtype == 0) CB(float, float, float);
     else if (adtype == 0 && gdtype == 0) CB(float, float, bf16);
     else if (adtype == 0) CB(float, bf16, bf16);
     else if (gdtype == 0) CB(bf16, float, bf16);
     else CB(bf16, bf16, bf16);
 #undef CB
+    ASSL_LAUNCH_CHECK();
+}
+
+// The same backward in two halves for SyncBatchNorm (statistics exchanged between ranks in between): colbn_bwd_stats leaves this
+// rank's sum g / sum g xhat in tmp [2][G*C] (fp64); colbn_bwd_apply computes da from (all-reduced) sums over `count` rows and takes
+// no parameter gradients (the caller adds its own rank's sums to dgamma / dbeta with add_d2f).
+extern "C" int audiossl_colbn_bwd_stats(int dtype, int adtype, int gdtype, const void* a, const void* dh, const float* scale,
+                                        const float* shift, const float* mean, const float* rstd, int relu, int groups, long M, int C,
+                                        double* tmp, void* stream) {
+    ASSL_REQUIRE(a && dh && scale && shift && mean && rstd && tmp && groups > 0 && M > 0 && C > 0 && (C % 64) == 0);
+    ASSL_REQUIRE((dtype == 0 || dtype == 1) && (gdtype == 0 || gdtype == dtype) && (adtype == 0 || adtype == dtype));
+    hipStream_t s = S_(stream);
+    ASSL_ZERO(tmp, sizeof(double) * 2 * C * groups, s);
+    const int rpb = M >= 4096 ? 256 : 64;
+    dim3 grid(ceil_div(M, rpb), C / 64, groups);
+    const long GC = (long)groups * C;
+#define CS(TA, TG) hipLaunchKernelGGL((colbn_bwd_stats_kernel<TA, TG>), grid, dim3(256), 0, s, (const TA*)a, (const TG*)dh, scale, shift, \
+                                      mean, rstd, relu, M, C, rpb, tmp, tmp + GC)
+    if (dtype == 0 || (adtype == 0 && gdtype == 0)) CS(float, float);
+    else if (adtype == 0) CS(float, bf16);
+    else if (gdtype == 0) CS(bf16, float);
+    else CS(bf16, bf16);
+#undef CS
+    ASSL_LAUNCH_CHECK();
+}
+extern "C" int audiossl_colbn_bwd_apply(int dtype, int adtype, int gdtype, const void* a, const void* dh, const float* scale,
+                                        const float* shift, const float* mean, const float* rstd, int relu, int groups, long M, int C,
+                                        const double* sums, double count, void* da, void* stream) {
+    ASSL_REQUIRE(a && dh && scale && shift && mean && rstd && sums && da && groups > 0 && M > 0 && C > 0 && (C % 64) == 0 && count > 1.0);
+    ASSL_REQUIRE((dtype == 0 || dtype == 1) && (gdtype == 0 || gdtype == dtype) && (adtype == 0 || adtype == dtype));
+    hipStream_t s = S_(stream);
+    const long total = groups * M * C / 8;
+    const long GC = (long)groups * C;
+    const float inv = (float)(1.0 / count);
+#define CA(TA, TG, TO) hipLaunchKernelGGL((colbn_bwd_apply_kernel<TA, TG, TO>), GRID1(total), dim3(256), 0, s, (const TA*)a, (const TG*)dh, \
+                                          scale, shift, mean, rstd, relu, M, C, groups, sums, sums + GC, (TO*)da, (float*)nullptr,          \
+                                          (float*)nullptr, inv)
+    if (dtype == 0) CA(float, float, float);
+    else if (adtype == 0 && gdtype == 0) CA(float, float, bf16);
+    else if (adtype == 0) CA(float, bf16, bf16);
+    else if (gdtype == 0) CA(bf16, float, bf16);
+    else CA(bf16, bf16, bf16);
+#undef CA
     ASSL_LAUNCH_CHECK();
 }
 

@@ -155,6 +155,28 @@ def set_high_precision(flag):
     HP = bool(flag)
 
 
+# SyncBatchNorm (`nn.SyncBatchNorm.convert_sync_batchnorm`, extras/decar-v2/main.py:82): when set, every train-mode BatchNorm of
+# the encoder / BatchNorm1dFn exchanges its sums between the ranks (one small all-reduce per layer and direction) and normalises
+# with the statistics of the GLOBAL batch.  Eager steps only (a collective cannot sit inside a captured graph).
+SYNC_BN = None
+
+
+class SyncBN:
+    def __init__(self, group=None):
+        import torch.distributed as dist
+        self.dist, self.group = dist, group
+        self.world = dist.get_world_size(group)
+
+    def all_reduce(self, t):
+        self.dist.all_reduce(t, group=self.group)
+        return t
+
+
+def set_sync_bn(sync):
+    global SYNC_BN
+    SYNC_BN = sync if (sync is not None and sync.world > 1) else None
+
+
 def _ad(dtype):
     """storage type of BatchNorm inputs"""
     return N.F32 if (HP or dtype == N.F32) else dtype
@@ -201,6 +223,9 @@ def _bn_train(dtype, Y, M, C, gamma, beta, rm, rv, update_running, groups=1):
     """Batch statistics of Y [groups][M][C] -> per-group (scale, shift, mean, rstd), each [groups*C]."""
     sq = ARENA.scratch((2, groups * C), torch.float64, Y)
     N.call("colstats", dtype, Y, groups, M, C, C, 1, sq[0], sq[1])
+    if SYNC_BN is not None:
+        SYNC_BN.all_reduce(sq)
+        M = M * SYNC_BN.world
     st = _empty((4, groups * C), torch.float32, like=Y)
     N.call("bn_finalize", sq[0], sq[1], groups, float(M), C, gamma, beta, rm if update_running else None,
            rv if update_running else None, BN_MOMENTUM, BN_EPS, st[0], st[1], st[2], st[3])
@@ -210,7 +235,7 @@ def _bn_train(dtype, Y, M, C, gamma, beta, rm, rv, update_running, groups=1):
 def bn_train_apply(dtype, ad, a, M, C, gamma, beta, rm, rv, update_running, groups, relu, out):
     """Train-mode BatchNorm1d of a [groups][M][C] (+ReLU) -> out; returns (scale, shift, mean, rstd).  One fused launch for
     the short projector batches, colstats -> bn_finalize -> colbn_fwd otherwise."""
-    if M <= 1024 and C % 32 == 0 and _BN_FUSED:
+    if M <= 1024 and C % 32 == 0 and _BN_FUSED and SYNC_BN is None:
         st = _empty((4, groups * C), torch.float32, like=a)
         N.call("colbn_train_fwd", dtype, ad, a, gamma, beta, rm if update_running else None, rv if update_running else None,
                BN_MOMENTUM, BN_EPS, relu, groups, M, C, out, st[0], st[1], st[2], st[3])
@@ -259,6 +284,9 @@ def _conv_block_fwd(dtype, Pin, Nimg, Ti, Fi, W, bias, bn, train, update_running
         gemm(dtype, 0, 0, M, 64, 576, col, 576, Wf, 576, Y, 64, bias=bias, out_f32=int(ad == N.F32))
     if train and fused:
         st = _empty((4, 64), torch.float32, like=Pin)
+        if SYNC_BN is not None:
+            SYNC_BN.all_reduce(sq)
+            M = M * SYNC_BN.world
         N.call("bn_finalize", sq[0], sq[1], 1, float(M), 64, gamma, beta, rm if update_running else None,
                rv if update_running else None, BN_MOMENTUM, BN_EPS, st[0], st[1], st[2], st[3])
         scale, shift, mean, rstd = st[0], st[1], st[2], st[3]
@@ -300,9 +328,15 @@ def encoder_forward(P, x, dtype, keep=None, p_drop=0.3, train=True, update_runni
     if train:
         c.mom1 = ARENA.scratch((16 * 54,), torch.float64, x)         # 16 replicas of the 54 tap moments; totals end up in [0:54]
         c.sc1, c.sh1, c.mean1, c.rstd1 = (_empty((64,), torch.float32, like=x) for _ in range(4))
-        N.call("conv1_stats", img, Nimg, F, T, w1, b1, g1, be1, P["features_1.1.running_mean"] if update_running else None,
-               P["features_1.1.running_var"] if update_running else None, BN_MOMENTUM, BN_EPS, c.mom1, c.sc1, c.sh1, c.mean1,
-               c.rstd1)
+        rm1 = P["features_1.1.running_mean"] if update_running else None
+        rv1 = P["features_1.1.running_var"] if update_running else None
+        if SYNC_BN is None:
+            N.call("conv1_stats", img, Nimg, F, T, w1, b1, g1, be1, rm1, rv1, BN_MOMENTUM, BN_EPS, c.mom1, c.sc1, c.sh1, c.mean1, c.rstd1)
+        else:                                     # this rank's tap moments stay in c.mom1 (the backward needs the local sums)
+            N.call("conv1_moments", img, Nimg, F, T, c.mom1)
+            mom_g = SYNC_BN.all_reduce(c.mom1[:54].clone())
+            N.call("conv1_finalize", mom_g, w1, b1, g1, be1, rm1, rv1, BN_MOMENTUM, BN_EPS, float(Nimg * F * T * SYNC_BN.world),
+                   c.sc1, c.sh1, c.mean1, c.rstd1)
     else:
         c.sc1, c.sh1 = _bn_eval(x, 64, g1, be1, P["features_1.1.running_mean"], P["features_1.1.running_var"])
     T1, F1 = T // 2, F // 2
@@ -353,7 +387,14 @@ def _conv_block_bwd(dtype, Y, dP, dxl, st, Nimg, Ti, Fi, Pin, Wd, G_w, G_gamma, 
     M = Nimg * Ti * Fi
     dY = torch.empty((M, 64), dtype=td, device=Y.device)
     stat = ARENA.scratch((33 * 128,), torch.float32, Y)
-    N.call("bn_relu_pool_bwd", dtype, N.F32 if Y.dtype == torch.float32 else dtype, GD, Y, dP, dxl, scale, shift, mean, rstd, stat, dY, G_gamma, G_beta, Nimg, Ti, Fi)
+    yd = N.F32 if Y.dtype == torch.float32 else dtype
+    if SYNC_BN is None:
+        N.call("bn_relu_pool_bwd", dtype, yd, GD, Y, dP, dxl, scale, shift, mean, rstd, stat, dY, G_gamma, G_beta, Nimg, Ti, Fi)
+    else:
+        N.call("bn_relu_pool_bwd_stats", dtype, yd, GD, Y, dP, dxl, scale, shift, mean, rstd, stat, Nimg, Ti, Fi)
+        gstat = SYNC_BN.all_reduce(stat[:128].clone())
+        N.call("bn_relu_pool_bwd_apply", dtype, yd, GD, Y, dP, dxl, scale, shift, mean, rstd, stat, gstat, float(M * SYNC_BN.world), dY,
+               G_gamma, G_beta, Nimg, Ti, Fi)
     # wgrad: dWp[co][tap*64+ci] = sum_pix dY[pix][co] * Pin[pix + off(tap)][ci]
     fused = dtype == N.BF16 and Fi in (16, 32)
     if fused:
@@ -416,9 +457,18 @@ def encoder_backward(c, G, dA2=None, dH2=None, dx1=None, dx2=None, dx3=None):
                           G["features_2.1.weight"], G["features_2.1.bias"], True, col, keep)
     acc = ARENA.scratch((32 * 64 * 11,), torch.float32, c.H2)
     P = c.P
-    N.call("conv1_bwd", GD, int(c.stem_mfma), c.img, Nimg, c.F, c.T, P["features_1.0.weight"].reshape(64, 9), P["features_1.0.bias"],
-           P["features_1.1.weight"], c.sc1, c.sh1, c.mean1, c.rstd1, c.mom1, dP1, dx1, acc,
-           G["features_1.0.weight"].view(64, 9), G["features_1.0.bias"], G["features_1.1.weight"], G["features_1.1.bias"])
+    w1, b1, g1 = P["features_1.0.weight"].reshape(64, 9), P["features_1.0.bias"], P["features_1.1.weight"]
+    gw, gb = G["features_1.0.weight"].view(64, 9), G["features_1.0.bias"]
+    if SYNC_BN is None:
+        N.call("conv1_bwd", GD, int(c.stem_mfma), c.img, Nimg, c.F, c.T, w1, b1, g1, c.sc1, c.sh1, c.mean1, c.rstd1, c.mom1, dP1, dx1,
+               acc, gw, gb, G["features_1.1.weight"], G["features_1.1.bias"])
+    else:
+        lstat = _empty((128,), torch.float32, like=c.H2)
+        N.call("conv1_bwd_sums", GD, int(c.stem_mfma), c.img, Nimg, c.F, c.T, w1, b1, g1, c.sc1, c.sh1, c.mean1, c.rstd1, c.mom1, dP1,
+               dx1, acc, lstat)
+        gstat = SYNC_BN.all_reduce(lstat.clone())
+        N.call("conv1_bwd_finalize", acc, c.mom1, w1, b1, g1, c.mean1, c.rstd1, float(Nimg * c.F * c.T * SYNC_BN.world), gstat, gw, gb,
+               G["features_1.1.weight"], G["features_1.1.bias"])
     WGRAD.join(dev)            # dA2 / dA1 / dY* stay referenced until the side stream is ordered before us
 
 
@@ -504,6 +554,8 @@ def projector_forward(PP, Y, dtype, groups, B, update_running=True, Wc=None):
 def projector_backward(c, PP, G, dzn, dy_rows=None):
     """dzn [groups*B, D] (activation dtype) -> accumulates projector grads into G; returns dY for the first `dy_rows`
     rows of the stacked input (None: all rows, 0: skip)."""
+    if SYNC_BN is not None:
+        raise NotImplementedError("SyncBatchNorm is wired for the encoder and BatchNorm1dFn (DeepCluster-v2), not for the Barlow projector")
     dtype, B, D, kin, groups = c.dtype, c.B, c.D, c.kin, c.groups
     M = groups * B
     td = N.torch_dtype(dtype)

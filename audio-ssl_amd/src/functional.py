@@ -145,6 +145,13 @@ class BatchNorm1dFn(torch.autograd.Function):
         da = torch.empty(M, C, dtype=N.torch_dtype(dtype), device=a.device)
         dgamma = torch.zeros(C, dtype=torch.float32, device=a.device)
         dbeta = torch.zeros(C, dtype=torch.float32, device=a.device)
-        N.call("colbn_bwd", dtype, N.F32, N.F32, a, dh.float().contiguous(), scale, shift, mean, rstd, relu, 1, M, C, tmp, da,
-               dgamma, dbeta)
+        g = dh.float().contiguous()
+        if E.SYNC_BN is None:
+            N.call("colbn_bwd", dtype, N.F32, N.F32, a, g, scale, shift, mean, rstd, relu, 1, M, C, tmp, da, dgamma, dbeta)
+        else:                                    # SyncBatchNorm: the two backward means are over the global batch
+            N.call("colbn_bwd_stats", dtype, N.F32, N.F32, a, g, scale, shift, mean, rstd, relu, 1, M, C, tmp)
+            tg = E.SYNC_BN.all_reduce(tmp.clone())
+            N.call("colbn_bwd_apply", dtype, N.F32, N.F32, a, g, scale, shift, mean, rstd, relu, 1, M, C, tg, float(M * E.SYNC_BN.world), da)
+            N.call("add_d2f", tmp[:C], dbeta, C)
+            N.call("add_d2f", tmp[C:], dgamma, C)
         return da.float(), dgamma, dbeta, None, None, None, None, None

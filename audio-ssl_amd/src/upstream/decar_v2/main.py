@@ -4,8 +4,10 @@ config 3), one process per GPU.
 What the reference does per rank and what is done here:
   * model `AudioNTT2020(args, feat_dim, n_mels=64, d=2048)` wrapped in SyncBatchNorm + DistributedDataParallel (`main.py:80-84`)
     -> the HIP model of `decar_v2.model`, parameters in one flat buffer, gradients averaged over ranks with ONE all-reduce of
-    the flat gradient per step (RCCL; 1/world folded into the optimiser launch).  BatchNorm statistics stay per rank (like
-    the `src/` Lightning path): the SyncBN statistics exchange is not built.
+    the flat gradient per step (RCCL; 1/world folded into the optimiser launch) and SyncBatchNorm as a statistics exchange
+    (`engine.SyncBN`): every train-mode BatchNorm - three BatchNorm2d of the encoder, the BatchNorm1d of the projection
+    head - all-reduces its sums (54 tap moments / 2 x 64 / 2 x 2048 doubles forward, 2 x C sums backward) and normalises with the
+    global batch; `sync_bn=False` keeps per-rank statistics.
   * SGD(momentum 0.9, wd 1e-6) inside apex LARC(trust 0.001, clip False) (`main.py:92-97, 111`) -> `HipLARC`.
   * `lr_schedule` = 10 warm-up epochs + cosine (`main.py:118-122`).  The reference builds it, hands it to `train` and never
     applies it (its optimiser runs at base_lr throughout); `apply_lr_schedule=True` applies it per iteration as the SwAV
@@ -59,10 +61,12 @@ class ShardedBatches:
             yield torch.from_numpy(ids), torch.stack([self.get(int(i)) for i in ids])
 
 
-def run(args, n_items, get_wave, front_end, device=None, max_iters=None, log=print):
+def run(args, n_items, get_wave, front_end, device=None, max_iters=None, log=print, sync_bn=True):
     """Train for `args.epochs` epochs (or `max_iters` iterations).  front_end(waves[B, L] on the device) -> (view1, view2).
     -> (state, history of (iteration, loss))."""
     rank, world = _world()
+    from src import engine as E
+    E.set_sync_bn(E.SyncBN() if (sync_bn and world > 1) else None)
     device = device or torch.device("cuda", torch.cuda.current_device())
     torch.manual_seed(args.seed)
     np.random.seed(args.seed)

@@ -131,6 +131,37 @@ int audiossl_tmean_fwd(int dtype, int out_f32, const void* P, void* xl, int N, i
 int audiossl_bn_relu_pool_bwd(int dtype, int ydtype, int gdtype, const void* Y, const void* dP, const void* dxl, const float* scale,
                               const float* shift, const float* mean, const float* rstd, float* stat, void* dY,
                               float* dgamma, float* dbeta, int N, int Ti, int Fi, void* stream);
+/* ---- SyncBatchNorm halves (C2: `nn.SyncBatchNorm.convert_sync_batchnorm`, extras/decar-v2/main.py:82).  Every train-mode
+ * BatchNorm of the path exists as "sums" + "finalize / apply" with the rank's sums in plain buffers in between, so the caller can
+ * all-reduce them (RCCL) and pass the GLOBAL element count:
+ *   forward : conv1_moments -> [all-reduce mom[0..53]] -> conv1_finalize;  conv3x3_fwd's sum / sumsq or colstats -> [all-reduce]
+ *             -> bn_finalize(count = global)
+ *   backward: bn_relu_pool_bwd_stats -> [all-reduce stat[0..127]] -> bn_relu_pool_bwd_apply;  conv1_bwd_sums -> [all-reduce lstat]
+ *             -> conv1_bwd_finalize;  colbn_bwd_stats -> [all-reduce tmp] -> colbn_bwd_apply (+ add_d2f of the rank's own sums).
+ * Parameter gradients always come from the rank's own sums (the data-parallel gradient all-reduce sums them afterwards). */
+int audiossl_conv1_moments(const float* img, int N, int F, int T, double* mom, void* stream);
+int audiossl_conv1_finalize(double* mom_totals, const float* w, const float* bias, const float* gamma, const float* beta,
+                            float* running_mean, float* running_var, float momentum, float eps, double count, float* scale,
+                            float* shift, float* save_mean, float* save_rstd, void* stream);
+int audiossl_conv1_bwd_sums(int dtype, int conv_dtype, const float* img, int N, int F, int T, const float* w, const float* bias,
+                            const float* gamma, const float* scale, const float* shift, const float* mean, const float* rstd,
+                            const double* mom, const void* dP, const void* dxl, float* acc, float* lstat, void* stream);
+int audiossl_conv1_bwd_finalize(const float* acc, const double* mom, const float* w, const float* bias, const float* gamma,
+                                const float* mean, const float* rstd, double count_global, const float* gstat, float* dW,
+                                float* dbias, float* dgamma, float* dbeta, void* stream);
+int audiossl_bn_relu_pool_bwd_stats(int dtype, int ydtype, int gdtype, const void* Y, const void* dP, const void* dxl,
+                                    const float* scale, const float* shift, const float* mean, const float* rstd, float* stat,
+                                    int N, int Ti, int Fi, void* stream);
+int audiossl_bn_relu_pool_bwd_apply(int dtype, int ydtype, int gdtype, const void* Y, const void* dP, const void* dxl,
+                                    const float* scale, const float* shift, const float* mean, const float* rstd, float* stat,
+                                    const float* gstat, double count_global, void* dY, float* dgamma, float* dbeta, int N, int Ti,
+                                    int Fi, void* stream);
+int audiossl_colbn_bwd_stats(int dtype, int adtype, int gdtype, const void* a, const void* dh, const float* scale,
+                             const float* shift, const float* mean, const float* rstd, int relu, int groups, long M, int C,
+                             double* tmp, void* stream);
+int audiossl_colbn_bwd_apply(int dtype, int adtype, int gdtype, const void* a, const void* dh, const float* scale,
+                             const float* shift, const float* mean, const float* rstd, int relu, int groups, long M, int C,
+                             const double* sums, double count, void* da, void* stream);
 int audiossl_im2col3x3(int dtype, const void* X, void* col, int N, int Ti, int Fi, void* stream);
 int audiossl_pack_conv_w(int dtype, const float* W, void* Wf, void* Wd, void* stream);
 int audiossl_unpack_conv_dw(const float* dWp, float* dW, void* stream);

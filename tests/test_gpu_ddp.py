@@ -161,3 +161,82 @@ def test_two_rank_deepcluster_v2_harness_keeps_replicas_identical():
     assert r0["shard"].tolist()[:48] == list(range(48)) and r1["shard"].tolist()[:48] == list(range(64, 112))   # 3 x 16 clips each
     assert 0 < r0["lr"] < 0.3                                       # warm-up value of iteration 2, not base_lr
     np.testing.assert_allclose(np.linalg.norm(r0["w"]["prototypes.prototypes0.weight"], axis=1), 1.0, rtol=1e-4)
+
+
+def _decar_syncbn_step(world, rank, prec="fp32"):
+    """One forward / backward of the DeepCluster-v2 model on this rank's slice of a fixed 16-clip batch -> numpy results."""
+    import types
+    from oracle import fill
+    from helpers import drop_mask, views
+    from src import _native as N
+    from src import engine as E
+    from src.flat import FlatGroup
+    from src.upstream.decar_v2.kmeans import prototype_cross_entropy
+    from src.upstream.decar_v2.model import AudioNTT2020
+    B, T, K = 16, 96, 32
+    args = types.SimpleNamespace(nmb_prototypes=[K], prototype_sizes=[K], crops_for_assign=[0])
+    m = AudioNTT2020(args, 512, n_mels=64, d=2048, nmb_prototypes=[K])
+    fill.fill_state_dict_(m, seed=41)
+    m = m.cuda().train()
+    m.precision = {"fp32": N.F32, "bf16": N.BF16}[prec]
+    named = [(n, p) for n, p in m.named_parameters()]
+    flat = FlatGroup(named)
+    flat.zero_grad()
+    flat.attach_grads()
+    lo, hi = rank * (B // world), (rank + 1) * (B // world)
+    x1, x2 = views(B, T, 9900)[lo:hi].cuda(), views(B, T, 9901)[lo:hi].cuda()
+    m.dropout_masks.queue = [drop_mask((B, T // 8, 2048), 9902)[lo:hi], drop_mask((B, T // 8, 2048), 9903)[lo:hi]]
+    tgt = torch.from_numpy((fill.uniform01((B,), 9904) * K).astype(np.int64))[lo:hi].cuda()
+    E.set_sync_bn(E.SyncBN() if world > 1 else None)
+    try:
+        emb, scores = m([x1, x2])
+        loss = prototype_cross_entropy(scores[0], tgt)
+        loss.backward()
+        if world > 1:
+            dist.all_reduce(flat.grad)
+            flat.grad.div_(world)
+        torch.cuda.synchronize()
+    finally:
+        E.set_sync_bn(None)
+    return {"emb": emb.detach().float().cpu().numpy(), "loss": float(loss),
+            "g": {n: flat.grad_view(i).detach().cpu().numpy().copy() for i, (n, _) in enumerate(named)},
+            "rm1": m.features[1].running_mean.cpu().numpy(), "rv3": m.features[9].running_var.cpu().numpy(),
+            "rmp": m.projection_head[1].running_mean.cpu().numpy(), "rvp": m.projection_head[1].running_var.cpu().numpy()}
+
+
+def _worker_syncbn(rank, world, port, ret):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        ret[rank] = _decar_syncbn_step(world, rank)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_sync_batchnorm_equals_one_rank_on_the_whole_batch():
+    """SyncBatchNorm as a statistics exchange (`nn.SyncBatchNorm.convert_sync_batchnorm` + DDP, extras/decar-v2/
+    main.py:82-84): two ranks with 8 clips each - stem tap moments, conv sum / sumsq, projection-head column sums all-reduced
+    forward, the BatchNorm-backward sums all-reduced backward, gradients averaged - against ONE rank on all 16 clips with plain
+    BatchNorm: same embeddings, same loss, same gradients (fp32 path: 2e-3), same running statistics on both ranks."""
+    from helpers import rel_l2
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker_syncbn, args=(2, port, ret), nprocs=2, join=True)
+    one = _decar_syncbn_step(1, 0)
+    r0, r1 = ret[0], ret[1]
+    emb = np.concatenate([r0["emb"], r1["emb"]])
+    assert rel_l2(torch.from_numpy(emb), torch.from_numpy(one["emb"])) < 2e-4
+    assert abs(0.5 * (r0["loss"] + r1["loss"]) - one["loss"]) <= 2e-4 * abs(one["loss"])
+    for n, g in one["g"].items():
+        if n in ("features.0.bias", "features.4.bias", "features.8.bias", "projection_head.0.bias"):
+            assert float(np.abs(r0["g"][n]).max()) < 1e-6        # a bias in front of a train-mode BatchNorm: zero gradient (rounding residue)
+            continue
+        np.testing.assert_array_equal(r0["g"][n], r1["g"][n], err_msg=n)
+        assert rel_l2(torch.from_numpy(r0["g"][n]), torch.from_numpy(g)) < 2e-3, n
+    for k in ("rm1", "rv3", "rmp", "rvp"):
+        np.testing.assert_allclose(r0[k], one[k], rtol=2e-4, atol=1e-6, err_msg=k)
+        np.testing.assert_array_equal(r0[k], r1[k], err_msg=k)
