@@ -105,11 +105,85 @@ __global__ __launch_bounds__(256) void bn_relu_pool_fwd_kernel(const TY* __restr
     o.store(P + idx * 8);
 }
 
+// The same with the BatchNorm finalisation folded in (train mode, 64 channels): every workgroup turns the fp64 column sums into
+// scale / shift itself (64 lanes, a few flops each) instead of waiting for a one-workgroup bn_finalize launch between the
+// convolution and the pooling - one graph node and one dependent-launch gap less per conv block; workgroup 0 also stores
+// scale / shift / mean / rstd for the backward and updates the running buffers.
+template <typename TY, typename T_>
+__global__ __launch_bounds__(256) void bn_relu_pool_train_fwd_kernel(const TY* __restrict__ Y, const double* __restrict__ sum,
+                                                                     const double* __restrict__ sumsq, double count,
+                                                                     const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                                     float* running_mean, float* running_var, float momentum, float eps,
+                                                                     T_* __restrict__ P, float* __restrict__ scale,
+                                                                     float* __restrict__ shift, float* __restrict__ save_mean,
+                                                                     float* __restrict__ save_rstd, int N, int Ti, int Fi) {
+    __shared__ float sc_s[64], sh_s[64];
+    if (threadIdx.x < 64) {
+        const int c = threadIdx.x;
+        const double g = (double)gamma[c], b = (double)beta[c];
+        const double mean = sum[c] / count;
+        double var = sumsq[c] / count - mean * mean;
+        var = var < 0.0 ? 0.0 : var;
+        const double rstd = 1.0 / sqrt(var + (double)eps);
+        const float sc = (float)(g * rstd), sh = (float)(b - mean * g * rstd);
+        sc_s[c] = sc; sh_s[c] = sh;
+        if (blockIdx.x == 0) {
+            scale[c] = sc; shift[c] = sh; save_mean[c] = (float)mean; save_rstd[c] = (float)rstd;
+            if (running_mean) {
+                running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mean;
+                const double unb = count > 1.0 ? var * count / (count - 1.0) : var;
+                running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unb;
+            }
+        }
+    }
+    __syncthreads();
+    const int To = Ti / 2, Fo = Fi / 2;
+    const long total = (long)N * To * Fo * 8;
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= total) return;
+    const int c8 = (int)(idx & 7);
+    long r = idx >> 3;
+    const int fo = (int)(r % Fo); r /= Fo;
+    const int to = (int)(r % To);
+    const int n = (int)(r / To);
+    float sc[8], sh[8], m[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { sc[i] = sc_s[c8 * 8 + i]; sh[i] = sh_s[c8 * 8 + i]; m[i] = 0.f; }
+#pragma unroll
+    for (int df = 0; df < 2; ++df)
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) {
+            const Vec8<TY> v = Vec8<TY>::load(Y + ((((long)n * Ti + 2 * to + dt) * Fi + 2 * fo + df) * 64 + c8 * 8));
+#pragma unroll
+            for (int i = 0; i < 8; ++i) m[i] = fmaxf(m[i], sc[i] * v.get(i) + sh[i]);
+        }
+    Vec8<T_> o;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) o.set(i, m[i]);
+    o.store(P + idx * 8);
+}
+
 // xl[n][f*64+c] = mean_t P[n][t][f][c].  A workgroup owns one image and a strip of 64 vectors (512 features); its four
 // waves take the time rows t = w, w + 4, ... (1 KB contiguous per wave and row) and fold through LDS.  (One thread per
 // output vector walking all To rows serially ran at 2 TB/s: 8 waves per CU, one dependent 16-byte load in flight each.)
 template <typename T_, typename TO>
+__device__ __forceinline__ void tmean_body(const T_* __restrict__ P, TO* __restrict__ xl, int N, int To, int Fo);
+
+template <typename T_, typename TO>
 __global__ __launch_bounds__(256) void tmean_fwd_kernel(const T_* __restrict__ P, TO* __restrict__ xl, int N, int To, int Fo) {
+    tmean_body<T_, TO>(P, xl, N, To, Fo);
+}
+// the three layer means of one encoder pass (x_1, x_2, x_3) in ONE launch: blockIdx.z = layer
+struct Tmean3 { const void* P[3]; void* xl[3]; int To[3], Fo[3]; };
+template <typename T_, typename TO>
+__global__ __launch_bounds__(256) void tmean3_fwd_kernel(Tmean3 a, int N) {
+    const int l = blockIdx.z;
+    if ((int)blockIdx.x * 64 >= a.Fo[l] * 8) return;
+    tmean_body<T_, TO>(static_cast<const T_*>(a.P[l]), static_cast<TO*>(a.xl[l]), N, a.To[l], a.Fo[l]);
+}
+
+template <typename T_, typename TO>
+__device__ __forceinline__ void tmean_body(const T_* __restrict__ P, TO* __restrict__ xl, int N, int To, int Fo) {
     __shared__ float red[4][64][9];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int nv = Fo * 8;                                        // vectors per time row
@@ -343,6 +417,22 @@ extern "C" int audiossl_bn_relu_pool_fwd(int dtype, int ydtype, const void* Y, c
     ASSL_LAUNCH_CHECK();
 }
 
+extern "C" int audiossl_bn_relu_pool_train_fwd(int dtype, int ydtype, const void* Y, const double* sum, const double* sumsq, double count,
+                                               const float* gamma, const float* beta, float* running_mean, float* running_var,
+                                               float momentum, float eps, void* P, float* scale, float* shift, float* save_mean,
+                                               float* save_rstd, int N, int Ti, int Fi, void* stream) {
+    ASSL_REQUIRE(Y && sum && sumsq && gamma && beta && P && scale && shift && save_mean && save_rstd && count > 0.0);
+    ASSL_REQUIRE(N > 0 && Ti >= 2 && Fi >= 2 && (Fi % 2) == 0 && (dtype == 0 || dtype == 1) && (ydtype == 0 || ydtype == dtype));
+    const long total = (long)N * (Ti / 2) * (Fi / 2) * 8;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+#define PF(TY, TO) hipLaunchKernelGGL((bn_relu_pool_train_fwd_kernel<TY, TO>), dim3(ceil_div(total, 256)), dim3(256), 0, s,          \
+        static_cast<const TY*>(Y), sum, sumsq, count, gamma, beta, running_mean, running_var, momentum, eps, static_cast<TO*>(P), \
+        scale, shift, save_mean, save_rstd, N, Ti, Fi)
+    if (dtype == 0) PF(float, float); else if (ydtype == 0) PF(float, bf16); else PF(bf16, bf16);
+#undef PF
+    ASSL_LAUNCH_CHECK();
+}
+
 extern "C" int audiossl_tmean_fwd(int dtype, int out_f32, const void* P, void* xl, int N, int To, int Fo, void* stream) {
     ASSL_REQUIRE(P && xl && N > 0 && To > 0 && Fo > 0 && (dtype == 0 || dtype == 1));
     hipStream_t s = static_cast<hipStream_t>(stream);
@@ -350,6 +440,19 @@ extern "C" int audiossl_tmean_fwd(int dtype, int out_f32, const void* P, void* x
         static_cast<const TI*>(P), static_cast<TO_*>(xl), N, To, Fo)
     if (dtype == 0) TM(float, float); else if (out_f32) TM(bf16, float); else TM(bf16, bf16);
 #undef TM
+    ASSL_LAUNCH_CHECK();
+}
+
+extern "C" int audiossl_tmean3_fwd(int dtype, int out_f32, const void* P1, void* x1, int To1, int Fo1, const void* P2, void* x2, int To2,
+                                   int Fo2, const void* P3, void* x3, int To3, int Fo3, int N, void* stream) {
+    ASSL_REQUIRE(P1 && x1 && P2 && x2 && P3 && x3 && N > 0 && To1 > 0 && To2 > 0 && To3 > 0 && Fo1 > 0 && Fo2 > 0 && Fo3 > 0);
+    ASSL_REQUIRE(dtype == 0 || dtype == 1);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    Tmean3 a{{P1, P2, P3}, {x1, x2, x3}, {To1, To2, To3}, {Fo1, Fo2, Fo3}};
+    const int gx = ceil_div(max(Fo1, max(Fo2, Fo3)) * 8, 64);
+#define TM3(TI, TO_) hipLaunchKernelGGL((tmean3_fwd_kernel<TI, TO_>), dim3(gx, N, 3), dim3(256), 0, s, a, N)
+    if (dtype == 0) TM3(float, float); else if (out_f32) TM3(bf16, float); else TM3(bf16, bf16);
+#undef TM3
     ASSL_LAUNCH_CHECK();
 }
 

@@ -1035,8 +1035,22 @@ __global__ __launch_bounds__(256) void split_bf16_kernel(const float* __restrict
 // only its running mean sees it (shift_running_mean below), and the weight gradient da1^T y = da1^T yc because a BatchNorm
 // input gradient sums to zero over the batch.  One workgroup = 32 columns of one group, rows in registers (M <= 64 * NR).
 template <int NR>
+__device__ __forceinline__ void center_cast_body(const float* __restrict__ y, bf16* __restrict__ yc, float* __restrict__ cmean, int M, int C);
+template <int NR>
 __global__ __launch_bounds__(256) void center_cast_kernel(const float* __restrict__ y, bf16* __restrict__ yc,
                                                           float* __restrict__ cmean, int M, int C) {
+    center_cast_body<NR>(y, yc, cmean, M, C);
+}
+// the three Barlow heads of DeLoRes-M in one launch (blockIdx.z = head; their widths differ)
+struct CenterMulti { const float* y[MAXP]; bf16* yc[MAXP]; float* cmean[MAXP]; int C[MAXP]; };
+template <int NR>
+__global__ __launch_bounds__(256) void center_cast_multi_kernel(CenterMulti m, int M) {
+    const int p = blockIdx.z;
+    if ((int)blockIdx.x * 32 >= m.C[p]) return;
+    center_cast_body<NR>(m.y[p], m.yc[p], m.cmean[p], M, m.C[p]);
+}
+template <int NR>
+__device__ __forceinline__ void center_cast_body(const float* __restrict__ y, bf16* __restrict__ yc, float* __restrict__ cmean, int M, int C) {
     __shared__ float red[64][65];
     __shared__ double tot[32];
     __shared__ float mu_s[32];
@@ -1080,9 +1094,20 @@ __global__ __launch_bounds__(256) void center_cast_kernel(const float* __restric
 }
 // running_mean[j] += sum_g momentum (1 - momentum)^(G-1-g) * (cmean[g] . W[j]): what the running mean of the BatchNorm behind
 // W (bf16 [D][K], row-major) would have seen from the un-centred input.  One wave per output row j.
+__device__ __forceinline__ void shift_running_mean_body(const bf16* __restrict__ W, const float* __restrict__ cmean,
+                                                        float* __restrict__ running_mean, int D, int K, int groups, float momentum);
 __global__ __launch_bounds__(256) void shift_running_mean_kernel(const bf16* __restrict__ W, const float* __restrict__ cmean,
                                                                  float* __restrict__ running_mean, int D, int K, int groups,
                                                                  float momentum) {
+    shift_running_mean_body(W, cmean, running_mean, D, K, groups, momentum);
+}
+struct ShiftMulti { const bf16* W[MAXP]; const float* cmean[MAXP]; float* rm[MAXP]; int K[MAXP]; };
+__global__ __launch_bounds__(256) void shift_running_mean_multi_kernel(ShiftMulti m, int D, int groups, float momentum) {
+    const int p = blockIdx.y;
+    shift_running_mean_body(m.W[p], m.cmean[p], m.rm[p], D, m.K[p], groups, momentum);
+}
+__device__ __forceinline__ void shift_running_mean_body(const bf16* __restrict__ W, const float* __restrict__ cmean,
+                                                        float* __restrict__ running_mean, int D, int K, int groups, float momentum) {
     const int lane = threadIdx.x & 63, j = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (j >= D) return;
     float acc = 0.f, coef = momentum;
@@ -1134,6 +1159,34 @@ extern "C" int audiossl_center_cast(const float* y, void* yc, float* cmean, int 
     const dim3 grid(C / 32, groups);
     if (M <= 512) hipLaunchKernelGGL(center_cast_kernel<8>, grid, dim3(256), 0, S_(stream), y, (bf16*)yc, cmean, (int)M, C);
     else          hipLaunchKernelGGL(center_cast_kernel<16>, grid, dim3(256), 0, S_(stream), y, (bf16*)yc, cmean, (int)M, C);
+    ASSL_LAUNCH_CHECK();
+}
+
+extern "C" int audiossl_center_cast_multi(int count, const float* const* y, void* const* yc, float* const* cmean, const int* C, int groups,
+                                          long M, void* stream) {
+    ASSL_REQUIRE(count >= 1 && count <= MAXP && y && yc && cmean && C && groups > 0 && M > 0 && M <= 1024);
+    CenterMulti m;
+    int cmax = 0;
+    for (int i = 0; i < count; ++i) {
+        ASSL_REQUIRE(y[i] && yc[i] && cmean[i] && C[i] > 0 && C[i] % 32 == 0 && ASSL_ALIGNED16(y[i]) && ASSL_ALIGNED16(yc[i]));
+        m.y[i] = y[i]; m.yc[i] = static_cast<bf16*>(yc[i]); m.cmean[i] = cmean[i]; m.C[i] = C[i];
+        cmax = max(cmax, C[i]);
+    }
+    const dim3 grid(cmax / 32, groups, count);
+    if (M <= 512) hipLaunchKernelGGL(center_cast_multi_kernel<8>, grid, dim3(256), 0, S_(stream), m, (int)M);
+    else          hipLaunchKernelGGL(center_cast_multi_kernel<16>, grid, dim3(256), 0, S_(stream), m, (int)M);
+    ASSL_LAUNCH_CHECK();
+}
+
+extern "C" int audiossl_shift_running_mean_multi(int count, const void* const* W, const float* const* cmean, float* const* running_mean,
+                                                 int D, const int* K, int groups, float momentum, void* stream) {
+    ASSL_REQUIRE(count >= 1 && count <= MAXP && W && cmean && running_mean && K && D > 0 && groups > 0);
+    ShiftMulti m;
+    for (int i = 0; i < count; ++i) {
+        ASSL_REQUIRE(W[i] && cmean[i] && running_mean[i] && K[i] > 0 && K[i] % 8 == 0 && ASSL_ALIGNED16(W[i]) && ASSL_ALIGNED16(cmean[i]));
+        m.W[i] = static_cast<const bf16*>(W[i]); m.cmean[i] = cmean[i]; m.rm[i] = running_mean[i]; m.K[i] = K[i];
+    }
+    hipLaunchKernelGGL(shift_running_mean_multi_kernel, dim3(ceil_div(D, 4), count), dim3(256), 0, S_(stream), m, D, groups, momentum);
     ASSL_LAUNCH_CHECK();
 }
 

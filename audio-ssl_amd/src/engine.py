@@ -282,12 +282,17 @@ def _conv_block_fwd(dtype, Pin, Nimg, Ti, Fi, W, bias, bn, train, update_running
     else:
         N.call("im2col3x3", dtype, Pin, col, Nimg, Ti, Fi)
         gemm(dtype, 0, 0, M, 64, 576, col, 576, Wf, 576, Y, 64, bias=bias, out_f32=int(ad == N.F32))
+    Pout = _empty((Nimg, Ti // 2, Fi // 2, 64), td, like=Pin)
+    if train and fused and SYNC_BN is None:
+        # statistics -> scale / shift inside the pooling launch (no bn_finalize node between the convolution and the pooling)
+        st = _empty((4, 64), torch.float32, like=Pin)
+        N.call("bn_relu_pool_train_fwd", dtype, ad, Y, sq[0], sq[1], float(M), gamma, beta, rm if update_running else None,
+               rv if update_running else None, BN_MOMENTUM, BN_EPS, Pout, st[0], st[1], st[2], st[3], Nimg, Ti, Fi)
+        return Y, Pout, (st[0], st[1], st[2], st[3]), Wf, Wd
     if train and fused:
         st = _empty((4, 64), torch.float32, like=Pin)
-        if SYNC_BN is not None:
-            SYNC_BN.all_reduce(sq)
-            M = M * SYNC_BN.world
-        N.call("bn_finalize", sq[0], sq[1], 1, float(M), 64, gamma, beta, rm if update_running else None,
+        SYNC_BN.all_reduce(sq)
+        N.call("bn_finalize", sq[0], sq[1], 1, float(M * SYNC_BN.world), 64, gamma, beta, rm if update_running else None,
                rv if update_running else None, BN_MOMENTUM, BN_EPS, st[0], st[1], st[2], st[3])
         scale, shift, mean, rstd = st[0], st[1], st[2], st[3]
     elif train:
@@ -295,7 +300,6 @@ def _conv_block_fwd(dtype, Pin, Nimg, Ti, Fi, W, bias, bn, train, update_running
     else:
         scale, shift = _bn_eval(Y, 64, gamma, beta, rm, rv)
         mean = rstd = None
-    Pout = _empty((Nimg, Ti // 2, Fi // 2, 64), td, like=Pin)
     N.call("bn_relu_pool_fwd", dtype, ad, Y, scale, shift, Pout, Nimg, Ti, Fi)
     return Y, Pout, (scale, shift, mean, rstd), Wf, Wd
 
@@ -359,9 +363,7 @@ def encoder_forward(P, x, dtype, keep=None, p_drop=0.3, train=True, update_runni
     if want_layers:
         x1, x2, x3 = layer_out if layer_out is not None else (_empty((Nimg, f * 64), td, like=x) for f in (F1, F2, F3))
         o32 = int(x1.dtype == torch.float32)
-        N.call("tmean_fwd", dtype, o32, c.P1, x1, Nimg, T1, F1)
-        N.call("tmean_fwd", dtype, o32, c.P2, x2, Nimg, T2, F2)
-        N.call("tmean_fwd", dtype, o32, c.P3, x3, Nimg, T3, F3)
+        N.call("tmean3_fwd", dtype, o32, c.P1, x1, T1, F1, c.P2, x2, T2, F2, c.P3, x3, T3, F3, Nimg)
     d = P["fc.0.weight"].shape[0]
     kin = F3 * 64
     M = Nimg * T3
@@ -676,11 +678,20 @@ def barlow_heads_forward_backward(PPs, Gs, Ys, dtype, lambds, scale_losses, loss
                BN_MOMENTUM, BN_EPS, relu, 2, B, D, adr(arrs[5]), adr(arrs[6]))
         return a, st, out
     # centred bf16 operands of the first layer (see projector_forward); Ys arrive in fp32
-    ycs, cms = (list(t) for t in zip(*[center_cast(Y, 2, B) for Y in Ys]))
+    ycs = [torch.empty(M, k, dtype=torch.bfloat16, device=dev) for k in kins]
+    cms = [torch.empty(2, k, dtype=torch.float32, device=dev) for k in kins]
+    _multi_check(list(Ys), ycs, cms)
+    if any(Y.dtype != torch.float32 or k % 32 for Y, k in zip(Ys, kins)):
+        raise RuntimeError("grouped Barlow heads: fp32 inputs with width % 32 == 0")
+    arrs = (_harr(vp, list(Ys)), _harr(vp, ycs), _harr(vp, cms), _harr(ctypes.c_int, kins))
+    N.call("center_cast_multi", nh, adr(arrs[0]), adr(arrs[1]), adr(arrs[2]), adr(arrs[3]), 2, B)
     a1, st1, h1 = layer(ycs, [W[h][0] for h in H], kins, "projector.1", True, 1)
     if update_running:
-        for h in H:
-            N.call("shift_running_mean", W[h][0], cms[h], PPs[h]["projector.1.running_mean"], D, kins[h], 2, BN_MOMENTUM)
+        rms = [PP["projector.1.running_mean"] for PP in PPs]
+        w0 = [W[h][0] for h in H]
+        _multi_check(w0, rms)
+        arrs = (_harr(vp, w0), _harr(vp, cms), _harr(vp, rms), _harr(ctypes.c_int, kins))
+        N.call("shift_running_mean_multi", nh, adr(arrs[0]), adr(arrs[1]), adr(arrs[2]), D, adr(arrs[3]), 2, BN_MOMENTUM)
     a2, st2, h2 = layer(h1, [W[h][1] for h in H], [D] * nh, "projector.4", True, 1)
     z, st0, zn = layer(h2, [W[h][2] for h in H], [D] * nh, "bn", False, 0)
     # correlation c_h = zn1^T zn2 / B, loss, dc

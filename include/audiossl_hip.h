@@ -127,7 +127,16 @@ int audiossl_bn_finalize(const double* sum, const double* sumsq, int groups, dou
                          float* scale, float* shift, float* save_mean, float* save_rstd, void* stream);
 int audiossl_bn_relu_pool_fwd(int dtype, int ydtype, const void* Y, const float* scale, const float* shift, void* P, int N,
                               int Ti, int Fi, void* stream);
+/* bn_finalize + bn_relu_pool_fwd of one train-mode conv block (64 channels) in one launch: every workgroup derives scale / shift
+ * from the fp64 sums itself; scale / shift / mean / rstd (for the backward) and the running buffers are written by workgroup 0. */
+int audiossl_bn_relu_pool_train_fwd(int dtype, int ydtype, const void* Y, const double* sum, const double* sumsq, double count,
+                                    const float* gamma, const float* beta, float* running_mean, float* running_var, float momentum,
+                                    float eps, void* P, float* scale, float* shift, float* save_mean, float* save_rstd, int N, int Ti,
+                                    int Fi, void* stream);
 int audiossl_tmean_fwd(int dtype, int out_f32, const void* P, void* xl, int N, int To, int Fo, void* stream);
+/* x_1, x_2, x_3 of one encoder pass (`audiontt.py:76-93`) in one launch */
+int audiossl_tmean3_fwd(int dtype, int out_f32, const void* P1, void* x1, int To1, int Fo1, const void* P2, void* x2, int To2, int Fo2,
+                        const void* P3, void* x3, int To3, int Fo3, int N, void* stream);
 int audiossl_bn_relu_pool_bwd(int dtype, int ydtype, int gdtype, const void* Y, const void* dP, const void* dxl, const float* scale,
                               const float* shift, const float* mean, const float* rstd, float* stat, void* dY,
                               float* dgamma, float* dbeta, int N, int Ti, int Fi, void* stream);
@@ -291,6 +300,11 @@ int audiossl_split_bf16(const float* x, void* hi, void* lo, long n, void* stream
 int audiossl_center_cast(const float* y, void* yc, float* cmean, int groups, long M, int C, void* stream);
 int audiossl_shift_running_mean(const void* W, const float* cmean, float* running_mean, int D, int K, int groups,
                                 float momentum, void* stream);
+/* the same for up to four heads per launch (host arrays of device pointers / widths, as the other *_multi entry points) */
+int audiossl_center_cast_multi(int count, const float* const* y, void* const* yc, float* const* cmean, const int* C, int groups,
+                               long M, void* stream);
+int audiossl_shift_running_mean_multi(int count, const void* const* W, const float* const* cmean, float* const* running_mean,
+                                      int D, const int* K, int groups, float momentum, void* stream);
 
 /* ---- K14 NT-Xent / ClusterLoss: extras/slicer/contrastive_loss.py:6-92 -----------------------------------------
  * sim [N][N] fp32 = z z^T / tau from audiossl_gemm (N = 2B; positives at (r + B) mod N; the diagonal is excluded).

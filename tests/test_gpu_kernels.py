@@ -384,6 +384,23 @@ def test_conv1_block_fwd_bwd(N, dtype, T):
     assert float(conv.bias.grad.abs().max()) < 1e-3 and float(db.abs().max()) == 0.0
 
 
+@pytest.mark.parametrize("shape", [(5, 40, 300), (2, 64, 129), (3, 8, 2), (7, 64, 101), (2, 120, 128)])
+def test_conv1_tap_moments(N, shape):
+    """The 9 first + 45 second moments of the shifted copies of the input the stem's batch statistics are built from
+    (csrc/conv1.hip): time chunks of 128 columns with a halo, chunk boundaries inside and at the end of the image."""
+    import torch.nn.functional as Fnn
+    Nimg, F_, T = shape
+    x = torch.from_numpy(fill.normalish((Nimg, 1, F_, T), 7 + T)).double()
+    taps = Fnn.unfold(x, 3, padding=1)                               # [N, 9, F*T], tap order kh*3+kw
+    s1 = taps.sum((0, 2))
+    s2 = torch.einsum("nap,nbp->ab", taps, taps)
+    want = torch.cat([s1, torch.stack([s2[a, b] for a in range(9) for b in range(a, 9)])])
+    mom = torch.empty(16 * 54, dtype=torch.float64, device="cuda")
+    N.call("conv1_moments", x[:, 0].float().cuda().contiguous(), Nimg, F_, T, mom)
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(mom[:54].cpu().numpy(), want.numpy(), rtol=2e-5, atol=1e-3)
+
+
 # ------------------------------------------------------------------------------------------------ implicit-GEMM conv
 @pytest.mark.parametrize("shape", [(3, 50, 32), (2, 48, 32), (3, 25, 16), (5, 24, 16), (1, 3, 32),
                                    (80, 50, 32), (600, 25, 16), (261, 24, 16)])
@@ -518,6 +535,51 @@ def test_center_cast_and_running_mean_shift(N):
         da = torch.randn(M, D, generator=g).cuda().double()
         da = da - da.mean(0)                                 # a BatchNorm input gradient sums to zero over the batch
         assert rel_l2((da.T @ want[0].double()).cpu(), (da.T @ y[0].double()).cpu()) < 1e-5
+
+
+def test_multi_head_launches_equal_single_ones(N):
+    """center_cast_multi / shift_running_mean_multi / tmean3_fwd are the per-head (per-layer) launches folded into one grid:
+    bit-identical to the single-problem entry points at the widths DeLoRes-M uses (2048 / 1024 / 512; F = 32 / 16 / 8)."""
+    import ctypes
+    from src import engine as E
+    g = torch.Generator().manual_seed(5)
+    G, M, D, mom = 2, 384, 96, 0.1
+    Ks = [2048, 1024, 512]
+    ys = [(torch.rand(G * M, K, generator=g) + 3.0).cuda() for K in Ks]
+    one = [(torch.empty(G * M, K, device="cuda", dtype=torch.bfloat16), torch.empty(G, K, device="cuda")) for K in Ks]
+    for y, (yc, cm), K in zip(ys, one, Ks):
+        N.call("center_cast", y, yc, cm, G, M, K)
+    ycs = [torch.empty_like(o[0]) for o in one]
+    cms = [torch.empty_like(o[1]) for o in one]
+    vp, adr = ctypes.c_void_p, ctypes.addressof
+    a = (E._harr(vp, ys), E._harr(vp, ycs), E._harr(vp, cms), E._harr(ctypes.c_int, Ks))
+    N.call("center_cast_multi", 3, adr(a[0]), adr(a[1]), adr(a[2]), adr(a[3]), G, M)
+    torch.cuda.synchronize()
+    for (yc, cm), yc2, cm2 in zip(one, ycs, cms):
+        assert torch.equal(yc, yc2) and torch.equal(cm, cm2)
+    Ws = [(torch.randn(D, K, generator=g) * 0.05).cuda().bfloat16() for K in Ks]
+    rm1 = [torch.full((D,), 0.25, device="cuda") for _ in Ks]
+    rm2 = [t.clone() for t in rm1]
+    for W, cm, rm, K in zip(Ws, cms, rm1, Ks):
+        N.call("shift_running_mean", W, cm, rm, D, K, G, mom)
+    a = (E._harr(vp, Ws), E._harr(vp, cms), E._harr(vp, rm2), E._harr(ctypes.c_int, Ks))
+    N.call("shift_running_mean_multi", 3, adr(a[0]), adr(a[1]), adr(a[2]), D, adr(a[3]), G, mom)
+    torch.cuda.synchronize()
+    for r1, r2 in zip(rm1, rm2):
+        assert torch.equal(r1, r2) and float((r1 - 0.25).abs().max()) > 0
+    Nimg = 6
+    for dt, td, o32 in ((N.F32, torch.float32, 1), (N.BF16, torch.bfloat16, 1), (N.BF16, torch.bfloat16, 0)):
+        dims = [(48, 32), (24, 16), (12, 8)]
+        Ps = [torch.randn(Nimg, T, F, 64, generator=g).cuda().to(td) for T, F in dims]
+        to = torch.float32 if o32 else td
+        x1 = [torch.empty(Nimg, F * 64, device="cuda", dtype=to) for _, F in dims]
+        x3 = [torch.full_like(t, -1.0) for t in x1]
+        for P, x, (T, F) in zip(Ps, x1, dims):
+            N.call("tmean_fwd", dt, o32, P, x, Nimg, T, F)
+        N.call("tmean3_fwd", dt, o32, Ps[0], x3[0], *dims[0], Ps[1], x3[1], *dims[1], Ps[2], x3[2], *dims[2], Nimg)
+        torch.cuda.synchronize()
+        for u, v in zip(x1, x3):
+            assert torch.equal(u, v)
 
 
 def test_gemm_multi_per_problem_shapes(N):
