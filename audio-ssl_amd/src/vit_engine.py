@@ -4,7 +4,7 @@ Forward and backward of the ViT that `ASTModel` wraps (`extras/mast_new/mast/mod
 timm DeiT-base = 12 pre-norm blocks x 768 x 12 heads) as sequences of C-ABI calls:
 
   patch_unfold -> GEMM(+bias, + position embedding as the residual operand)              tokens [B*N, 768] fp32
-  per block:  layernorm -> GEMM qkv -> attention (one workgroup per clip and head) -> GEMM proj (+bias +residual)
+  per block:  layernorm -> GEMM qkv -> attention (one workgroup per clip, head and 128-token block) -> GEMM proj (+bias +residual)
               layernorm -> GEMM fc1 (+bias) -> GELU -> GEMM fc2 (+bias +residual)
   layernorm -> mean over tokens -> GEMM head
 
@@ -46,8 +46,8 @@ def vit_forward(P, W, x, cfg, need_ctx=True):
     Ntok = nf * nt
     M = B * Ntok
     dev = x.device
-    if Ntok > 128:
-        raise ValueError(f"{Ntok} patches per clip: the single-tile attention kernel covers sequences up to 128 tokens (1 s clips)")
+    if B * H > 65535:
+        raise ValueError("batch * heads must stay within 65,535 (attention grid)")
     if M % 8:
         raise ValueError("batch * patches must be a multiple of 8 (weight-gradient GEMMs contract over the token rows)")
     c = ViTCtx()
@@ -161,7 +161,7 @@ def vit_backward(c, P, W, G, dout):
         E.colsum_add(N.F32, dX, M, C, G[p + "attn.proj.bias"])
         dA = E.linear_bwd_x(BF, dXb, W[p + "attn.proj.weight"], M, C, C)                   # bf16 [M, C]
         dQKV = torch.empty(M, 3 * C, dtype=torch.bfloat16, device=dev)
-        N.call("attn_bwd", k.QKV, dA, k.lse, dQKV, B, Ntok, H, scale)
+        N.call("attn_bwd", k.QKV, k.A, dA, k.lse, dQKV, B, Ntok, H, scale)
         _wgrad(dQKV, k.Y1, G[p + "attn.qkv.weight"], M, 3 * C, C)
         E.colsum_add(BF, dQKV, M, 3 * C, G[p + "attn.qkv.bias"])
         dY1 = E.linear_bwd_x(BF, dQKV, W[p + "attn.qkv.weight"], M, 3 * C, C, out_f32=1)

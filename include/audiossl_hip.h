@@ -336,8 +336,10 @@ int audiossl_softmax_rows_bwd(const float* y, const float* gy, float* gx, int M,
 /* ---- K18 AST / MAST transformer encoder (BASELINE config 4, "AST-base 12x768"): the ViT timm builds for ASTModel,
  * extras/mast_new/mast/models/ast_work.py:70-81, 101, 183-230; optimiser extras/mast_new/mast/moco_model.py:373-379 ----
  * attn_fwd: qkv bf16 [B*S][3*H*64] (q | k | v column blocks, head h at columns h*64) -> out bf16 [B*S][H*64] =
- *           softmax(scale * q k^T) v per (clip, head), lse fp32 [B*H][S] kept for the backward.  S <= 128.
- * attn_bwd: dout bf16 [B*S][H*64] -> dqkv bf16 [B*S][3*H*64].
+ *           softmax(scale * q k^T) v per (clip, head), lse fp32 [B*H][S] kept for the backward.  S <= 128 runs as one
+ *           tile per (clip, head); longer sequences (10 s clips: 1,212 tokens) walk 128-token blocks, B*H <= 65535.
+ * attn_bwd: dout bf16 [B*S][H*64] -> dqkv bf16 [B*S][3*H*64].  `out` = what attn_fwd wrote (needed when S > 128: the
+ *           multi-block backward takes D = rowsum(dout * out) from it; may be NULL for S <= 128).
  * layernorm_fwd: x fp32 [M][C] -> y bf16, mean / rstd fp32 [M] (C % 64 == 0, C <= 1024).
  * layernorm_bwd: dres fp32 [M][C] += dx (the residual-stream gradient accumulates in place); dgamma, dbeta += .
  * gelu_fwd / gelu_bwd: exact GELU on bf16, da = dh * gelu'(a).
@@ -346,8 +348,8 @@ int audiossl_softmax_rows_bwd(const float* y, const float* gy, float* gx, int M,
  *            the backward of the mean over tokens (group N, period B, scale 1/N).
  * adamw: torch.optim.AdamW on a flat buffer; `step` = device int64 holding the 1-based step count. */
 int audiossl_attn_fwd(const void* qkv, void* out, float* lse, int B, int S, int H, float scale, void* stream);
-int audiossl_attn_bwd(const void* qkv, const void* dout, const float* lse, void* dqkv, int B, int S, int H, float scale,
-                      void* stream);
+int audiossl_attn_bwd(const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv, int B, int S, int H,
+                      float scale, void* stream);
 int audiossl_layernorm_fwd(const float* x, const float* gamma, const float* beta, void* y, float* mean, float* rstd, int M,
                            int C, float eps, void* stream);
 int audiossl_layernorm_bwd(const float* dy, const float* x, const float* mean, const float* rstd, const float* gamma,
