@@ -36,6 +36,35 @@ def _ln(x, g, b, M, C, eps):
     return y, mean, rstd
 
 
+def block_forward(P, W, p, X, B, Ntok, C, H, eps):
+    """One pre-norm transformer block (timm `Block`; equally the reference's `MultiScaleBlock` without pooling,
+    `mvit/models/attention.py:304-393`): X fp32 [B*Ntok, C] -> (X' fp32, ctx).  Parameters under prefix `p`."""
+    M, dev = B * Ntok, X.device
+    scale = 1.0 / math.sqrt(C // H)
+    k = ViTCtx()
+    k.X1 = X
+    k.Y1, k.mu1, k.rs1 = _ln(X, P[p + "norm1.weight"], P[p + "norm1.bias"], M, C, eps)
+    k.QKV = torch.empty(M, 3 * C, dtype=torch.bfloat16, device=dev)
+    E.gemm(BF, 0, 0, M, 3 * C, C, k.Y1, C, W[p + "attn.qkv.weight"], C, k.QKV, 3 * C, bias=P[p + "attn.qkv.bias"])
+    k.A = torch.empty(M, C, dtype=torch.bfloat16, device=dev)
+    k.lse = torch.empty(B * H, Ntok, dtype=torch.float32, device=dev)
+    N.call("attn_fwd", k.QKV, k.A, k.lse, B, Ntok, H, scale)
+    X2 = torch.empty(M, C, dtype=torch.float32, device=dev)
+    E.gemm(BF, 0, 0, M, C, C, k.A, C, W[p + "attn.proj.weight"], C, X2, C, bias=P[p + "attn.proj.bias"], out_f32=1,
+           resid=X, ldr=C)
+    k.X2 = X2
+    k.Y2, k.mu2, k.rs2 = _ln(X2, P[p + "norm2.weight"], P[p + "norm2.bias"], M, C, eps)
+    Hd = W[p + "mlp.fc1.weight"].shape[0]
+    k.A1 = torch.empty(M, Hd, dtype=torch.bfloat16, device=dev)
+    E.gemm(BF, 0, 0, M, Hd, C, k.Y2, C, W[p + "mlp.fc1.weight"], C, k.A1, Hd, bias=P[p + "mlp.fc1.bias"])
+    k.H1 = torch.empty(M, Hd, dtype=torch.bfloat16, device=dev)
+    N.call("gelu_fwd", k.A1, k.H1, M * Hd)
+    X3 = torch.empty(M, C, dtype=torch.float32, device=dev)
+    E.gemm(BF, 0, 0, M, C, Hd, k.H1, Hd, W[p + "mlp.fc2.weight"], Hd, X3, C, bias=P[p + "mlp.fc2.bias"], out_f32=1,
+           resid=X2, ldr=C)
+    return X3, k
+
+
 def vit_forward(P, W, x, cfg, need_ctx=True):
     """P: name -> fp32 parameter (keys of `src.encoder.mast.ASTModel`, prefix stripped); W: name -> bf16 copy of every
     2-D weight.  x [B, 1, F, T] fp32 log-mel.  Returns (embedding [B, out_dim] fp32, ctx)."""
@@ -66,29 +95,7 @@ def vit_forward(P, W, x, cfg, need_ctx=True):
     c.blocks = []
     scale = 1.0 / math.sqrt(C // H)
     for i in range(depth):
-        p = f"v.blocks.{i}."
-        k = ViTCtx()
-        k.X1 = X
-        k.Y1, k.mu1, k.rs1 = _ln(X, P[p + "norm1.weight"], P[p + "norm1.bias"], M, C, eps)
-        k.QKV = torch.empty(M, 3 * C, dtype=torch.bfloat16, device=dev)
-        E.gemm(BF, 0, 0, M, 3 * C, C, k.Y1, C, W[p + "attn.qkv.weight"], C, k.QKV, 3 * C, bias=P[p + "attn.qkv.bias"])
-        k.A = torch.empty(M, C, dtype=torch.bfloat16, device=dev)
-        k.lse = torch.empty(B * H, Ntok, dtype=torch.float32, device=dev)
-        N.call("attn_fwd", k.QKV, k.A, k.lse, B, Ntok, H, scale)
-        X2 = torch.empty(M, C, dtype=torch.float32, device=dev)
-        E.gemm(BF, 0, 0, M, C, C, k.A, C, W[p + "attn.proj.weight"], C, X2, C, bias=P[p + "attn.proj.bias"], out_f32=1,
-               resid=X, ldr=C)
-        k.X2 = X2
-        k.Y2, k.mu2, k.rs2 = _ln(X2, P[p + "norm2.weight"], P[p + "norm2.bias"], M, C, eps)
-        Hd = W[p + "mlp.fc1.weight"].shape[0]
-        k.A1 = torch.empty(M, Hd, dtype=torch.bfloat16, device=dev)
-        E.gemm(BF, 0, 0, M, Hd, C, k.Y2, C, W[p + "mlp.fc1.weight"], C, k.A1, Hd, bias=P[p + "mlp.fc1.bias"])
-        k.H1 = torch.empty(M, Hd, dtype=torch.bfloat16, device=dev)
-        N.call("gelu_fwd", k.A1, k.H1, M * Hd)
-        X3 = torch.empty(M, C, dtype=torch.float32, device=dev)
-        E.gemm(BF, 0, 0, M, C, Hd, k.H1, Hd, W[p + "mlp.fc2.weight"], Hd, X3, C, bias=P[p + "mlp.fc2.bias"], out_f32=1,
-               resid=X2, ldr=C)
-        X = X3
+        X, k = block_forward(P, W, f"v.blocks.{i}.", X, B, Ntok, C, H, eps)
         c.blocks.append(k)
     c.XL = X
     if cfg["final_norm"]:
@@ -113,6 +120,36 @@ def _cast(x32, M, C):
 def _wgrad(dYb, Xb, dW, M, Nout, K):
     """dW[Nout, K] += dY[M, Nout]^T X[M, K]"""
     E.linear_bwd_w(BF, dYb, Xb, dW, M, Nout, K)
+
+
+def block_backward(k, P, W, G, p, dX, B, Ntok, C, H):
+    """Backward of `block_forward`: dX fp32 [B*Ntok, C] is the gradient of the block's output on entry and of its input on
+    return (updated in place); parameter gradients are accumulated into G."""
+    M, dev = B * Ntok, dX.device
+    scale = 1.0 / math.sqrt(C // H)
+    Hd = W[p + "mlp.fc1.weight"].shape[0]
+    # ---- MLP branch: X3 = X2 + fc2(gelu(fc1(LN2(X2))))
+    dXb = _cast(dX, M, C)
+    _wgrad(dXb, k.H1, G[p + "mlp.fc2.weight"], M, C, Hd)
+    E.colsum_add(N.F32, dX, M, C, G[p + "mlp.fc2.bias"])
+    dH1 = E.linear_bwd_x(BF, dXb, W[p + "mlp.fc2.weight"], M, C, Hd)                   # bf16 [M, Hd]
+    dA1 = torch.empty(M, Hd, dtype=torch.bfloat16, device=dev)
+    N.call("gelu_bwd", k.A1, dH1, dA1, M * Hd)
+    _wgrad(dA1, k.Y2, G[p + "mlp.fc1.weight"], M, Hd, C)
+    E.colsum_add(BF, dA1, M, Hd, G[p + "mlp.fc1.bias"])
+    dY2 = E.linear_bwd_x(BF, dA1, W[p + "mlp.fc1.weight"], M, Hd, C, out_f32=1)
+    N.call("layernorm_bwd", dY2, k.X2, k.mu2, k.rs2, P[p + "norm2.weight"], dX, G[p + "norm2.weight"], G[p + "norm2.bias"], M, C)
+    # ---- attention branch: X2 = X1 + proj(attn(qkv(LN1(X1))))
+    dXb = _cast(dX, M, C)
+    _wgrad(dXb, k.A, G[p + "attn.proj.weight"], M, C, C)
+    E.colsum_add(N.F32, dX, M, C, G[p + "attn.proj.bias"])
+    dA = E.linear_bwd_x(BF, dXb, W[p + "attn.proj.weight"], M, C, C)                   # bf16 [M, C]
+    dQKV = torch.empty(M, 3 * C, dtype=torch.bfloat16, device=dev)
+    N.call("attn_bwd", k.QKV, k.A, dA, k.lse, dQKV, B, Ntok, H, scale)
+    _wgrad(dQKV, k.Y1, G[p + "attn.qkv.weight"], M, 3 * C, C)
+    E.colsum_add(BF, dQKV, M, 3 * C, G[p + "attn.qkv.bias"])
+    dY1 = E.linear_bwd_x(BF, dQKV, W[p + "attn.qkv.weight"], M, 3 * C, C, out_f32=1)
+    N.call("layernorm_bwd", dY1, k.X1, k.mu1, k.rs1, P[p + "norm1.weight"], dX, G[p + "norm1.weight"], G[p + "norm1.bias"], M, C)
 
 
 def vit_backward(c, P, W, G, dout):
@@ -141,31 +178,7 @@ def vit_backward(c, P, W, G, dout):
     else:
         dX = dYf
     for i in reversed(range(depth)):
-        p = f"v.blocks.{i}."
-        k = c.blocks[i]
-        Hd = W[p + "mlp.fc1.weight"].shape[0]
-        # ---- MLP branch: X3 = X2 + fc2(gelu(fc1(LN2(X2))))
-        dXb = _cast(dX, M, C)
-        _wgrad(dXb, k.H1, G[p + "mlp.fc2.weight"], M, C, Hd)
-        E.colsum_add(N.F32, dX, M, C, G[p + "mlp.fc2.bias"])
-        dH1 = E.linear_bwd_x(BF, dXb, W[p + "mlp.fc2.weight"], M, C, Hd)                   # bf16 [M, Hd]
-        dA1 = torch.empty(M, Hd, dtype=torch.bfloat16, device=dev)
-        N.call("gelu_bwd", k.A1, dH1, dA1, M * Hd)
-        _wgrad(dA1, k.Y2, G[p + "mlp.fc1.weight"], M, Hd, C)
-        E.colsum_add(BF, dA1, M, Hd, G[p + "mlp.fc1.bias"])
-        dY2 = E.linear_bwd_x(BF, dA1, W[p + "mlp.fc1.weight"], M, Hd, C, out_f32=1)
-        N.call("layernorm_bwd", dY2, k.X2, k.mu2, k.rs2, P[p + "norm2.weight"], dX, G[p + "norm2.weight"], G[p + "norm2.bias"], M, C)
-        # ---- attention branch: X2 = X1 + proj(attn(qkv(LN1(X1))))
-        dXb = _cast(dX, M, C)
-        _wgrad(dXb, k.A, G[p + "attn.proj.weight"], M, C, C)
-        E.colsum_add(N.F32, dX, M, C, G[p + "attn.proj.bias"])
-        dA = E.linear_bwd_x(BF, dXb, W[p + "attn.proj.weight"], M, C, C)                   # bf16 [M, C]
-        dQKV = torch.empty(M, 3 * C, dtype=torch.bfloat16, device=dev)
-        N.call("attn_bwd", k.QKV, k.A, dA, k.lse, dQKV, B, Ntok, H, scale)
-        _wgrad(dQKV, k.Y1, G[p + "attn.qkv.weight"], M, 3 * C, C)
-        E.colsum_add(BF, dQKV, M, 3 * C, G[p + "attn.qkv.bias"])
-        dY1 = E.linear_bwd_x(BF, dQKV, W[p + "attn.qkv.weight"], M, 3 * C, C, out_f32=1)
-        N.call("layernorm_bwd", dY1, k.X1, k.mu1, k.rs1, P[p + "norm1.weight"], dX, G[p + "norm1.weight"], G[p + "norm1.bias"], M, C)
+        block_backward(c.blocks[i], P, W, G, f"v.blocks.{i}.", dX, B, Ntok, C, H)
     # ---- patch embedding (the input is data: no gradient beyond the projection) and the position embedding
     dXb = _cast(dX, M, C)
     _wgrad(dXb, c.U, G["v.patch_embed.proj.weight"].view(C, 256), M, C, 256)

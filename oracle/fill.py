@@ -77,3 +77,21 @@ def fill_state_dict_(module, seed=0):
                 v = uniform(shape, salt, 0.8, 1.2)
             p.copy_(torch.from_numpy(v))
     return module
+
+
+def fill_shapes(shapes, seed=0):
+    """`fill_state_dict_` for a plain name -> shape mapping: the same values a module with those parameter names would get."""
+    import torch
+    out = {}
+    for name, shape in shapes.items():
+        salt = (salt_of(name) + 0x9E3779B1 * seed) & 0xFFFFFFFF
+        shape = tuple(shape)
+        if len(shape) >= 2:
+            b = 1.0 / np.sqrt(int(np.prod(shape[1:])))
+            v = uniform(shape, salt, -b, b)
+        elif name.endswith("bias"):
+            v = uniform(shape, salt, -0.1, 0.1)
+        else:
+            v = uniform(shape, salt, 0.8, 1.2)
+        out[name] = torch.from_numpy(v)
+    return out

@@ -543,6 +543,52 @@ def g12_decar(ENC):
          state_keys=np.array(list(sd.keys())))
 
 
+def g15_mvit_block():
+    """The reference's own `MultiScaleBlock` (extras/mast_new/mast/mvit/models/attention.py:304-393) in three configurations
+    (oracle/mvit.py GOLDEN_CONFIGS): outputs + gradient digests.  Only attention.py and common.py of the vendored mvit package
+    are executed: the package `__init__`s pull in fvcore / iopath / simplejson (absent here), so `mvit`, `mvit.utils`,
+    `mvit.models` are registered as empty namespace modules and `mvit.utils.logging` as a stand-in for its `get_logger`
+    (the block does no logging arithmetic)."""
+    import logging
+    from functools import partial
+    from oracle import mvit as OM
+    root = os.path.join(REF, "extras/mast_new/mast")
+    for name, path in (("mvit", "mvit"), ("mvit.utils", "mvit/utils"), ("mvit.models", "mvit/models")):
+        m = types.ModuleType(name)
+        m.__path__ = [os.path.join(root, path)]
+        sys.modules[name] = m
+    lg = types.ModuleType("mvit.utils.logging")
+    lg.get_logger = logging.getLogger
+    sys.modules["mvit.utils.logging"] = lg
+    ATT = importlib.import_module("mvit.models.attention")
+    out = {}
+    for cname, cfg in OM.GOLDEN_CONFIGS.items():
+        hw = cfg["hw"]
+        blk = ATT.MultiScaleBlock(
+            dim=cfg["dim"], dim_out=cfg["dim_out"], num_heads=cfg["heads"], input_size=list(hw), mlp_ratio=4.0, qkv_bias=True,
+            drop_path=0.0, norm_layer=partial(nn.LayerNorm, eps=1e-6),
+            kernel_q=(3, 3) if cfg.get("stride_q") else (), kernel_kv=(3, 3) if cfg.get("stride_kv") else (),
+            stride_q=cfg.get("stride_q", ()), stride_kv=cfg.get("stride_kv", ()), mode="conv", has_cls_embed=False,
+            pool_first=False, rel_pos_spatial=cfg["rel_pos"], rel_pos_zero_init=False,
+            residual_pooling=cfg["residual_pooling"], dim_mul_in_att=cfg.get("dim_mul_in_att", False))
+        fill.fill_state_dict_(blk, seed=150 + len(cname))
+        with torch.no_grad():
+            for n, prm in blk.named_parameters():
+                if "rel_pos" in n:                                   # embedding tables: small values like their trunc-normal init
+                    prm.copy_(torch.from_numpy(fill.uniform(tuple(prm.shape), fill.salt_of(cname + n), -0.2, 0.2)))
+        blk.train()
+        B, L = 2, hw[0] * hw[1]
+        x = torch.from_numpy(fill.normalish((B, L, cfg["dim"]), 1500 + len(cname))).requires_grad_(True)
+        y, hw_out = blk(x, list(hw))
+        gy = torch.from_numpy(fill.uniform(tuple(y.shape), 1501 + len(cname)))
+        (y * gy).sum().backward()
+        gd = grad_digest(blk)
+        out.update({f"{cname}.y": t2n(y), f"{cname}.hw_out": np.array(hw_out), f"{cname}.dx": t2n(x.grad),
+                    f"{cname}.g_names": gd["names"], f"{cname}.g_norms": gd["norms"], f"{cname}.g_heads": gd["heads"],
+                    f"{cname}.state_keys": np.array(list(blk.state_dict().keys()))})
+    save("mvit_block", **out)
+
+
 def main():
     _install_shims()
     sys.path.insert(0, REF)
@@ -568,6 +614,9 @@ def main():
     if len(sys.argv) > 1 and sys.argv[1] == "kmix":
         g14_kmix(A)
         return
+    if len(sys.argv) > 1 and sys.argv[1] == "mvit":
+        g15_mvit_block()
+        return
     g1_window(U)
     g2_runnorm(A)
     g3_aug(A_pkg)
@@ -582,6 +631,7 @@ def main():
     g12_decar(ENC)
     g13_schedules(MP)
     g14_kmix(A)
+    g15_mvit_block()
 
 
 if __name__ == "__main__":

@@ -126,6 +126,37 @@ def test_adamw_matches_torch():
     np.testing.assert_allclose(p[:n].cpu().numpy(), ref_p.detach().numpy(), rtol=2e-5, atol=1e-7)
 
 
+# ------------------------------------------------------------------------------------------------ one block vs the reference
+def test_transformer_block_vs_reference_multiscale_block(golden):
+    """The HIP block launch sequence (LayerNorm, qkv GEMM, attention, proj + residual, LayerNorm, MLP + residual) against
+    outputs of the reference's own `MultiScaleBlock` without pooling (`mvit/models/attention.py:304-393`, fixture
+    `mvit_block.npz` / `plain`): output, input gradient and every parameter gradient.  bf16 MFMA operands: 1e-2 / 3e-2."""
+    from oracle import mvit as OM
+    from src import _native as N
+    from src import vit_engine as VE
+    g = golden("mvit_block")
+    Pc, x, kw, gsalt = OM.golden_case("plain")
+    C, H = kw["dim"], kw["heads"]
+    B, Ntok = x.shape[0], x.shape[1]
+    P = {k: v.cuda().contiguous() for k, v in Pc.items()}
+    W = {k: v.bfloat16().contiguous() for k, v in P.items() if v.dim() == 2}
+    X = x.reshape(B * Ntok, C).cuda().contiguous()
+    Y, ctx = VE.block_forward(P, W, "", X, B, Ntok, C, H, 1e-6)
+    torch.cuda.synchronize()
+    want = torch.from_numpy(g["plain.y"]).reshape(B * Ntok, C)
+    assert rel_l2(Y.cpu(), want) < 1e-2
+    G = {k: torch.zeros_like(v) for k, v in P.items()}
+    dX = torch.from_numpy(fill.uniform((B, Ntok, C), gsalt)).reshape(B * Ntok, C).cuda().contiguous()
+    VE.block_backward(ctx, P, W, G, "", dX, B, Ntok, C, H)
+    torch.cuda.synchronize()
+    assert rel_l2(dX.cpu(), torch.from_numpy(g["plain.dx"]).reshape(B * Ntok, C)) < 3e-2
+    for n, norm, head in zip(g["plain.g_names"], g["plain.g_norms"], g["plain.g_heads"]):
+        gr = G[str(n)].cpu()
+        assert abs(float(gr.norm()) - norm) <= 3e-2 * norm, (n, float(gr.norm()), norm)
+        h = gr.flatten()[:8].numpy()
+        assert np.abs(h - head[:h.size]).max() <= 3e-2 * max(np.abs(head).max(), norm / np.sqrt(gr.numel())) + 1e-6, n
+
+
 # ------------------------------------------------------------------------------------------------ whole encoder
 @pytest.mark.parametrize("depth,B,F,T", [(2, 4, 128, 101), (12, 2, 128, 101), (2, 8, 64, 96), (2, 2, 128, 1001)])
 def test_ast_encoder_forward_backward_vs_oracle(depth, B, F, T):

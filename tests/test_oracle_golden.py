@@ -360,3 +360,44 @@ def test_kmix_oracle_vs_reference_golden(golden):
     assert np.random.random() == float(g["tail"])
     for c in (0, 1, 5, 127, 128, 129, 141, 169):
         np.testing.assert_allclose(ys[c].numpy(), g[f"y{c}"], rtol=1e-6, atol=1e-6)
+
+
+@pytest.mark.parametrize("cname", ["plain", "pooled", "transition"])
+def test_mvit_block_oracle_vs_reference_block(golden, cname):
+    """oracle/mvit.py against outputs of the reference's own `MultiScaleBlock` (mvit/models/attention.py:304-393): the plain
+    pre-norm ViT block the AST encoder stacks, a pooled in-stage block with relative positions, and a stage transition."""
+    from oracle import mvit as OM
+    g = golden("mvit_block")
+    P, x, kw, gsalt = OM.golden_case(cname)
+    assert sorted(P) == sorted(str(k) for k in g[f"{cname}.state_keys"])
+    P = {k: v.requires_grad_(True) for k, v in P.items()}
+    x.requires_grad_(True)
+    y, hw_out = OM.multiscale_block(P, x, OM.GOLDEN_CONFIGS[cname]["hw"], **kw)
+    assert list(hw_out) == list(g[f"{cname}.hw_out"])
+    np.testing.assert_allclose(y.detach().numpy(), g[f"{cname}.y"], rtol=1e-4, atol=2e-5)
+    (y * torch.from_numpy(fill.uniform(tuple(y.shape), gsalt))).sum().backward()
+    np.testing.assert_allclose(x.grad.numpy(), g[f"{cname}.dx"], rtol=1e-3, atol=2e-5)
+    for n, norm, head in zip(g[f"{cname}.g_names"], g[f"{cname}.g_norms"], g[f"{cname}.g_heads"]):
+        gr = P[str(n)].grad
+        assert abs(float(gr.norm()) - norm) <= 1e-4 * norm + 1e-7, n
+        h = gr.flatten()[:8].numpy()
+        np.testing.assert_allclose(h, head[:h.size], rtol=2e-3, atol=1e-5)
+
+
+def test_vit_oracle_block_is_the_unpooled_reference_block(golden):
+    """oracle/vit.py's transformer block (the AST-base encoder's) against the reference's `MultiScaleBlock` run without
+    pooling / relative positions: pins the block arithmetic that timm (absent here) would otherwise have to vouch for."""
+    from oracle import mvit as OM
+    from oracle import vit as OV
+    g = golden("mvit_block")
+    P, x, kw, gsalt = OM.golden_case("plain")
+    blk = OV.Block(kw["dim"], kw["heads"], 4.0, 1e-6)
+    blk.load_state_dict(P)
+    x.requires_grad_(True)
+    y = blk(x)
+    np.testing.assert_allclose(y.detach().numpy(), g["plain.y"], rtol=1e-4, atol=2e-5)
+    (y * torch.from_numpy(fill.uniform(tuple(y.shape), gsalt))).sum().backward()
+    np.testing.assert_allclose(x.grad.numpy(), g["plain.dx"], rtol=1e-3, atol=2e-5)
+    grads = dict(blk.named_parameters())
+    for n, norm in zip(g["plain.g_names"], g["plain.g_norms"]):
+        assert abs(float(grads[str(n)].grad.norm()) - norm) <= 1e-4 * norm + 1e-7, n
