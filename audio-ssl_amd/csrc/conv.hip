@@ -31,7 +31,7 @@ typedef __attribute__((address_space(3))) bf16x4* lds4_t;
 
 struct ConvArgs {
     const bf16* X; const bf16* W; const float* bias; bf16* Y; double* sum; double* sumsq;
-    int Ti, rows_total, tiles, out_f32;
+    int Ti, rows_total, tiles, out_f32, dbg;
 };
 
 template <int FI, int PITCH, int NTH = 256>
@@ -111,7 +111,7 @@ __global__ __launch_bounds__(64 * NW, 1) void conv3x3_kernel(ConvArgs a) {
     for (; tile < a.tiles; tile += gridDim.x) {
         const int g0 = tile * TT;
         const int next = tile + gridDim.x;
-        if (next < a.tiles) halo.load(a.X, next * TT, a.rows_total);
+        if (next < a.tiles && !(a.dbg & 2)) halo.load(a.X, next * TT, a.rows_total);
 
         // per-lane geometry of the 32-pixel row-tiles this wave owns
         int tl[RT], fcol[RT];
@@ -134,6 +134,7 @@ __global__ __launch_bounds__(64 * NW, 1) void conv3x3_kernel(ConvArgs a) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
+        if (!(a.dbg & 4))
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) {
             const int dt = tap % 3, df = tap / 3;                 // tap = kh*3 + kw: kh walks mel (f), kw walks time (t)
@@ -158,7 +159,7 @@ __global__ __launch_bounds__(64 * NW, 1) void conv3x3_kernel(ConvArgs a) {
 #pragma unroll
         for (int i = 0; i < RT; ++i) {
             const int g = g0 + tl[i];
-            if (g < a.rows_total) {
+            if (g < a.rows_total && !(a.dbg & 1)) {
                 const long o = ((long)g * FI + fcol[i]) * CH;
 #pragma unroll
                 for (int j = 0; j < 2; ++j)
@@ -200,6 +201,260 @@ __global__ __launch_bounds__(64 * NW, 1) void conv3x3_kernel(ConvArgs a) {
             double t = 0.0;
 #pragma unroll
             for (int w = 0; w < NW; ++w) t += (double)red[(w * 64 + c) * 2 + k];
+            atomicAdd(k == 0 ? &a.sum[c] : &a.sumsq[c], t);
+        }
+    }
+}
+
+// ---- weights-stationary variant (the default): the 64 x 576 weight matrix lives in REGISTERS (72 MFMA A-fragments = 288
+// VGPRs per wave, loaded once per persistent workgroup), so the k-loop reads only pixel fragments from LDS: 2 ds_read_b128
+// per 4 MFMAs instead of 3 per 2 (the kernel above was LDS-read bound: 48 us of k-loop against 24 us of MFMA time at
+// B = 512, tools/conv_fwd_ablate.py).  4 waves x (64 pixels x 64 channels); 256-pixel tiles as above.
+// The halo tile is double-buffered and filled by LDS-DMA (buffer_load ... lds, no staging registers): pixel pitch 128 bytes,
+// 16-byte chunk c of the pixel in halo column `col` stored at chunk position c ^ ((col >> 1) & 7) (16 consecutive columns then
+// cover all 64 banks once: conflict-free ds_read_b128) - the swizzle is applied to the
+// DMA's source address, rows outside [0, rows_total) come back as zeros from the buffer bounds check.  One raw s_barrier
+// per tile; the epilogue's global stores are issued after the wait for the next tile's DMA and drain under the next k-loop.
+// Epilogue: the MFMA result layout (lane = pixel, 4 consecutive channels per register group) would store 8-byte pieces - 64
+// separate write requests per instruction, which made the stores the second largest cost of the kernel above (37 us at
+// B = 512).  Each wave transposes its 32-pixel row-tiles through a private, swizzled LDS staging area instead and writes whole
+// pixels: 1 KB contiguous per store instruction.
+template <int FI>
+struct WsGeom {
+    static constexpr int TT = 256 / FI, COLS = FI + 2, ROWS = TT + 2, SEGS = FI / 8;
+    static constexpr int UNITS = ROWS * SEGS;                    // DMA instructions per tile (8 pixels = 1 KB each)
+    static constexpr int UPW = (UNITS + 3) / 4;                  // per wave
+    static constexpr int BYTES = ROWS * COLS * 128;
+};
+
+template <int FI, bool STATS, bool F32OUT>
+__global__ __launch_bounds__(256, 1) void conv3x3_ws_kernel(ConvArgs a) {
+    using G = WsGeom<FI>;
+    constexpr int TT = G::TT, COLS = G::COLS;
+    typedef __attribute__((address_space(3))) void* lptr_t;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* const biasl = reinterpret_cast<float*>(smem + 2 * G::BYTES);          // [64]
+    float* const red = biasl + 64;                                              // [4][64][2]
+    constexpr int OPIX = F32OUT ? 256 : 128;                                    // bytes per staged output pixel
+    char* const stg = reinterpret_cast<char*>(red + 4 * 64 * 2) + (threadIdx.x >> 6) * 64 * OPIX;   // this wave's 2 x 32-pixel staging tiles
+    char* const zblk = reinterpret_cast<char*>(red + 4 * 64 * 2) + 4 * 64 * OPIX;                   // 512 bytes of zeros
+    if (threadIdx.x < 32) *reinterpret_cast<f32x4*>(zblk + threadIdx.x * 16) = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int m = lane & 31, h = lane >> 5;
+
+    // zero the border columns of both buffers once (the DMA only ever writes interior columns)
+    for (int i = threadIdx.x; i < 2 * G::ROWS * 2 * 8; i += 256) {
+        const int b = i / (G::ROWS * 16), r = (i / 16) % G::ROWS, side = (i >> 3) & 1, c8 = i & 7;
+        *reinterpret_cast<f32x4*>(smem + b * G::BYTES + (r * COLS + side * (FI + 1)) * 128 + c8 * 16) = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    if (threadIdx.x < 64) biasl[threadIdx.x] = a.bias ? a.bias[threadIdx.x] : 0.f;
+
+    // weights: A fragments, row = output channel j * 32 + m, k = ks * 16 + 8 h .. + 7
+    Vec8<bf16> wr[2][36];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int ks = 0; ks < 36; ++ks) wr[j][ks] = Vec8<bf16>::load(a.W + (j * 32 + m) * KTOT + ks * 16 + 8 * h);
+    // pin the homes of the 288 weight registers: channels 0-31 in VGPRs, 32-63 in AGPRs next to the accumulators.  Left to
+    // itself the allocator spreads them over both files and copies four registers into a VGPR temporary before every MFMA,
+    // each copy waiting for the MFMAs in flight to release that temporary (k-loop 50 cycles per MFMA instead of 32).
+#pragma unroll
+    for (int ks = 0; ks < 36; ++ks) {
+        asm volatile("" : "+v"(wr[0][ks].v));
+        asm volatile("" : "+a"(wr[1][ks].v));
+    }
+
+    // DMA addressing: lane -> (pixel of the 8-pixel segment, chunk position); source chunk = position ^ (halo column & 7)
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16*>(a.X), 0, (unsigned)((long)a.rows_total * FI * 128), 0x00020000);
+    const int pl = lane >> 3, cp = lane & 7;
+    const int key0 = ((1 + pl) >> 1) & 7;                                       // swizzle key of halo column 1 + 8 seg + pl, seg even
+    const int voff0 = pl * 128 + ((cp ^ key0) << 4), voff1 = pl * 128 + ((cp ^ key0 ^ 4) << 4);
+    auto dma_tile = [&](int g0, char* buf) {
+#pragma unroll
+        for (int i = 0; i < G::UPW; ++i) {
+            const int u = wave + 4 * i;                                         // wave-uniform
+            if (u < G::UNITS) {
+                const int row = u / G::SEGS, seg = u % G::SEGS;
+                const int gr = g0 - 1 + row;
+                const int so = (gr >= 0 && gr < a.rows_total) ? (gr * FI + 8 * seg) * 128 : 0x7FFFFF00;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lptr_t)(buf + (row * COLS + 1 + 8 * seg) * 128), 16, (seg & 1) ? voff1 : voff0, so, 0, 0);
+            }
+        }
+    };
+
+    // per-lane geometry of this wave's two 32-pixel row-tiles
+    int tl[2];
+    const int fcol = FI == 32 ? m : (m & 15);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int rt = 2 * wave + i;
+        tl[i] = FI == 32 ? rt : 2 * rt + (m >> 4);
+    }
+    int hs[3];                                                                  // ((h ^ swizzle key of column fcol + df) << 4
+#pragma unroll
+    for (int df = 0; df < 3; ++df) hs[df] = (h ^ (((fcol + df) >> 1) & 7)) << 4;
+
+    // batch statistics are taken from the values as they are stored (after the transpose a lane always sees the same NS
+    // channels: 2 * NS accumulators instead of 64 - the weights leave no room for more)
+    constexpr int NS = F32OUT ? 4 : 8;
+    float ssum[NS], ssq[NS];
+    if (STATS) {
+#pragma unroll
+        for (int e = 0; e < NS; ++e) { ssum[e] = 0.f; ssq[e] = 0.f; }
+    }
+
+    int tile = blockIdx.x, cur = 0;
+    if (tile < a.tiles) dma_tile(tile * TT, smem);
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+
+    long* const ts = (!STATS && (a.dbg & 16) && blockIdx.x == 0 && threadIdx.x == 0) ? reinterpret_cast<long*>(a.sum) : nullptr;
+    int tsi = 0;
+    if (ts) ts[60] = __builtin_amdgcn_s_memrealtime();
+    for (; tile < a.tiles; tile += gridDim.x, cur ^= 1) {
+        if (ts) ts[tsi++] = __builtin_amdgcn_s_memtime();
+        const int g0 = tile * TT;
+        const int next = tile + gridDim.x;
+        if (next < a.tiles && !(a.dbg & 2)) dma_tile(next * TT, smem + (cur ^ 1) * G::BYTES);
+        const char* const hl = smem + cur * G::BYTES;
+
+        // rows above / below the image (the global row enumeration runs across images) must read as zeros: such a
+        // (row-tile, dt) gets the address of a block of zeros instead of a select on every fragment
+        int bdt[2][3];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int g = g0 + tl[i];
+            const int ti = g % a.Ti;
+#pragma unroll
+            for (int dt = 0; dt < 3; ++dt) {
+                const bool ok = g < a.rows_total && ti + dt - 1 >= 0 && ti + dt - 1 < a.Ti;
+                bdt[i][dt] = ok ? (int)(size_t)((lptr_t)const_cast<char*>(hl)) + ((tl[i] + dt) * COLS + fcol) * 128
+                                : (int)(size_t)((lptr_t)zblk);
+            }
+        }
+        f32x16 acc[2][2];                                         // start from the bias: channel j * 32 + 8 q + 4 h + e in register 4 q + e
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const f32x4 b4 = *reinterpret_cast<const f32x4*>(biasl + j * 32 + 8 * q + 4 * h);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { acc[0][j][4 * q + e] = b4[e]; acc[1][j][4 * q + e] = b4[e]; }
+            }
+
+        // pixel fragments are fetched PF k-steps ahead of the MFMAs that consume them (one wave per SIMD: nothing else hides
+        // the LDS latency); k-step ks = tap * 4 + cc, tap = kh*3 + kw: kh walks mel (f), kw walks time (t)
+        constexpr int PF = 2;
+        Vec8<bf16> fa[PF + 1][2];
+        auto fetch = [&](int ks, Vec8<bf16> (&f)[2]) {
+            const int tap = ks >> 2, cc = ks & 3, dt = tap % 3, df = tap / 3;
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+                f[i] = Vec8<bf16>::load(reinterpret_cast<const bf16*>((const char*)(lptr_t)(size_t)(bdt[i][dt] + df * 128 + (hs[df] ^ (cc * 32)))));
+        };
+        if (!(a.dbg & 4)) {
+#pragma unroll
+        for (int ks = 0; ks < PF; ++ks) fetch(ks, fa[ks]);
+#pragma unroll
+        for (int ks = 0; ks < 36; ++ks) {
+            if (ks + PF < 36) fetch(ks + PF, fa[(ks + PF) % (PF + 1)]);
+            __builtin_amdgcn_sched_barrier(0);                    // keep the reads ahead: the scheduler otherwise sinks them to their use
+            Vec8<bf16> (&f)[2] = fa[ks % (PF + 1)];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wr[j][ks].v, f[i].v, acc[i][j], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        }
+        if (ts) ts[tsi++] = __builtin_amdgcn_s_memtime();
+        // the next tile's halo has had the whole k-loop to land; the stores below then drain under the next k-loop
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (ts) ts[tsi++] = __builtin_amdgcn_s_memtime();
+        // epilogue: this lane's pixel, channels j * 32 + 8 * q + 4 * h + (0..3) in accumulator registers 4q..4q+3 -> staging
+        if (!(a.dbg & 1)) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                char* const st = stg + i * 32 * OPIX;
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int slot = j * 8 + 2 * q + h;       // 16 slots of 4 channels per pixel
+                        const f32x4 v = f32x4{acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
+                        if (F32OUT) *reinterpret_cast<f32x4*>(st + m * 256 + ((slot ^ (m & 15)) << 4)) = v;
+                        else *reinterpret_cast<bf16x4*>(st + m * 128 + ((slot ^ ((m >> 1) & 15)) << 3)) =
+                                 bf16x4{(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
+                    }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            // whole pixels back out of the staging tiles: 1 KB contiguous per store instruction
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const char* const st = stg + i * 32 * OPIX;
+                const int grow = g0 + (2 * wave + i) * (32 / FI); // the row-tile's 32 consecutive output pixels start at row grow
+                const int prow_ok = a.rows_total - grow;          //   (FI = 16: two rows, the second may be past the end)
+                char* const yrow = reinterpret_cast<char*>(a.Y) + (long)grow * FI * 64 * (F32OUT ? 4 : 2);
+                if (F32OUT) {
+#pragma unroll
+                    for (int it = 0; it < 8; ++it) {
+                        const int p = it * 4 + (lane >> 4), c = lane & 15;
+                        const f32x4 v = *reinterpret_cast<const f32x4*>(st + p * 256 + ((c ^ (p & 15)) << 4));
+                        if ((p >> (FI == 32 ? 5 : 4)) < prow_ok) {
+                            *reinterpret_cast<f32x4*>(yrow + p * 256 + c * 16) = v;
+                            if (STATS) {
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) { ssum[e] += v[e]; ssq[e] += v[e] * v[e]; }
+                            }
+                        }
+                    }
+                } else {
+#pragma unroll
+                    for (int it = 0; it < 4; ++it) {
+                        const int p = it * 8 + (lane >> 3), c = lane & 7, k = (p >> 1) & 15;
+                        f32x4 v = *reinterpret_cast<const f32x4*>(st + p * 128 + ((c ^ (k >> 1)) << 4));
+                        if (k & 1) v = f32x4{v[2], v[3], v[0], v[1]};                  // the two 8-byte slots of the chunk sit swapped
+                        if ((p >> (FI == 32 ? 5 : 4)) < prow_ok) {
+                            *reinterpret_cast<f32x4*>(yrow + p * 128 + c * 16) = v;
+                            if (STATS) {
+                                const bf16x8 hv = __builtin_bit_cast(bf16x8, v);
+#pragma unroll
+                                for (int e = 0; e < 8; ++e) {
+                                    const float x = (float)hv[e];
+                                    ssum[e] += x; ssq[e] += x * x;
+                                }
+                            }
+                        }
+                    }
+                }
+            }
+        }
+        if (ts) ts[tsi++] = __builtin_amdgcn_s_memtime();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();          // every wave is done reading hb[cur]; every wave's share of hb[cur ^ 1] has landed
+    }
+    if (ts) ts[61] = __builtin_amdgcn_s_memrealtime();
+    if (STATS) {
+        // lane l holds channels (l & (64 / NS - 1)) * NS + e; fold the lanes that share them
+#pragma unroll
+        for (int e = 0; e < NS; ++e) {
+            float s = ssum[e], q = ssq[e];
+#pragma unroll
+            for (int o = 64 / NS; o < 64; o <<= 1) { s += __shfl_xor(s, o, 64); q += __shfl_xor(q, o, 64); }
+            if (lane < 64 / NS) {
+                const int co = lane * NS + e;
+                red[(wave * 64 + co) * 2] = s; red[(wave * 64 + co) * 2 + 1] = q;
+            }
+        }
+        __syncthreads();
+        if (threadIdx.x < 128) {
+            const int c = threadIdx.x >> 1, k = threadIdx.x & 1;
+            double t = 0.0;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) t += (double)red[(w * 64 + c) * 2 + k];
             atomicAdd(k == 0 ? &a.sum[c] : &a.sumsq[c], t);
         }
     }
@@ -356,7 +611,7 @@ extern "C" int audiossl_conv3x3_fwd(const void* X, const void* W, const float* b
     ASSL_REQUIRE(X && W && Y && N > 0 && Ti > 0 && (Fi == 32 || Fi == 16) && (!sum == !sumsq));
     if (!ASSL_ALIGNED16(X) || !ASSL_ALIGNED16(W) || !ASSL_ALIGNED16(Y)) return ASSL_EALIGN;
     hipStream_t s = static_cast<hipStream_t>(stream);
-    if (sum) {
+    if (sum && !(getenv("AUDIOSSL_CONV_DBG") && (atoi(getenv("AUDIOSSL_CONV_DBG")) & 16))) {
         if (sumsq == sum + 64) {
             ASSL_ZERO(sum, sizeof(double) * 128, s);
         } else {
@@ -365,8 +620,29 @@ extern "C" int audiossl_conv3x3_fwd(const void* X, const void* W, const float* b
         }
     }
     const int rows = N * Ti, TT = 256 / Fi, tiles = (rows + TT - 1) / TT;
-    ConvArgs a{static_cast<const bf16*>(X), static_cast<const bf16*>(W), bias, static_cast<bf16*>(Y), sum, sumsq, Ti, rows, tiles, out_f32};
+    static const int conv_dbg = getenv("AUDIOSSL_CONV_DBG") ? atoi(getenv("AUDIOSSL_CONV_DBG")) : 0;
+    ConvArgs a{static_cast<const bf16*>(X), static_cast<const bf16*>(W), bias, static_cast<bf16*>(Y), sum, sumsq, Ti, rows, tiles, out_f32, conv_dbg};
     const int grid = tiles < 256 ? tiles : 256;
+    // default: weights-stationary kernel (AUDIOSSL_CONV_WS=0 selects the LDS-weights kernel above)
+    static const int ws = getenv("AUDIOSSL_CONV_WS") ? atoi(getenv("AUDIOSSL_CONV_WS")) : 1;
+    if (ws && (long)rows * Fi * 128 < 0x7FFFFF00L) {
+        static bool wattr[8] = {false, false, false, false, false, false, false, false};
+#define WS_LAUNCH(FI_, ST_, F32_, SLOT)                                                                    \
+    do {                                                                                                  \
+        const size_t lds = 2 * WsGeom<FI_>::BYTES + sizeof(float) * (64 + 4 * 64 * 2) + 4 * 64 * (F32_ ? 256 : 128) + 512; \
+        if (!wattr[SLOT]) { if (set_lds(conv3x3_ws_kernel<FI_, ST_, F32_>, lds)) return ASSL_ELAUNCH; wattr[SLOT] = true; } \
+        hipLaunchKernelGGL((conv3x3_ws_kernel<FI_, ST_, F32_>), dim3(grid), dim3(256), lds, s, a);       \
+    } while (0)
+        if (Fi == 32) {
+            if (sum && !(conv_dbg & 16)) { if (out_f32) WS_LAUNCH(32, true, true, 0); else WS_LAUNCH(32, true, false, 1); }
+            else     { if (out_f32) WS_LAUNCH(32, false, true, 2); else WS_LAUNCH(32, false, false, 3); }
+        } else {
+            if (sum) { if (out_f32) WS_LAUNCH(16, true, true, 4); else WS_LAUNCH(16, true, false, 5); }
+            else     { if (out_f32) WS_LAUNCH(16, false, true, 6); else WS_LAUNCH(16, false, false, 7); }
+        }
+#undef WS_LAUNCH
+        ASSL_LAUNCH_CHECK();
+    }
     static const int nw = getenv("AUDIOSSL_CONV_WAVES") ? atoi(getenv("AUDIOSSL_CONV_WAVES")) : 8;
     static bool attr[4] = {false, false, false, false};
 #define CONV_LAUNCH(FI_, NW_, SLOT)                                                                       \
