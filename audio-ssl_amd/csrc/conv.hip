@@ -227,7 +227,7 @@ struct WsGeom {
     static constexpr int BYTES = ROWS * COLS * 128;
 };
 
-template <int FI, bool STATS, bool F32OUT>
+template <int FI, bool STATS, bool F32OUT, int PF = 2>
 __global__ __launch_bounds__(256, 1) void conv3x3_ws_kernel(ConvArgs a) {
     using G = WsGeom<FI>;
     constexpr int TT = G::TT, COLS = G::COLS;
@@ -242,20 +242,31 @@ __global__ __launch_bounds__(256, 1) void conv3x3_ws_kernel(ConvArgs a) {
 
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int m = lane & 31, h = lane >> 5;
+    long* const rts = (!STATS && (a.dbg & 16) && threadIdx.x == 0 && (blockIdx.x == 0 || blockIdx.x == gridDim.x - 1))
+                          ? reinterpret_cast<long*>(a.sum) + 64 + (blockIdx.x ? 8 : 0) : nullptr;
+    if (rts) rts[0] = __builtin_amdgcn_s_memrealtime();
 
-    // zero the border columns of both buffers once (the DMA only ever writes interior columns)
-    for (int i = threadIdx.x; i < 2 * G::ROWS * 2 * 8; i += 256) {
-        const int b = i / (G::ROWS * 16), r = (i / 16) % G::ROWS, side = (i >> 3) & 1, c8 = i & 7;
-        *reinterpret_cast<f32x4*>(smem + b * G::BYTES + (r * COLS + side * (FI + 1)) * 128 + c8 * 16) = f32x4{0.f, 0.f, 0.f, 0.f};
+    // weights: A fragments, row = output channel j * 32 + m, k = ks * 16 + 8 h .. + 7.  Staged through LDS (the halo buffers
+    // are still free): read straight from global memory every lane fetches its own 1,152-byte-strided row - 4,608 line
+    // requests per wave, 8 us before the first tile could start.
+    {
+        bf16* const wl = reinterpret_cast<bf16*>(smem);           // [64][WPITCH]
+        Vec8<bf16> tmp[CH * KTOT / 8 / 256];                       // 18 loads in flight, then 18 LDS stores
+#pragma unroll
+        for (int k = 0; k < CH * KTOT / 8 / 256; ++k) tmp[k] = Vec8<bf16>::load(a.W + (threadIdx.x + 256 * k) * 8);
+#pragma unroll
+        for (int k = 0; k < CH * KTOT / 8 / 256; ++k) {
+            const int v = threadIdx.x + 256 * k, row = v / (KTOT / 8), c = v % (KTOT / 8);
+            tmp[k].store(wl + row * WPITCH + c * 8);
+        }
+        __syncthreads();
     }
-    if (threadIdx.x < 64) biasl[threadIdx.x] = a.bias ? a.bias[threadIdx.x] : 0.f;
-
-    // weights: A fragments, row = output channel j * 32 + m, k = ks * 16 + 8 h .. + 7
     Vec8<bf16> wr[2][36];
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
-        for (int ks = 0; ks < 36; ++ks) wr[j][ks] = Vec8<bf16>::load(a.W + (j * 32 + m) * KTOT + ks * 16 + 8 * h);
+        for (int ks = 0; ks < 36; ++ks)
+            wr[j][ks] = Vec8<bf16>::load(reinterpret_cast<const bf16*>(smem) + (j * 32 + m) * WPITCH + ks * 16 + 8 * h);
     // pin the homes of the 288 weight registers: channels 0-31 in VGPRs, 32-63 in AGPRs next to the accumulators.  Left to
     // itself the allocator spreads them over both files and copies four registers into a VGPR temporary before every MFMA,
     // each copy waiting for the MFMAs in flight to release that temporary (k-loop 50 cycles per MFMA instead of 32).
@@ -265,14 +276,22 @@ __global__ __launch_bounds__(256, 1) void conv3x3_ws_kernel(ConvArgs a) {
         asm volatile("" : "+a"(wr[1][ks].v));
     }
 
+    __syncthreads();                                                            // every wave holds its weights: the buffers are free
+    // zero the border columns of both buffers once (the DMA only ever writes interior columns)
+    for (int i = threadIdx.x; i < 2 * G::ROWS * 2 * 8; i += 256) {
+        const int b = i / (G::ROWS * 16), r = (i / 16) % G::ROWS, side = (i >> 3) & 1, c8 = i & 7;
+        *reinterpret_cast<f32x4*>(smem + b * G::BYTES + (r * COLS + side * (FI + 1)) * 128 + c8 * 16) = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    if (threadIdx.x < 64) biasl[threadIdx.x] = a.bias ? a.bias[threadIdx.x] : 0.f;
+
+    if (rts) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); rts[3] = __builtin_amdgcn_s_memrealtime(); }
     // DMA addressing: lane -> (pixel of the 8-pixel segment, chunk position); source chunk = position ^ (halo column & 7)
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16*>(a.X), 0, (unsigned)((long)a.rows_total * FI * 128), 0x00020000);
     const int pl = lane >> 3, cp = lane & 7;
     const int key0 = ((1 + pl) >> 1) & 7;                                       // swizzle key of halo column 1 + 8 seg + pl, seg even
     const int voff0 = pl * 128 + ((cp ^ key0) << 4), voff1 = pl * 128 + ((cp ^ key0 ^ 4) << 4);
-    auto dma_tile = [&](int g0, char* buf) {
-#pragma unroll
-        for (int i = 0; i < G::UPW; ++i) {
+    auto dma_unit = [&](int g0, char* buf, int i) {
+        {
             const int u = wave + 4 * i;                                         // wave-uniform
             if (u < G::UNITS) {
                 const int row = u / G::SEGS, seg = u % G::SEGS;
@@ -281,6 +300,10 @@ __global__ __launch_bounds__(256, 1) void conv3x3_ws_kernel(ConvArgs a) {
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lptr_t)(buf + (row * COLS + 1 + 8 * seg) * 128), 16, (seg & 1) ? voff1 : voff0, so, 0, 0);
             }
         }
+    };
+    auto dma_tile = [&](int g0, char* buf) {
+#pragma unroll
+        for (int i = 0; i < G::UPW; ++i) dma_unit(g0, buf, i);
     };
 
     // per-lane geometry of this wave's two 32-pixel row-tiles
@@ -311,7 +334,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_ws_kernel(ConvArgs a) {
 
     long* const ts = (!STATS && (a.dbg & 16) && blockIdx.x == 0 && threadIdx.x == 0) ? reinterpret_cast<long*>(a.sum) : nullptr;
     int tsi = 0;
-    if (ts) ts[60] = __builtin_amdgcn_s_memrealtime();
+    if (rts) rts[1] = __builtin_amdgcn_s_memrealtime();
     for (; tile < a.tiles; tile += gridDim.x, cur ^= 1) {
         if (ts) ts[tsi++] = __builtin_amdgcn_s_memtime();
         const int g0 = tile * TT;
@@ -345,7 +368,6 @@ __global__ __launch_bounds__(256, 1) void conv3x3_ws_kernel(ConvArgs a) {
 
         // pixel fragments are fetched PF k-steps ahead of the MFMAs that consume them (one wave per SIMD: nothing else hides
         // the LDS latency); k-step ks = tap * 4 + cc, tap = kh*3 + kw: kh walks mel (f), kw walks time (t)
-        constexpr int PF = 2;
         Vec8<bf16> fa[PF + 1][2];
         auto fetch = [&](int ks, Vec8<bf16> (&f)[2]) {
             const int tap = ks >> 2, cc = ks & 3, dt = tap % 3, df = tap / 3;
@@ -436,7 +458,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_ws_kernel(ConvArgs a) {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();          // every wave is done reading hb[cur]; every wave's share of hb[cur ^ 1] has landed
     }
-    if (ts) ts[61] = __builtin_amdgcn_s_memrealtime();
+    if (rts) rts[2] = __builtin_amdgcn_s_memrealtime();
     if (STATS) {
         // lane l holds channels (l & (64 / NS - 1)) * NS + e; fold the lanes that share them
 #pragma unroll
@@ -633,6 +655,19 @@ extern "C" int audiossl_conv3x3_fwd(const void* X, const void* W, const float* b
         if (!wattr[SLOT]) { if (set_lds(conv3x3_ws_kernel<FI_, ST_, F32_>, lds)) return ASSL_ELAUNCH; wattr[SLOT] = true; } \
         hipLaunchKernelGGL((conv3x3_ws_kernel<FI_, ST_, F32_>), dim3(grid), dim3(256), lds, s, a);       \
     } while (0)
+        static const int pf = getenv("AUDIOSSL_CONV_PF") ? atoi(getenv("AUDIOSSL_CONV_PF")) : 2;
+        if (Fi == 32 && pf == 3 && !out_f32) {
+            static bool pattr[2] = {false, false};
+            const size_t lds = 2 * WsGeom<32>::BYTES + sizeof(float) * (64 + 4 * 64 * 2) + 4 * 64 * 128 + 512;
+            if (sum) {
+                if (!pattr[0]) { if (set_lds(conv3x3_ws_kernel<32, true, false, 3>, lds)) return ASSL_ELAUNCH; pattr[0] = true; }
+                hipLaunchKernelGGL((conv3x3_ws_kernel<32, true, false, 3>), dim3(grid), dim3(256), lds, s, a);
+            } else {
+                if (!pattr[1]) { if (set_lds(conv3x3_ws_kernel<32, false, false, 3>, lds)) return ASSL_ELAUNCH; pattr[1] = true; }
+                hipLaunchKernelGGL((conv3x3_ws_kernel<32, false, false, 3>), dim3(grid), dim3(256), lds, s, a);
+            }
+            ASSL_LAUNCH_CHECK();
+        }
         if (Fi == 32) {
             if (sum && !(conv_dbg & 16)) { if (out_f32) WS_LAUNCH(32, true, true, 0); else WS_LAUNCH(32, true, false, 1); }
             else     { if (out_f32) WS_LAUNCH(32, false, true, 2); else WS_LAUNCH(32, false, false, 3); }

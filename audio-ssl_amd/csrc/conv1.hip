@@ -319,6 +319,9 @@ __global__ __launch_bounds__(256) void conv1_fwd_mfma_kernel(const float* __rest
     extern __shared__ __attribute__((aligned(16))) float patch[];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, half = lane >> 5, l31 = lane & 31;
     const int To = T / 2, Fo = F / 2;
+    // the item's pooled output [Fo][64] is collected in LDS and written as whole 16-byte pieces (it is one contiguous run of
+    // Fo * 128 bytes): straight from the accumulator layout it was 2 bytes per lane - ~820 k store instructions per launch
+    bf16* const stage = reinterpret_cast<bf16*>(patch + (((F + 2) * 4 + 3) & ~3));
     Vec8<bf16> wb[2];
     float b[2], sc[2], sh[2];
 #pragma unroll
@@ -339,7 +342,6 @@ __global__ __launch_bounds__(256) void conv1_fwd_mfma_kernel(const float* __rest
         for (int tile = wv; tile * 8 < Fo; tile += 4) {
             const int fp = min(tile * 8 + pp, Fo - 1);
             const Vec8<bf16> a = stem_taps(patch, 2 * fp + df, dt, half);
-            bf16* o = out + (((long)n * To + tp) * Fo) * 64;
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
                 f32x16 acc;
@@ -352,12 +354,14 @@ __global__ __launch_bounds__(256) void conv1_fwd_mfma_kernel(const float* __rest
 #pragma unroll
                     for (int r3 = 0; r3 < 4; ++r3) m = fmaxf(m, sc[j] * (acc[4 * q + r3] + b[j]) + sh[j]);
                     const int fpo = tile * 8 + 2 * q + half;
-                    if (fpo < Fo) o[(long)fpo * 64 + 32 * j + l31] = (bf16)m;
+                    if (fpo < Fo) stage[fpo * 64 + 32 * j + l31] = (bf16)m;
                 }
             }
         }
         __syncthreads();
         if (nxt < N * To) pre.put(patch, F);
+        bf16* o = out + (((long)n * To + tp) * Fo) * 64;
+        for (int v = threadIdx.x; v < Fo * 8; v += 256) Vec8<bf16>::load(stage + v * 8).store(o + v * 8);
         __syncthreads();
     }
 }
@@ -623,7 +627,8 @@ extern "C" int audiossl_conv1_fwd(int dtype, const float* img, int N, int F, int
     ASSL_REQUIRE(dtype == 0 || dtype == 1 || dtype == 2);
     hipStream_t s = static_cast<hipStream_t>(stream);
     const int grid = min(N * (T / 2), 2048);
-    const size_t lds = sizeof(float) * (F + 2) * 4;
+    size_t lds = sizeof(float) * (F + 2) * 4;
+    if (dtype == 1) lds = sizeof(float) * (((F + 2) * 4 + 3) & ~3) + sizeof(bf16) * (F / 2) * 64;     // + the output staging tile
     if (dtype == 0)
         hipLaunchKernelGGL(conv1_fwd_kernel<float>, dim3(grid), dim3(256), lds, s, img, w, bias, scale, shift,
                            static_cast<float*>(out), N, F, T);
