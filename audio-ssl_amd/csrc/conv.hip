@@ -633,7 +633,9 @@ extern "C" int audiossl_conv3x3_fwd(const void* X, const void* W, const float* b
     ASSL_REQUIRE(X && W && Y && N > 0 && Ti > 0 && (Fi == 32 || Fi == 16) && (!sum == !sumsq));
     if (!ASSL_ALIGNED16(X) || !ASSL_ALIGNED16(W) || !ASSL_ALIGNED16(Y)) return ASSL_EALIGN;
     hipStream_t s = static_cast<hipStream_t>(stream);
-    if (sum && !(getenv("AUDIOSSL_CONV_DBG") && (atoi(getenv("AUDIOSSL_CONV_DBG")) & 16))) {
+    // AUDIOSSL_CONV_DBG (diagnostics, tools/conv_fwd_ablate.py / conv_ts.py): 1 no epilogue, 2 no halo DMA, 4 no k-loop, 16 cycle stamps
+    static const int conv_dbg = getenv("AUDIOSSL_CONV_DBG") ? atoi(getenv("AUDIOSSL_CONV_DBG")) : 0;
+    if (sum && !(conv_dbg & 16)) {
         if (sumsq == sum + 64) {
             ASSL_ZERO(sum, sizeof(double) * 128, s);
         } else {
@@ -642,7 +644,6 @@ extern "C" int audiossl_conv3x3_fwd(const void* X, const void* W, const float* b
         }
     }
     const int rows = N * Ti, TT = 256 / Fi, tiles = (rows + TT - 1) / TT;
-    static const int conv_dbg = getenv("AUDIOSSL_CONV_DBG") ? atoi(getenv("AUDIOSSL_CONV_DBG")) : 0;
     ConvArgs a{static_cast<const bf16*>(X), static_cast<const bf16*>(W), bias, static_cast<bf16*>(Y), sum, sumsq, Ti, rows, tiles, out_f32, conv_dbg};
     const int grid = tiles < 256 ? tiles : 256;
     // default: weights-stationary kernel (AUDIOSSL_CONV_WS=0 selects the LDS-weights kernel above)
@@ -655,19 +656,6 @@ extern "C" int audiossl_conv3x3_fwd(const void* X, const void* W, const float* b
         if (!wattr[SLOT]) { if (set_lds(conv3x3_ws_kernel<FI_, ST_, F32_>, lds)) return ASSL_ELAUNCH; wattr[SLOT] = true; } \
         hipLaunchKernelGGL((conv3x3_ws_kernel<FI_, ST_, F32_>), dim3(grid), dim3(256), lds, s, a);       \
     } while (0)
-        static const int pf = getenv("AUDIOSSL_CONV_PF") ? atoi(getenv("AUDIOSSL_CONV_PF")) : 2;
-        if (Fi == 32 && pf == 3 && !out_f32) {
-            static bool pattr[2] = {false, false};
-            const size_t lds = 2 * WsGeom<32>::BYTES + sizeof(float) * (64 + 4 * 64 * 2) + 4 * 64 * 128 + 512;
-            if (sum) {
-                if (!pattr[0]) { if (set_lds(conv3x3_ws_kernel<32, true, false, 3>, lds)) return ASSL_ELAUNCH; pattr[0] = true; }
-                hipLaunchKernelGGL((conv3x3_ws_kernel<32, true, false, 3>), dim3(grid), dim3(256), lds, s, a);
-            } else {
-                if (!pattr[1]) { if (set_lds(conv3x3_ws_kernel<32, false, false, 3>, lds)) return ASSL_ELAUNCH; pattr[1] = true; }
-                hipLaunchKernelGGL((conv3x3_ws_kernel<32, false, false, 3>), dim3(grid), dim3(256), lds, s, a);
-            }
-            ASSL_LAUNCH_CHECK();
-        }
         if (Fi == 32) {
             if (sum && !(conv_dbg & 16)) { if (out_f32) WS_LAUNCH(32, true, true, 0); else WS_LAUNCH(32, true, false, 1); }
             else     { if (out_f32) WS_LAUNCH(32, false, true, 2); else WS_LAUNCH(32, false, false, 3); }
