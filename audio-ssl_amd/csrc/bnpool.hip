@@ -111,7 +111,7 @@ __global__ __launch_bounds__(256) void bn_relu_pool_fwd_kernel(const TY* __restr
 // scale / shift / mean / rstd for the backward and updates the running buffers.
 template <typename TY, typename T_>
 __global__ __launch_bounds__(256) void bn_relu_pool_train_fwd_kernel(const TY* __restrict__ Y, const double* __restrict__ sum,
-                                                                     const double* __restrict__ sumsq, double count,
+                                                                     const double* __restrict__ sumsq, int stat_rep, double count,
                                                                      const float* __restrict__ gamma, const float* __restrict__ beta,
                                                                      float* running_mean, float* running_var, float momentum, float eps,
                                                                      T_* __restrict__ P, float* __restrict__ scale,
@@ -121,8 +121,10 @@ __global__ __launch_bounds__(256) void bn_relu_pool_train_fwd_kernel(const TY* _
     if (threadIdx.x < 64) {
         const int c = threadIdx.x;
         const double g = (double)gamma[c], b = (double)beta[c];
-        const double mean = sum[c] / count;
-        double var = sumsq[c] / count - mean * mean;
+        double s1 = 0.0, s2 = 0.0;
+        for (int r = 0; r < stat_rep; ++r) { s1 += sum[r * 128 + c]; s2 += sumsq[r * 128 + c]; }      // fold the replicas
+        const double mean = s1 / count;
+        double var = s2 / count - mean * mean;
         var = var < 0.0 ? 0.0 : var;
         const double rstd = 1.0 / sqrt(var + (double)eps);
         const float sc = (float)(g * rstd), sh = (float)(b - mean * g * rstd);
@@ -417,16 +419,19 @@ extern "C" int audiossl_bn_relu_pool_fwd(int dtype, int ydtype, const void* Y, c
     ASSL_LAUNCH_CHECK();
 }
 
-extern "C" int audiossl_bn_relu_pool_train_fwd(int dtype, int ydtype, const void* Y, const double* sum, const double* sumsq, double count,
+extern "C" int audiossl_bn_relu_pool_train_fwd(int dtype, int ydtype, const void* Y, const double* sum, const double* sumsq,
+                                               int stat_replicas, double count,
                                                const float* gamma, const float* beta, float* running_mean, float* running_var,
                                                float momentum, float eps, void* P, float* scale, float* shift, float* save_mean,
                                                float* save_rstd, int N, int Ti, int Fi, void* stream) {
     ASSL_REQUIRE(Y && sum && sumsq && gamma && beta && P && scale && shift && save_mean && save_rstd && count > 0.0);
+    ASSL_REQUIRE(stat_replicas >= 1 && (stat_replicas == 1 || sumsq == sum + 64));
     ASSL_REQUIRE(N > 0 && Ti >= 2 && Fi >= 2 && (Fi % 2) == 0 && (dtype == 0 || dtype == 1) && (ydtype == 0 || ydtype == dtype));
     const long total = (long)N * (Ti / 2) * (Fi / 2) * 8;
     hipStream_t s = static_cast<hipStream_t>(stream);
 #define PF(TY, TO) hipLaunchKernelGGL((bn_relu_pool_train_fwd_kernel<TY, TO>), dim3(ceil_div(total, 256)), dim3(256), 0, s,          \
-        static_cast<const TY*>(Y), sum, sumsq, count, gamma, beta, running_mean, running_var, momentum, eps, static_cast<TO*>(P), \
+        static_cast<const TY*>(Y), sum, sumsq, stat_replicas, count, gamma, beta, running_mean, running_var, momentum, eps,      \
+        static_cast<TO*>(P),                                                                                                      \
         scale, shift, save_mean, save_rstd, N, Ti, Fi)
     if (dtype == 0) PF(float, float); else if (ydtype == 0) PF(float, bf16); else PF(bf16, bf16);
 #undef PF

@@ -31,7 +31,7 @@ typedef __attribute__((address_space(3))) bf16x4* lds4_t;
 
 struct ConvArgs {
     const bf16* X; const bf16* W; const float* bias; bf16* Y; double* sum; double* sumsq;
-    int Ti, rows_total, tiles, out_f32, dbg;
+    int Ti, rows_total, tiles, out_f32, dbg, stat_rep;
 };
 
 template <int FI, int PITCH, int NTH = 256>
@@ -201,7 +201,8 @@ __global__ __launch_bounds__(64 * NW, 1) void conv3x3_kernel(ConvArgs a) {
             double t = 0.0;
 #pragma unroll
             for (int w = 0; w < NW; ++w) t += (double)red[(w * 64 + c) * 2 + k];
-            atomicAdd(k == 0 ? &a.sum[c] : &a.sumsq[c], t);
+            const int rep = (blockIdx.x % a.stat_rep) * 128;     // replicated accumulators: same-address atomics serialise
+            atomicAdd(k == 0 ? &a.sum[rep + c] : &a.sumsq[rep + c], t);
         }
     }
 }
@@ -477,7 +478,8 @@ __global__ __launch_bounds__(256, 1) void conv3x3_ws_kernel(ConvArgs a) {
             double t = 0.0;
 #pragma unroll
             for (int w = 0; w < 4; ++w) t += (double)red[(w * 64 + c) * 2 + k];
-            atomicAdd(k == 0 ? &a.sum[c] : &a.sumsq[c], t);
+            const int rep = (blockIdx.x % a.stat_rep) * 128;     // replicated accumulators: same-address atomics serialise
+            atomicAdd(k == 0 ? &a.sum[rep + c] : &a.sumsq[rep + c], t);
         }
     }
 }
@@ -627,24 +629,27 @@ int set_lds(K kernel, size_t bytes) {
 
 // X, W, Y bf16.  W = packed [64][576] (audiossl_pack_conv_w: Wf for the forward, Wd for the data gradient).
 // bias / sum / sumsq may be NULL; sum and sumsq (fp64 [64]) are zeroed here.  Fi must be 32 or 16.
+// stat_replicas > 1: sum points to [stat_replicas][128] doubles (replica r: sums at r*128, sums of squares at r*128 + 64, sumsq ==
+// sum + 64); workgroup i adds into replica i % stat_replicas and the consumer folds them (bn_relu_pool_train_fwd).
 // out_f32: Y is float (used for the data gradient that feeds a BatchNorm backward).
 extern "C" int audiossl_conv3x3_fwd(const void* X, const void* W, const float* bias, void* Y, int out_f32, double* sum,
-                                    double* sumsq, int N, int Ti, int Fi, void* stream) {
+                                    double* sumsq, int stat_replicas, int N, int Ti, int Fi, void* stream) {
     ASSL_REQUIRE(X && W && Y && N > 0 && Ti > 0 && (Fi == 32 || Fi == 16) && (!sum == !sumsq));
+    ASSL_REQUIRE(stat_replicas >= 1 && stat_replicas <= 64 && (stat_replicas == 1 || !sum || sumsq == sum + 64));
     if (!ASSL_ALIGNED16(X) || !ASSL_ALIGNED16(W) || !ASSL_ALIGNED16(Y)) return ASSL_EALIGN;
     hipStream_t s = static_cast<hipStream_t>(stream);
     // AUDIOSSL_CONV_DBG (diagnostics, tools/conv_fwd_ablate.py / conv_ts.py): 1 no epilogue, 2 no halo DMA, 4 no k-loop, 16 cycle stamps
     static const int conv_dbg = getenv("AUDIOSSL_CONV_DBG") ? atoi(getenv("AUDIOSSL_CONV_DBG")) : 0;
     if (sum && !(conv_dbg & 16)) {
         if (sumsq == sum + 64) {
-            ASSL_ZERO(sum, sizeof(double) * 128, s);
+            ASSL_ZERO(sum, sizeof(double) * 128 * stat_replicas, s);
         } else {
             ASSL_ZERO(sum, sizeof(double) * 64, s);
             ASSL_ZERO(sumsq, sizeof(double) * 64, s);
         }
     }
     const int rows = N * Ti, TT = 256 / Fi, tiles = (rows + TT - 1) / TT;
-    ConvArgs a{static_cast<const bf16*>(X), static_cast<const bf16*>(W), bias, static_cast<bf16*>(Y), sum, sumsq, Ti, rows, tiles, out_f32, conv_dbg};
+    ConvArgs a{static_cast<const bf16*>(X), static_cast<const bf16*>(W), bias, static_cast<bf16*>(Y), sum, sumsq, Ti, rows, tiles, out_f32, conv_dbg, stat_replicas};
     const int grid = tiles < 256 ? tiles : 256;
     // default: weights-stationary kernel (AUDIOSSL_CONV_WS=0 selects the LDS-weights kernel above)
     static const int ws = getenv("AUDIOSSL_CONV_WS") ? atoi(getenv("AUDIOSSL_CONV_WS")) : 1;

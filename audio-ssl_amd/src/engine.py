@@ -264,6 +264,9 @@ def _wgrad_workspace(device):
     return ws
 
 
+STAT_REPLICAS = 8
+
+
 def _conv_block_fwd(dtype, Pin, Nimg, Ti, Fi, W, bias, bn, train, update_running, col):
     """3x3 conv -> BN -> ReLU -> pool.  bf16: implicit-GEMM kernel with the batch statistics fused into its epilogue;
     fp32 (validation path): im2col + exact-f32 MFMA GEMM + colstats.  Returns (Y, Pout, stats, Wf, Wd)."""
@@ -275,10 +278,13 @@ def _conv_block_fwd(dtype, Pin, Nimg, Ti, Fi, W, bias, bn, train, update_running
     Y = _empty((M, 64), N.torch_dtype(ad), like=Pin)          # BatchNorm input: fp32 on the fp32 and bf16_hp paths
     gamma, beta, rm, rv = bn
     fused = dtype == N.BF16 and Fi in (16, 32)
-    sq = ARENA.scratch((2, 64), torch.float64, Pin) if (fused and train) else None
+    # batch statistics: 8 replicas of the (sum | sum of squares) accumulator when the pooling launch folds them itself
+    # (256 workgroups adding into one set of 128 addresses cost ~12 us at the end of the convolution)
+    rep = STAT_REPLICAS if (fused and train and SYNC_BN is None) else 1
+    sq = ARENA.scratch((rep, 2, 64), torch.float64, Pin) if (fused and train) else None
     if fused:
-        N.call("conv3x3_fwd", Pin, Wf, bias, Y, int(ad == N.F32), None if sq is None else sq[0], None if sq is None else sq[1],
-               Nimg, Ti, Fi)
+        N.call("conv3x3_fwd", Pin, Wf, bias, Y, int(ad == N.F32), None if sq is None else sq[0, 0], None if sq is None else sq[0, 1],
+               rep, Nimg, Ti, Fi)
     else:
         N.call("im2col3x3", dtype, Pin, col, Nimg, Ti, Fi)
         gemm(dtype, 0, 0, M, 64, 576, col, 576, Wf, 576, Y, 64, bias=bias, out_f32=int(ad == N.F32))
@@ -286,11 +292,12 @@ def _conv_block_fwd(dtype, Pin, Nimg, Ti, Fi, W, bias, bn, train, update_running
     if train and fused and SYNC_BN is None:
         # statistics -> scale / shift inside the pooling launch (no bn_finalize node between the convolution and the pooling)
         st = _empty((4, 64), torch.float32, like=Pin)
-        N.call("bn_relu_pool_train_fwd", dtype, ad, Y, sq[0], sq[1], float(M), gamma, beta, rm if update_running else None,
+        N.call("bn_relu_pool_train_fwd", dtype, ad, Y, sq[0, 0], sq[0, 1], rep, float(M), gamma, beta, rm if update_running else None,
                rv if update_running else None, BN_MOMENTUM, BN_EPS, Pout, st[0], st[1], st[2], st[3], Nimg, Ti, Fi)
         return Y, Pout, (st[0], st[1], st[2], st[3]), Wf, Wd
     if train and fused:
         st = _empty((4, 64), torch.float32, like=Pin)
+        sq = sq[0]
         SYNC_BN.all_reduce(sq)
         N.call("bn_finalize", sq[0], sq[1], 1, float(M * SYNC_BN.world), 64, gamma, beta, rm if update_running else None,
                rv if update_running else None, BN_MOMENTUM, BN_EPS, st[0], st[1], st[2], st[3])
@@ -417,7 +424,7 @@ def _conv_block_bwd(dtype, Y, dP, dxl, st, Nimg, Ti, Fi, Pin, Wd, G_w, G_gamma, 
     # dgrad: dPin[pix][ci] = sum_{tap,co} dY[pix + off(tap)][co] * W[co][ci][8 - tap]
     dPin = _empty((Nimg, Ti, Fi, 64), torch.float32, like=Y)            # feeds the previous block's BN backward: fp32
     if fused:
-        N.call("conv3x3_fwd", dY, Wd, None, dPin, 1, None, None, Nimg, Ti, Fi)
+        N.call("conv3x3_fwd", dY, Wd, None, dPin, 1, None, None, 1, Nimg, Ti, Fi)
     else:
         N.call("im2col3x3", dtype, dY, col, Nimg, Ti, Fi)
         gemm(dtype, 0, 0, M, 64, 576, col, 576, Wd, 576, dPin, 64)

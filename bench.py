@@ -64,6 +64,12 @@ def _work(entry, a):
     if entry == "bn_relu_pool_fwd":
         d, yd, n, ti, fi = a[:5]
         return "hbm", n * ti * fi * 64.0 * ES[yd] + n * (ti // 2) * (fi // 2) * 64.0 * ES[d], 0
+    if entry == "bn_relu_pool_train_fwd":       # (dtype, ydtype, replicas, count, momentum, eps, N, Ti, Fi)
+        d, yd = a[:2]
+        n, ti, fi = a[-3:]
+        return "hbm", n * ti * fi * 64.0 * ES[yd] + n * (ti // 2) * (fi // 2) * 64.0 * ES[d], 0
+    if entry == "tmean3_fwd":                   # (dtype, out_f32, To1, Fo1, To2, Fo2, To3, Fo3, N)
+        return "hbm", a[8] * 64.0 * ES[a[0]] * (a[2] * a[3] + a[4] * a[5] + a[6] * a[7]), 0
     if entry == "bn_relu_pool_bwd":
         d, yd, gd, n, ti, fi = a[:6]
         return "hbm", n * ti * fi * 64.0 * (ES[yd] + ES[d]) + n * (ti // 2) * (fi // 2) * 64.0 * ES[gd], 0
@@ -118,7 +124,7 @@ def per_kernel_report(prof, prof_steps, step_ms):
                 key = f"gemm<{'bf16' if a[0] else 'f32'},{GEMM_SYMBOL[(a[1], a[2])]}>"
                 g = gemm_groups.setdefault((a[0], a[1], a[2]), [0.0, 0.0, 0])
                 g[0] += sec; g[1] += 2.0 * a[3] * a[4] * a[5]; g[2] += 1
-            elif entry in ("conv3x3_fwd", "bn_relu_pool_fwd", "bn_relu_pool_bwd", "conv3x3_wgrad", "tmean_fwd"):
+            elif entry in ("conv3x3_fwd", "bn_relu_pool_fwd", "bn_relu_pool_train_fwd", "bn_relu_pool_bwd", "conv3x3_wgrad", "tmean_fwd"):
                 key = f"{entry}[F={a[-1]}]"
             r = rows.setdefault(key, {"sec": 0.0, "work": 0.0, "n": 0, "bound": None, "dt": 0})
             r["sec"] += sec; r["n"] += 1

@@ -129,10 +129,10 @@ int audiossl_bn_relu_pool_fwd(int dtype, int ydtype, const void* Y, const float*
                               int Ti, int Fi, void* stream);
 /* bn_finalize + bn_relu_pool_fwd of one train-mode conv block (64 channels) in one launch: every workgroup derives scale / shift
  * from the fp64 sums itself; scale / shift / mean / rstd (for the backward) and the running buffers are written by workgroup 0. */
-int audiossl_bn_relu_pool_train_fwd(int dtype, int ydtype, const void* Y, const double* sum, const double* sumsq, double count,
-                                    const float* gamma, const float* beta, float* running_mean, float* running_var, float momentum,
-                                    float eps, void* P, float* scale, float* shift, float* save_mean, float* save_rstd, int N, int Ti,
-                                    int Fi, void* stream);
+int audiossl_bn_relu_pool_train_fwd(int dtype, int ydtype, const void* Y, const double* sum, const double* sumsq, int stat_replicas,
+                                    double count, const float* gamma, const float* beta, float* running_mean, float* running_var,
+                                    float momentum, float eps, void* P, float* scale, float* shift, float* save_mean, float* save_rstd,
+                                    int N, int Ti, int Fi, void* stream);
 int audiossl_tmean_fwd(int dtype, int out_f32, const void* P, void* xl, int N, int To, int Fo, void* stream);
 /* x_1, x_2, x_3 of one encoder pass (`audiontt.py:76-93`) in one launch */
 int audiossl_tmean3_fwd(int dtype, int out_f32, const void* P1, void* x1, int To1, int Fo1, const void* P2, void* x2, int To2, int Fo2,
@@ -177,12 +177,14 @@ int audiossl_unpack_conv_dw(const float* dWp, float* dW, void* stream);
 
 /* Implicit-GEMM 3x3 / 64->64 convolution on the bf16 MFMA pipe (no im2col buffer); bf16 only, Fi in {32, 16}.
  * conv3x3_fwd : Y = conv(X, W) (+bias); W = packed [64][576] (pack_conv_w: Wf = forward, Wd = data gradient);
- *               optional BatchNorm batch statistics of the fp32 accumulators: sum / sumsq fp64 [64] (zeroed inside).
+ *               optional BatchNorm batch statistics of the values as stored: sum / sumsq fp64 [64] (zeroed inside).
+ *               stat_replicas > 1: sum -> [stat_replicas][128] doubles (replica r: sums at r*128, sums of squares at r*128 + 64;
+ *               sumsq == sum + 64): workgroup i adds into replica i % stat_replicas, bn_relu_pool_train_fwd folds them.
  * conv3x3_wgrad: dWp fp32 [64][576] += dY^T * patches(X) (caller zeroes; unpack_conv_dw maps back to [co][ci][3][3]).
  *   workspace (optional, 2 * 256 * 64 * 576 floats = 75.5 MB covers every shape): per-workgroup results are stored there and
  *   folded by a second kernel; null = every workgroup adds its result to dWp with fp32 atomics. */
 int audiossl_conv3x3_fwd(const void* X, const void* W, const float* bias, void* Y, int out_f32, double* sum,
-                         double* sumsq, int N, int Ti, int Fi, void* stream);
+                         double* sumsq, int stat_replicas, int N, int Ti, int Fi, void* stream);
 int audiossl_conv3x3_wgrad(const void* dY, const void* X, float* dWp, float* workspace, long workspace_floats, int N, int Ti,
                            int Fi, void* stream);
 

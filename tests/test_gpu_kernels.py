@@ -423,7 +423,7 @@ def test_conv3x3_implicit_gemm_fwd_dgrad_wgrad(N, shape):
     ref = Fnn.conv2d(x_nchw.double(), wq.double(), b.double(), padding=1)                         # [N][co][F][T]
     Y = torch.full((Nimg, Ti, Fi, 64), float("nan"), device="cuda", dtype=torch.bfloat16)
     sq = torch.empty(2, 64, dtype=torch.float64, device="cuda")
-    N.call("conv3x3_fwd", x, Wf, b, Y, 0, sq[0], sq[1], Nimg, Ti, Fi)
+    N.call("conv3x3_fwd", x, Wf, b, Y, 0, sq[0], sq[1], 1, Nimg, Ti, Fi)
     torch.cuda.synchronize()
     ref_cl = ref.permute(0, 3, 2, 1)
     assert rel_l2(Y.float().cpu(), ref_cl.cpu()) < 4e-3                                           # bf16 output rounding only
@@ -438,12 +438,12 @@ def test_conv3x3_implicit_gemm_fwd_dgrad_wgrad(N, shape):
     assert float(((mean - mean_ref).abs() / var_ref.sqrt()).max()) < 2e-3 / np.sqrt(npix / 4800.0) + 1e-4
     assert float(((var - var_ref).abs() / var_ref).max()) < 2e-3
     Y32 = torch.full((Nimg, Ti, Fi, 64), float("nan"), device="cuda", dtype=torch.float32)        # fp32-output variant (bf16_hp)
-    N.call("conv3x3_fwd", x, Wf, b, Y32, 1, None, None, Nimg, Ti, Fi)
+    N.call("conv3x3_fwd", x, Wf, b, Y32, 1, None, None, 1, Nimg, Ti, Fi)
     assert rel_l2(Y32.cpu(), ref_cl.cpu()) < 1e-5
     # data gradient = the same kernel on dY with the flipped / transposed weights
     dy = torch.from_numpy(fill.normalish((Nimg, Ti, Fi, 64), 64 + Ti)).cuda().bfloat16()
     dx = torch.empty(Nimg, Ti, Fi, 64, device="cuda", dtype=torch.float32)       # fp32 output variant
-    N.call("conv3x3_fwd", dy, Wd, None, dx, 1, None, None, Nimg, Ti, Fi)
+    N.call("conv3x3_fwd", dy, Wd, None, dx, 1, None, None, 1, Nimg, Ti, Fi)
     dy_nchw = dy.float().permute(0, 3, 2, 1).contiguous().double()
     ref_dx = torch.nn.grad.conv2d_input(x_nchw.shape, wq.double(), dy_nchw, padding=1).permute(0, 3, 2, 1)
     assert rel_l2(dx.cpu(), ref_dx.cpu()) < 1e-5

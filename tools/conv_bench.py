@@ -14,8 +14,8 @@ for Nimg, Ti, Fi in ((512, 50, 32), (512, 25, 16)):
     Y = torch.empty_like(x); dx = torch.empty(Nimg, Ti, Fi, 64, device="cuda")
     sq = torch.zeros(2, 64, dtype=torch.float64, device="cuda"); dWp = torch.zeros(64, 576, device="cuda")
     gf = 2.0 * Nimg * Ti * Fi * 64 * 576 / 1e6
-    t = timeit(lambda: N.call("conv3x3_fwd", x, Wf, b, Y, 0, sq[0], sq[1], Nimg, Ti, Fi)); print(f"{(Nimg,Ti,Fi)} fwd+stats {t:7.1f} us {gf/t:6.1f} TF/s")
-    t = timeit(lambda: N.call("conv3x3_fwd", dy, Wd, None, dx, 1, None, None, Nimg, Ti, Fi)); print(f"{(Nimg,Ti,Fi)} dgrad f32 {t:7.1f} us {gf/t:6.1f} TF/s")
+    t = timeit(lambda: N.call("conv3x3_fwd", x, Wf, b, Y, 0, sq[0], sq[1], 1, Nimg, Ti, Fi)); print(f"{(Nimg,Ti,Fi)} fwd+stats {t:7.1f} us {gf/t:6.1f} TF/s")
+    t = timeit(lambda: N.call("conv3x3_fwd", dy, Wd, None, dx, 1, None, None, 1, Nimg, Ti, Fi)); print(f"{(Nimg,Ti,Fi)} dgrad f32 {t:7.1f} us {gf/t:6.1f} TF/s")
     t = timeit(lambda: N.call("conv3x3_wgrad", dy, x, dWp, ws, ws.numel(), Nimg, Ti, Fi)); print(f"{(Nimg,Ti,Fi)} wgrad 2-stage {t:7.1f} us {gf/t:6.1f} TF/s")
     t = timeit(lambda: N.call("conv3x3_wgrad", dy, x, dWp, None, 0, Nimg, Ti, Fi)); print(f"{(Nimg,Ti,Fi)} wgrad atomics {t:7.1f} us {gf/t:6.1f} TF/s")
 # stem: batch statistics from the 54 image moments, forward, backward

@@ -12,5 +12,5 @@ N.call("pack_conv_w", 1, w, Wf, Wd)
 Y = torch.empty_like(x)
 sq = torch.zeros(2, 64, dtype=torch.float64, device="cuda")
 for _ in range(30):
-    N.call("conv3x3_fwd", x, Wf, b, Y, 0, sq[0], sq[1], Nimg, Ti, Fi)
+    N.call("conv3x3_fwd", x, Wf, b, Y, 0, sq[0], sq[1], 1, Nimg, Ti, Fi)
 torch.cuda.synchronize()

@@ -14,7 +14,7 @@ N.call("pack_conv_w", 1, w, Wf, Wd)
 Y = torch.empty_like(x)
 ts = torch.zeros(128, dtype=torch.float64, device="cuda")
 for _ in range(3):
-    N.call("conv3x3_fwd", x, Wf, None, Y, 0, ts[:64], ts[64:], Nimg, Ti, Fi)
+    N.call("conv3x3_fwd", x, Wf, None, Y, 0, ts[:64], ts[64:], 1, Nimg, Ti, Fi)
 torch.cuda.synchronize()
 t = ts.view(torch.int64).cpu().numpy()[:52].reshape(13, 4)
 print("tile  kloop  dma_wait  epilogue  barrier+next  (cycles)")

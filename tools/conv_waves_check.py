@@ -17,9 +17,9 @@ for Nimg, Ti, Fi in ((16, 50, 32), (16, 25, 16), (1024, 50, 32)):
     for rep in range(3):
         Y = torch.empty(Nimg, Ti, Fi, 64, device="cuda", dtype=torch.bfloat16)
         sq = torch.zeros(2, 64, dtype=torch.float64, device="cuda")
-        N.call("conv3x3_fwd", x, Wf, b, Y, 0, sq[0], sq[1], Nimg, Ti, Fi)
+        N.call("conv3x3_fwd", x, Wf, b, Y, 0, sq[0], sq[1], 1, Nimg, Ti, Fi)
         dx = torch.empty(Nimg, Ti, Fi, 64, device="cuda", dtype=torch.float32)
-        N.call("conv3x3_fwd", x, Wd, None, dx, 1, None, None, Nimg, Ti, Fi)
+        N.call("conv3x3_fwd", x, Wd, None, dx, 1, None, None, 1, Nimg, Ti, Fi)
         torch.cuda.synchronize()
         res.append((Y.clone(), dx.clone(), sq.clone()))
     same = all(torch.equal(res[0][0], r[0]) and torch.equal(res[0][1], r[1]) for r in res[1:])
