@@ -176,11 +176,27 @@ __global__ __launch_bounds__(256) void tmean_fwd_kernel(const T_* __restrict__ P
     tmean_body<T_, TO>(P, xl, N, To, Fo);
 }
 // the three layer means of one encoder pass (x_1, x_2, x_3) in ONE launch: blockIdx.z = layer
-struct Tmean3 { const void* P[3]; void* xl[3]; int To[3], Fo[3]; };
+struct Tmean3 { const void* P[3]; void* xl[3]; int To[3], Fo[3]; const float* parts; };
 template <typename T_, typename TO>
 __global__ __launch_bounds__(256) void tmean3_fwd_kernel(Tmean3 a, int N) {
     const int l = blockIdx.z;
     if ((int)blockIdx.x * 64 >= a.Fo[l] * 8) return;
+    if (!a.P[l]) {                                               // x_1 from the parts the stem left (fixed order: reproducible)
+        if (a.parts && l == 0) {
+            const long row = (long)a.Fo[0] * 64, tot = (long)N * row;
+            const long i = (long)blockIdx.y * row + blockIdx.x * 512 + threadIdx.x * 2;
+            if (blockIdx.x * 512 + threadIdx.x * 2 < row) {
+                float2 s = *reinterpret_cast<const float2*>(a.parts + i);
+#pragma unroll
+                for (int k = 1; k < 4; ++k) {
+                    const float2 v = *reinterpret_cast<const float2*>(a.parts + k * tot + i);
+                    s.x += v.x; s.y += v.y;
+                }
+                *reinterpret_cast<float2*>(static_cast<float*>(a.xl[0]) + i) = s;
+            }
+        }
+        return;
+    }
     tmean_body<T_, TO>(static_cast<const T_*>(a.P[l]), static_cast<TO*>(a.xl[l]), N, a.To[l], a.Fo[l]);
 }
 
@@ -448,12 +464,14 @@ extern "C" int audiossl_tmean_fwd(int dtype, int out_f32, const void* P, void* x
     ASSL_LAUNCH_CHECK();
 }
 
-extern "C" int audiossl_tmean3_fwd(int dtype, int out_f32, const void* P1, void* x1, int To1, int Fo1, const void* P2, void* x2, int To2,
-                                   int Fo2, const void* P3, void* x3, int To3, int Fo3, int N, void* stream) {
-    ASSL_REQUIRE(P1 && x1 && P2 && x2 && P3 && x3 && N > 0 && To1 > 0 && To2 > 0 && To3 > 0 && Fo1 > 0 && Fo2 > 0 && Fo3 > 0);
+extern "C" int audiossl_tmean3_fwd(int dtype, int out_f32, const void* P1, void* x1, const float* x1_parts, int To1, int Fo1,
+                                   const void* P2, void* x2, int To2, int Fo2, const void* P3, void* x3, int To3, int Fo3, int N,
+                                   void* stream) {
+    ASSL_REQUIRE(x1 && P2 && x2 && P3 && x3 && N > 0 && To1 > 0 && To2 > 0 && To3 > 0 && Fo1 > 0 && Fo2 > 0 && Fo3 > 0);
+    ASSL_REQUIRE((P1 != nullptr) != (x1_parts != nullptr) && (!x1_parts || (out_f32 && dtype == 1)));
     ASSL_REQUIRE(dtype == 0 || dtype == 1);
     hipStream_t s = static_cast<hipStream_t>(stream);
-    Tmean3 a{{P1, P2, P3}, {x1, x2, x3}, {To1, To2, To3}, {Fo1, Fo2, Fo3}};
+    Tmean3 a{{P1, P2, P3}, {x1, x2, x3}, {To1, To2, To3}, {Fo1, Fo2, Fo3}, x1_parts};
     const int gx = ceil_div(max(Fo1, max(Fo2, Fo3)) * 8, 64);
 #define TM3(TI, TO_) hipLaunchKernelGGL((tmean3_fwd_kernel<TI, TO_>), dim3(gx, N, 3), dim3(256), 0, s, a, N)
     if (dtype == 0) TM3(float, float); else if (out_f32) TM3(bf16, float); else TM3(bf16, bf16);

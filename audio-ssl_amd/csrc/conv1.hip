@@ -331,7 +331,7 @@ __device__ __forceinline__ Vec8<bf16> stem_weights(const float* w, int c, int ha
 __global__ __launch_bounds__(256) void conv1_fwd_mfma_kernel(const float* __restrict__ img, const float* __restrict__ w,
                                                              const float* __restrict__ bias, const float* __restrict__ scale,
                                                              const float* __restrict__ shift, bf16* __restrict__ out,
-                                                             int N, int F, int T) {
+                                                             float* __restrict__ xl, int XS, int N, int F, int T) {
     extern __shared__ __attribute__((aligned(16))) float patch[];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, half = lane >> 5, l31 = lane & 31;
     const int To = T / 2, Fo = F / 2;
@@ -348,14 +348,34 @@ __global__ __launch_bounds__(256) void conv1_fwd_mfma_kernel(const float* __rest
     }
     const int pp = l31 >> 2, df = (l31 >> 1) & 1, dt = l31 & 1;          // this lane's A row: pooled pixel pp, window (df, dt)
     PatchRegs pre;
-    int item = blockIdx.x;
-    if (item < N * To) { pre.fetch(img, item / To, item % To, F, T); pre.put(patch, F); }
+    // items (image, pooled time column): strided over the grid - or, when the layer output x_l = mean over time of the pooled
+    // map is wanted too (`audiontt.py:76-78`), XS workgroups per image walking a share of its columns each, so the column sums
+    // stay in registers; each leaves its part in xl[share][N][Fo*64] and tmean3_fwd adds the parts in a fixed order (a separate
+    // pass re-read the whole 105 MB map; one workgroup per image was no faster than that pass; atomics are not reproducible)
+    int item, step, end;
+    if (xl) {
+        const int n = blockIdx.x / XS, s4 = blockIdx.x - n * XS, per = (To + XS - 1) / XS;
+        item = n * To + s4 * per; step = 1; end = n * To + min(To, (s4 + 1) * per);
+    } else {
+        item = blockIdx.x; step = gridDim.x; end = N * To;
+    }
+    float xs[2][2][4];
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) xs[u][j][q] = 0.f;
+    if (item < end) { pre.fetch(img, item / To, item % To, F, T); pre.put(patch, F); }
     __syncthreads();
-    for (; item < N * To; item += gridDim.x) {
+    for (; item < end; item += step) {
         const int n = item / To, tp = item - n * To;
-        const int nxt = item + gridDim.x;
-        if (nxt < N * To) pre.fetch(img, nxt / To, nxt % To, F, T);
-        for (int tile = wv; tile * 8 < Fo; tile += 4) {
+        const int nxt = item + step;
+        if (nxt < end) pre.fetch(img, nxt / To, nxt % To, F, T);
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int tile = wv + 4 * u;                          // Fo <= 63: at most two 8-row tiles per wave
+            if (tile * 8 >= Fo) break;
             const int fp = min(tile * 8 + pp, Fo - 1);
             const Vec8<bf16> a = stem_taps(patch, 2 * fp + df, dt, half);
 #pragma unroll
@@ -370,15 +390,34 @@ __global__ __launch_bounds__(256) void conv1_fwd_mfma_kernel(const float* __rest
 #pragma unroll
                     for (int r3 = 0; r3 < 4; ++r3) m = fmaxf(m, sc[j] * (acc[4 * q + r3] + b[j]) + sh[j]);
                     const int fpo = tile * 8 + 2 * q + half;
-                    if (fpo < Fo) stage[fpo * 64 + 32 * j + l31] = (bf16)m;
+                    if (fpo < Fo) {
+                        const bf16 mb = (bf16)m;
+                        stage[fpo * 64 + 32 * j + l31] = mb;
+                        xs[u][j][q] += (float)mb;
+                    }
                 }
             }
         }
         __syncthreads();
-        if (nxt < N * To) pre.put(patch, F);
+        if (nxt < end) pre.put(patch, F);
         bf16* o = out + (((long)n * To + tp) * Fo) * 64;
         for (int v = threadIdx.x; v < Fo * 8; v += 256) Vec8<bf16>::load(stage + v * 8).store(o + v * 8);
         __syncthreads();
+    }
+    if (xl) {
+        const int n = blockIdx.x / XS, s4 = blockIdx.x - n * XS;
+        const float inv = 1.f / (float)To;
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int fpo = (wv + 4 * u) * 8 + 2 * q + half;
+                    if (fpo < Fo) {
+                        xl[((long)s4 * N + n) * Fo * 64 + fpo * 64 + 32 * j + l31] = xs[u][j][q] * inv;   // this quarter's part
+                    }
+                }
     }
 }
 
@@ -640,11 +679,13 @@ extern "C" int audiossl_conv1_finalize(double* mom_totals, const float* w, const
 }
 
 extern "C" int audiossl_conv1_fwd(int dtype, const float* img, int N, int F, int T, const float* w, const float* bias,
-                                  const float* scale, const float* shift, void* out, void* stream) {
+                                  const float* scale, const float* shift, void* out, float* xl, void* stream) {
     ASSL_REQUIRE(img && w && bias && scale && shift && out && N > 0 && F >= 2 && F <= 126 && T >= 2 && (F % 2) == 0);
     ASSL_REQUIRE(dtype == 0 || dtype == 1 || dtype == 2);
+    ASSL_REQUIRE(!xl || dtype == 1);                              // the fused layer mean exists for the MFMA kernel only
     hipStream_t s = static_cast<hipStream_t>(stream);
-    const int grid = min(N * (T / 2), 2048);
+    const int xs_split = 4;                                       // AUDIOSSL_CONV1_XL_PARTS in include/audiossl_hip.h
+    const int grid = xl ? N * xs_split : min(N * (T / 2), 2048);
     size_t lds = sizeof(float) * (F + 2) * 4;
     if (dtype == 1) lds = sizeof(float) * (((F + 2) * 4 + 3) & ~3) + sizeof(bf16) * (F / 2) * 64;     // + the output staging tile
     if (dtype == 0)
@@ -655,7 +696,7 @@ extern "C" int audiossl_conv1_fwd(int dtype, const float* img, int N, int F, int
                            static_cast<bf16*>(out), N, F, T);
     else
         hipLaunchKernelGGL(conv1_fwd_mfma_kernel, dim3(grid), dim3(256), lds, s, img, w, bias, scale, shift,
-                           static_cast<bf16*>(out), N, F, T);
+                           static_cast<bf16*>(out), xl, xs_split, N, F, T);
     ASSL_LAUNCH_CHECK();
 }
 

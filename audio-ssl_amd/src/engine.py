@@ -354,7 +354,13 @@ def encoder_forward(P, x, dtype, keep=None, p_drop=0.3, train=True, update_runni
     c.P1 = _empty((Nimg, T1, F1, 64), td, like=x)
     # bf16: the stem conv is a bf16 MFMA; bf16_hp keeps the fp32 VALU convolution (exact pooling arg-max) with bf16 output
     c.stem_mfma = dtype == N.BF16 and not HP and not _STEM_VALU
-    N.call("conv1_fwd", dtype if (dtype == N.F32 or c.stem_mfma) else 2, img, Nimg, F, T, w1, b1, c.sc1, c.sh1, c.P1)
+    x1 = x2 = x3 = None
+    if want_layers:
+        x1, x2, x3 = layer_out if layer_out is not None else (_empty((Nimg, f * 64), td, like=x) for f in (F // 2, F // 4, F // 8))
+    # the MFMA stem also leaves x_1 (mean over time of its pooled output) when an fp32 buffer is wanted for it
+    x1_fused = c.stem_mfma and x1 is not None and x1.dtype == torch.float32 and x1.is_contiguous()
+    x1_parts = _empty((4, Nimg, (F // 2) * 64), torch.float32, like=x) if x1_fused else None        # AUDIOSSL_CONV1_XL_PARTS
+    N.call("conv1_fwd", dtype if (dtype == N.F32 or c.stem_mfma) else 2, img, Nimg, F, T, w1, b1, c.sc1, c.sh1, c.P1, x1_parts)
     col = _col_buffer(dtype, Nimg, T1, F1, x)
     bn2 = (P["features_2.1.weight"], P["features_2.1.bias"], P["features_2.1.running_mean"], P["features_2.1.running_var"])
     c.Y2, c.P2, c.st2, c.W2f, c.W2d = _conv_block_fwd(dtype, c.P1, Nimg, T1, F1, P["features_2.0.weight"],
@@ -366,11 +372,9 @@ def encoder_forward(P, x, dtype, keep=None, p_drop=0.3, train=True, update_runni
     del col
     T3, F3 = T2 // 2, F2 // 2
     c.dims = (T1, F1, T2, F2, T3, F3)
-    x1 = x2 = x3 = None
     if want_layers:
-        x1, x2, x3 = layer_out if layer_out is not None else (_empty((Nimg, f * 64), td, like=x) for f in (F1, F2, F3))
         o32 = int(x1.dtype == torch.float32)
-        N.call("tmean3_fwd", dtype, o32, c.P1, x1, T1, F1, c.P2, x2, T2, F2, c.P3, x3, T3, F3, Nimg)
+        N.call("tmean3_fwd", dtype, o32, None if x1_fused else c.P1, x1, x1_parts, T1, F1, c.P2, x2, T2, F2, c.P3, x3, T3, F3, Nimg)
     d = P["fc.0.weight"].shape[0]
     kin = F3 * 64
     M = Nimg * T3

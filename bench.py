@@ -68,8 +68,8 @@ def _work(entry, a):
         d, yd = a[:2]
         n, ti, fi = a[-3:]
         return "hbm", n * ti * fi * 64.0 * ES[yd] + n * (ti // 2) * (fi // 2) * 64.0 * ES[d], 0
-    if entry == "tmean3_fwd":                   # (dtype, out_f32, To1, Fo1, To2, Fo2, To3, Fo3, N)
-        return "hbm", a[8] * 64.0 * ES[a[0]] * (a[2] * a[3] + a[4] * a[5] + a[6] * a[7]), 0
+    if entry == "tmean3_fwd":                   # (dtype, out_f32, To1, Fo1, To2, Fo2, To3, Fo3, N); x_1 comes from the stem's parts
+        return "hbm", a[8] * 64.0 * (ES[a[0]] * (a[4] * a[5] + a[6] * a[7]) + 16.0 * a[3]), 0
     if entry == "bn_relu_pool_bwd":
         d, yd, gd, n, ti, fi = a[:6]
         return "hbm", n * ti * fi * 64.0 * (ES[yd] + ES[d]) + n * (ti // 2) * (fi // 2) * 64.0 * ES[gd], 0

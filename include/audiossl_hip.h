@@ -105,8 +105,12 @@ int audiossl_mask_fill(float* x, const int* tab, int n_img, int max_masks, int F
 int audiossl_conv1_stats(const float* img, int N, int F, int T, const float* w, const float* bias, const float* gamma,
                          const float* beta, float* running_mean, float* running_var, float momentum, float eps,
                          double* mom, float* scale, float* shift, float* save_mean, float* save_rstd, void* stream);
+/* xl (optional, dtype 1 only): fp32 [AUDIOSSL_CONV1_XL_PARTS][N][F/2 * 64]: four partial sums of the mean over pooled time of
+ * `out` (the layer output x_1, audiontt.py:76-78), left by the same launch; tmean3_fwd(x1_parts) adds them in a fixed order -
+ * the separate tmean pass re-read the whole pooled map */
+#define AUDIOSSL_CONV1_XL_PARTS 4
 int audiossl_conv1_fwd(int dtype, const float* img, int N, int F, int T, const float* w, const float* bias,
-                       const float* scale, const float* shift, void* out, void* stream);
+                       const float* scale, const float* shift, void* out, float* xl, void* stream);
 int audiossl_conv1_bwd(int dtype, int conv_dtype, const float* img, int N, int F, int T, const float* w, const float* bias,
                        const float* gamma, const float* scale, const float* shift, const float* mean, const float* rstd,
                        const double* mom, const void* dP, const void* dxl, float* acc, float* dW, float* dbias,
@@ -134,9 +138,10 @@ int audiossl_bn_relu_pool_train_fwd(int dtype, int ydtype, const void* Y, const 
                                     float momentum, float eps, void* P, float* scale, float* shift, float* save_mean, float* save_rstd,
                                     int N, int Ti, int Fi, void* stream);
 int audiossl_tmean_fwd(int dtype, int out_f32, const void* P, void* xl, int N, int To, int Fo, void* stream);
-/* x_1, x_2, x_3 of one encoder pass (`audiontt.py:76-93`) in one launch */
-int audiossl_tmean3_fwd(int dtype, int out_f32, const void* P1, void* x1, int To1, int Fo1, const void* P2, void* x2, int To2, int Fo2,
-                        const void* P3, void* x3, int To3, int Fo3, int N, void* stream);
+/* x_1, x_2, x_3 of one encoder pass (`audiontt.py:76-93`) in one launch; with P1 == NULL and x1_parts given (out_f32 only)
+ * x_1 = sum of the AUDIOSSL_CONV1_XL_PARTS parts conv1_fwd left */
+int audiossl_tmean3_fwd(int dtype, int out_f32, const void* P1, void* x1, const float* x1_parts, int To1, int Fo1, const void* P2,
+                        void* x2, int To2, int Fo2, const void* P3, void* x3, int To3, int Fo3, int N, void* stream);
 int audiossl_bn_relu_pool_bwd(int dtype, int ydtype, int gdtype, const void* Y, const void* dP, const void* dxl, const float* scale,
                               const float* shift, const float* mean, const float* rstd, float* stat, void* dY,
                               float* dgamma, float* dbeta, int N, int Ti, int Fi, void* stream);

@@ -362,8 +362,19 @@ def test_conv1_block_fwd_bwd(N, dtype, T):
     img = dev(x[:, 0])
     N.call("conv1_stats", img, Nimg, F_, T, w, b, gamma, beta, rm, rv, 0.1, 1e-5, mom, scale, shift, mean, rstd)
     P = torch.empty(Nimg, T // 2, F_ // 2, 64, device="cuda", dtype=td)
-    N.call("conv1_fwd", dtype, img, Nimg, F_, T, w, b, scale, shift, P)
+    xl = torch.full((4, Nimg, (F_ // 2) * 64), float("nan"), device="cuda") if dtype == 1 else None
+    N.call("conv1_fwd", dtype, img, Nimg, F_, T, w, b, scale, shift, P, xl)
     torch.cuda.synchronize()
+    if xl is not None:              # fused layer output x_1 = mean over time of the pooled map as stored, left as four partial sums
+        want = P.float().mean(1).reshape(Nimg, -1)
+        np.testing.assert_allclose(xl.sum(0).cpu().numpy(), want.cpu().numpy(), rtol=1e-5, atol=1e-6)
+        x1 = torch.full_like(want, float("nan"))
+        P2 = torch.randn(Nimg, 6, 16, 64, device="cuda").bfloat16(); P3 = torch.randn(Nimg, 3, 8, 64, device="cuda").bfloat16()
+        x2, x3 = torch.empty(Nimg, 16 * 64, device="cuda"), torch.empty(Nimg, 8 * 64, device="cuda")
+        N.call("tmean3_fwd", 1, 1, None, x1, xl, T // 2, F_ // 2, P2, x2, 6, 16, P3, x3, 3, 8, Nimg)
+        torch.cuda.synchronize()
+        assert torch.equal(x1, (xl[0] + xl[1]) + xl[2] + xl[3])     # the parts are added in this fixed order
+        np.testing.assert_allclose(x2.cpu().numpy(), P2.float().mean(1).reshape(Nimg, -1).cpu().numpy(), rtol=1e-5, atol=1e-6)
     ref_cl = ref.detach().permute(0, 3, 2, 1)                       # [N, T/2, F/2, 64]
     assert rel_l2(P.float().cpu(), ref_cl) < (1e-5 if dtype == 0 else 1e-2)         # dtype 1: bf16 MFMA operands + bf16 output
     np.testing.assert_allclose(rm.cpu().numpy(), bn.running_mean.numpy(), rtol=1e-4, atol=1e-6)
@@ -584,7 +595,7 @@ def test_multi_head_launches_equal_single_ones(N):
         x3 = [torch.full_like(t, -1.0) for t in x1]
         for P, x, (T, F) in zip(Ps, x1, dims):
             N.call("tmean_fwd", dt, o32, P, x, Nimg, T, F)
-        N.call("tmean3_fwd", dt, o32, Ps[0], x3[0], *dims[0], Ps[1], x3[1], *dims[1], Ps[2], x3[2], *dims[2], Nimg)
+        N.call("tmean3_fwd", dt, o32, Ps[0], x3[0], None, *dims[0], Ps[1], x3[1], *dims[1], Ps[2], x3[2], *dims[2], Nimg)
         torch.cuda.synchronize()
         for u, v in zip(x1, x3):
             assert torch.equal(u, v)

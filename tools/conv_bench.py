@@ -25,4 +25,6 @@ gm = torch.rand(64, device="cuda") + 0.5; bt = torch.randn(64, device="cuda"); r
 mom = torch.zeros(16 * 54, dtype=torch.float64, device="cuda"); st = torch.empty(4, 64, device="cuda")
 t = timeit(lambda: N.call("conv1_stats", img, Nimg, F, T, w, b, gm, bt, rm, rv, 0.1, 1e-5, mom, st[0], st[1], st[2], st[3])); print(f"conv1_stats {t:7.1f} us")
 P = torch.empty(Nimg, T // 2, F // 2, 64, device="cuda", dtype=torch.bfloat16)
-t = timeit(lambda: N.call("conv1_fwd", 1, img, Nimg, F, T, w, b, st[0], st[1], P)); print(f"conv1_fwd (MFMA) {t:7.1f} us")
+t = timeit(lambda: N.call("conv1_fwd", 1, img, Nimg, F, T, w, b, st[0], st[1], P, None)); print(f"conv1_fwd (MFMA) {t:7.1f} us")
+xl = torch.empty(4, Nimg, (F // 2) * 64, device="cuda")
+t = timeit(lambda: N.call("conv1_fwd", 1, img, Nimg, F, T, w, b, st[0], st[1], P, xl)); print(f"conv1_fwd (MFMA) + layer mean {t:7.1f} us")
