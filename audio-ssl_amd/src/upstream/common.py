@@ -181,11 +181,12 @@ class GraphedStep:
         self._takes_optimizer = "optimizer" in inspect.signature(expert.fused_loss).parameters
         self.key = None
         self.replays = 0
-        # AUDIOSSL_FUSED_REFRESH=1: let the SGD pass also write the bf16 weight copies and clear the gradients (nobody reads
-        # the gradients between the optimiser pass and the next forward).  Off by default: measured 2.86 vs 2.81 ms/step on
-        # delores_m - the two sweeps it removes ran beside the key encoder's convolutions anyway, while the fatter head SGD
-        # competes with the encoder-backward GEMMs for HBM.
-        if hasattr(optimizer, "fused_refresh") and os.environ.get("AUDIOSSL_FUSED_REFRESH", "0") == "1":
+        # The SGD pass also writes the bf16 weight copies and clears the gradients (nobody reads the gradients between the
+        # optimiser pass and the next forward): the cast sweep over the 38 M parameters (228 MB, ~65 us) and the gradient clear
+        # leave the next step.  Round 1 measured this as a small loss (2.86 vs 2.81 ms: the sweeps ran beside the key
+        # encoder's convolutions); with the serial kernels shorter it is a gain (2.41 vs 2.43-2.48 ms).  AUDIOSSL_FUSED_REFRESH=0
+        # switches it off.
+        if hasattr(optimizer, "fused_refresh") and os.environ.get("AUDIOSSL_FUSED_REFRESH", "1") == "1":
             optimizer.fused_refresh = True
 
     def _hyper(self):
