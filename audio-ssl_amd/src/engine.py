@@ -11,6 +11,8 @@ the path.  Gradients are ACCUMULATED into the tensors handed in (flat-buffer vie
 Activation layout [N][T][F][64] (time, mel, channel); `dtype` 0 = fp32 storage / exact-f32 MFMA,
 1 = bf16 storage / bf16 MFMA with fp32 accumulate (parameters, statistics, losses stay fp32).
 """
+import os
+
 import torch
 
 from src import _native as N
@@ -22,6 +24,10 @@ BN_EPS = 1e-5
 _BN_FUSED = _os.environ.get("AUDIOSSL_BN_FUSED", "1") != "0"
 
 
+# AUDIOSSL_ONE_STREAM=1: no side streams at all - every launch of a step goes to the current stream in program order
+ONE_STREAM = os.environ.get("AUDIOSSL_ONE_STREAM", "0") == "1"
+
+
 class SideStream:
     """A second HIP stream for work that is off the critical dependency chain (weight-gradient GEMMs, the key
     encoder): `run(fn)` orders the side stream after everything enqueued so far on the current stream, `join()`
@@ -31,19 +37,24 @@ class SideStream:
         self._streams = {}
 
     def stream(self, device):
+        if ONE_STREAM:
+            return torch.cuda.current_stream(device)
         key = str(device)
         if key not in self._streams:
             self._streams[key] = torch.cuda.Stream(device=device)
         return self._streams[key]
 
     def run(self, device, fn):
+        if ONE_STREAM:
+            return fn()
         s = self.stream(device)
         s.wait_stream(torch.cuda.current_stream(device))
         with torch.cuda.stream(s):
             return fn()
 
     def join(self, device):
-        torch.cuda.current_stream(device).wait_stream(self.stream(device))
+        if not ONE_STREAM:
+            torch.cuda.current_stream(device).wait_stream(self.stream(device))
 
 
 WGRAD = SideStream()

@@ -24,6 +24,8 @@ from src.utils import concat_all_gather
 
 
 _PREP_ASIDE = os.environ.get("AUDIOSSL_PREP_ASIDE", "1") != "0"
+_HEADS_ASIDE = os.environ.get("AUDIOSSL_HEADS_ASIDE", "1") != "0"        # 0: the grouped Barlow heads are issued on the main stream
+_SGD_ASIDE = os.environ.get("AUDIOSSL_SGD_ASIDE", "1") != "0"            # 0: the early head-segment SGD is issued on the main stream
 
 
 def _world():
@@ -164,7 +166,8 @@ class Upstream_Expert(MocoQueueMixin, FusedExpertMixin, UpstreamModule):
         heads = (self.p1, self.p2, self.p3)
         if self.high_precision or dt == N.F32 or not self.grouped_heads:
             for i, p in enumerate(heads):
-                streams[i].wait_stream(main)
+                if not E.ONE_STREAM:
+                    streams[i].wait_stream(main)
                 with torch.cuda.stream(streams[i]):
                     dys[i] = R.phase(f"head{i + 1}", lambda i=i, p=p: head_phase(i, p))
         else:
@@ -178,8 +181,10 @@ class Upstream_Expert(MocoQueueMixin, FusedExpertMixin, UpstreamModule):
                     [p.param_dict() for p in heads], [G(f"p{i + 1}.") for i in range(3)], Ys, dt, [p.lambd for p in heads],
                     [p.scale_loss for p in heads], [loss[i + 1:i + 2] for i in range(3)], update_running=self.training,
                     backward=need_grad, Wcs=[tuple(Wp[f"projector.{j}.weight"] for j in (0, 3, 6)) for Wp in Wps])
-            streams[0].wait_stream(main)
-            with torch.cuda.stream(streams[0]):
+            hs = streams[0] if _HEADS_ASIDE else main
+            if not E.ONE_STREAM and _HEADS_ASIDE:
+                streams[0].wait_stream(main)
+            with torch.cuda.stream(hs):
                 dys = list(R.phase("heads", heads_phase))
 
         def moco_phase():
@@ -198,7 +203,8 @@ class Upstream_Expert(MocoQueueMixin, FusedExpertMixin, UpstreamModule):
         # after the logits and dq GEMMs have read the queue; the new keys go into the fp32 queue and its bf16 shadow
         self._dequeue_and_enqueue(kn32, self.queue_shadow(dt) if dt != N.F32 else None)
         for st in streams:
-            main.wait_stream(st)
+            if not E.ONE_STREAM:
+                main.wait_stream(st)
         for d in dys:
             if d is not None:
                 d.record_stream(main)
@@ -208,8 +214,9 @@ class Upstream_Expert(MocoQueueMixin, FusedExpertMixin, UpstreamModule):
             if optimizer is not None and not ddp and hasattr(optimizer, "step_tail"):
                 # single rank: the head parameters can be updated right now, on a side stream under the encoder backward
                 # (nothing reads the fp32 head weights or their gradients again in this step)
-                early = streams[0]
-                early.wait_stream(main)
+                early = streams[0] if _SGD_ASIDE else main
+                if not E.ONE_STREAM and _SGD_ASIDE:
+                    early.wait_stream(main)
                 with torch.cuda.stream(early):
                     if R.phase("sgd_heads", lambda: optimizer.step_tail(flat, self.head_offset())):
                         optimizer.mark_early(flat, self.head_offset())
@@ -220,7 +227,7 @@ class Upstream_Expert(MocoQueueMixin, FusedExpertMixin, UpstreamModule):
                 E.encoder_backward(cq, G("encoder_q.encoder."), dA2=dA2, dx1=dys[0], dx2=dys[1], dx3=dys[2])
                 return loss.sum()
             total = R.phase("encoder_bwd", backward_phase)
-            if early is not None:
+            if early is not None and not E.ONE_STREAM and _SGD_ASIDE:
                 main.wait_stream(early)
             self.reduce_begin("enc")
         else:
@@ -230,6 +237,8 @@ class Upstream_Expert(MocoQueueMixin, FusedExpertMixin, UpstreamModule):
         return total
 
     def _streams(self, dev):
+        if E.ONE_STREAM:
+            return [torch.cuda.current_stream(dev)] * 3
         if getattr(self, "_side_streams", None) is None or self._side_streams[0].device != dev:
             self._side_streams = [torch.cuda.Stream(device=dev) for _ in range(3)]
         return self._side_streams
