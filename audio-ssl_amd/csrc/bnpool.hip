@@ -375,6 +375,20 @@ __global__ void pack_conv_w_kernel(const float* __restrict__ W, T_* __restrict__
     Wd[idx] = from_f32<T_>(W[(c * 64 + row) * 9 + (8 - tap)]);           // row = ci, c = co
 }
 
+// both 3x3 layers of an encoder in one launch (blockIdx.y = layer)
+template <typename T_>
+__global__ void pack_conv_w2_kernel(const float* __restrict__ Wa, T_* __restrict__ Wfa, T_* __restrict__ Wda,
+                                    const float* __restrict__ Wb, T_* __restrict__ Wfb, T_* __restrict__ Wdb) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= 64 * 576) return;
+    const float* W = blockIdx.y ? Wb : Wa;
+    T_* Wf = blockIdx.y ? Wfb : Wfa;
+    T_* Wd = blockIdx.y ? Wdb : Wda;
+    const int row = idx / 576, k = idx % 576, tap = k / 64, c = k % 64;
+    Wf[idx] = from_f32<T_>(W[(row * 64 + c) * 9 + tap]);
+    Wd[idx] = from_f32<T_>(W[(c * 64 + row) * 9 + (8 - tap)]);
+}
+
 // dWp fp32 [co][tap*64+ci] -> dW [co][ci][3][3] +=
 __global__ void unpack_conv_dw_kernel(const float* __restrict__ dWp, float* __restrict__ dW) {
     const int idx = blockIdx.x * 256 + threadIdx.x;
@@ -561,6 +575,17 @@ extern "C" int audiossl_pack_conv_w(int dtype, const float* W, void* Wf, void* W
     DISPATCH_T(dtype,
         hipLaunchKernelGGL(pack_conv_w_kernel<float>, dim3(144), dim3(256), 0, s, W, static_cast<float*>(Wf), static_cast<float*>(Wd)),
         hipLaunchKernelGGL(pack_conv_w_kernel<bf16>, dim3(144), dim3(256), 0, s, W, static_cast<bf16*>(Wf), static_cast<bf16*>(Wd)));
+    ASSL_LAUNCH_CHECK();
+}
+
+extern "C" int audiossl_pack_conv_w2(int dtype, const float* Wa, void* Wfa, void* Wda, const float* Wb, void* Wfb, void* Wdb, void* stream) {
+    ASSL_REQUIRE(Wa && Wfa && Wda && Wb && Wfb && Wdb && (dtype == 0 || dtype == 1));
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    DISPATCH_T(dtype,
+        hipLaunchKernelGGL(pack_conv_w2_kernel<float>, dim3(144, 2), dim3(256), 0, s, Wa, static_cast<float*>(Wfa), static_cast<float*>(Wda),
+                           Wb, static_cast<float*>(Wfb), static_cast<float*>(Wdb)),
+        hipLaunchKernelGGL(pack_conv_w2_kernel<bf16>, dim3(144, 2), dim3(256), 0, s, Wa, static_cast<bf16*>(Wfa), static_cast<bf16*>(Wda),
+                           Wb, static_cast<bf16*>(Wfb), static_cast<bf16*>(Wdb)));
     ASSL_LAUNCH_CHECK();
 }
 

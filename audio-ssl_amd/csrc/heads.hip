@@ -439,6 +439,32 @@ __global__ __launch_bounds__(64) void l2norm_fwd_kernel(const float* __restrict_
     if (threadIdx.x == 0) inv_norm[b] = inv;
 }
 
+// the MoCo head's prologue in one launch (`delores_m/upstream_expert.py:235-252`): both normalisations and the positive logit -
+// the arithmetic of l2norm_fwd (twice) and rowdot, per row, in the same order
+template <typename T_>
+__global__ __launch_bounds__(64) void moco_prep_kernel(const float* __restrict__ q, const float* __restrict__ k, int D, float scale,
+                                                       T_* __restrict__ qn, float* __restrict__ qn32, float* __restrict__ qinv,
+                                                       T_* __restrict__ kn, float* __restrict__ kn32, float* __restrict__ kinv,
+                                                       float* __restrict__ lpos) {
+    const long b = blockIdx.x;
+    float sq = 0.f, sk = 0.f;
+    for (int d = threadIdx.x; d < D; d += 64) {
+        const float v = q[b * D + d], u = k[b * D + d];
+        sq += v * v; sk += u * u;
+    }
+    sq = wave_sum(sq); sk = wave_sum(sk);
+    const float iq = 1.f / fmaxf(sqrtf(sq), 1e-12f), ik = 1.f / fmaxf(sqrtf(sk), 1e-12f);
+    float s = 0.f;
+    for (int d = threadIdx.x; d < D; d += 64) {
+        const float v = q[b * D + d] * iq, u = k[b * D + d] * ik;
+        qn32[b * D + d] = v; qn[b * D + d] = from_f32<T_>(v);
+        kn32[b * D + d] = u; kn[b * D + d] = from_f32<T_>(u);
+        s += v * u;
+    }
+    s = wave_sum(s);
+    if (threadIdx.x == 0) { qinv[b] = iq; kinv[b] = ik; lpos[b] = s * scale; }
+}
+
 // lpos[b] = <qn_b, kn_b> / temp
 __global__ __launch_bounds__(64) void rowdot_kernel(const float* __restrict__ a, const float* __restrict__ bb, int D, float scale,
                                                     float* __restrict__ out) {
@@ -606,9 +632,11 @@ __global__ __launch_bounds__(256) void sgd_kernel(float* __restrict__ p, float* 
 }
 
 // pk = pk*m + pq*(1-m)
-__global__ __launch_bounds__(256) void ema_kernel(float* __restrict__ pk, const float* __restrict__ pq, long n, float m) {
+// shadow (optional): bf16 copy of the updated pk, written in the same pass (the key encoder's MFMA operands)
+__global__ __launch_bounds__(256) void ema_kernel(float* __restrict__ pk, const float* __restrict__ pq, long n, float m,
+                                                  bf16* __restrict__ shadow) {
     const float om = 1.f - m;
-    const bool vec = ((reinterpret_cast<size_t>(pk) | reinterpret_cast<size_t>(pq)) & 15) == 0;
+    const bool vec = ((reinterpret_cast<size_t>(pk) | reinterpret_cast<size_t>(pq)) & 15) == 0 && (reinterpret_cast<size_t>(shadow) & 7) == 0;
     const long n4 = vec ? n / 4 : 0;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
         f32x4 a = *reinterpret_cast<const f32x4*>(pk + i * 4);
@@ -616,8 +644,13 @@ __global__ __launch_bounds__(256) void ema_kernel(float* __restrict__ pk, const 
 #pragma unroll
         for (int k = 0; k < 4; ++k) a[k] = a[k] * m + b[k] * om;
         *reinterpret_cast<f32x4*>(pk + i * 4) = a;
+        if (shadow) *reinterpret_cast<bf16x4*>(shadow + i * 4) = bf16x4{(bf16)a[0], (bf16)a[1], (bf16)a[2], (bf16)a[3]};
     }
-    for (long i = n4 * 4 + (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) pk[i] = pk[i] * m + pq[i] * om;
+    for (long i = n4 * 4 + (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        const float v = pk[i] * m + pq[i] * om;
+        pk[i] = v;
+        if (shadow) shadow[i] = (bf16)v;
+    }
 }
 
 // 8 elements per thread and trip (16-byte stores of bf16); `vec` = both pointers 16-byte aligned
@@ -905,6 +938,16 @@ extern "C" int audiossl_l2norm_fwd(int dtype, const float* q, int B, int D, void
     ASSL_LAUNCH_CHECK();
 }
 
+extern "C" int audiossl_moco_prep(int dtype, const float* q, const float* k, int B, int D, float scale, void* qn, float* qn32, float* qinv,
+                                  void* kn, float* kn32, float* kinv, float* lpos, void* stream) {
+    ASSL_REQUIRE(q && k && qn && qn32 && qinv && kn && kn32 && kinv && lpos && B > 0 && D > 0 && (dtype == 0 || dtype == 1));
+    if (dtype == 0) hipLaunchKernelGGL(moco_prep_kernel<float>, dim3(B), dim3(64), 0, S_(stream), q, k, D, scale, (float*)qn, qn32, qinv,
+                                       (float*)kn, kn32, kinv, lpos);
+    else            hipLaunchKernelGGL(moco_prep_kernel<bf16>, dim3(B), dim3(64), 0, S_(stream), q, k, D, scale, (bf16*)qn, qn32, qinv,
+                                       (bf16*)kn, kn32, kinv, lpos);
+    ASSL_LAUNCH_CHECK();
+}
+
 extern "C" int audiossl_rowdot(const float* a, const float* b, int B, int D, float scale, float* out, void* stream) {
     ASSL_REQUIRE(a && b && out && B > 0 && D > 0);
     hipLaunchKernelGGL(rowdot_kernel, dim3(B), dim3(64), 0, S_(stream), a, b, D, scale, out);
@@ -965,10 +1008,10 @@ extern "C" int audiossl_sgd_momentum(float* p, float* g, float* buf, long n, flo
     ASSL_LAUNCH_CHECK();
 }
 
-extern "C" int audiossl_ema_update(float* pk, const float* pq, long n, float m, void* stream) {
+extern "C" int audiossl_ema_update(float* pk, const float* pq, long n, float m, void* shadow, void* stream) {
     ASSL_REQUIRE(pk && pq && n > 0);
     const int grid = (int)min((long)2048, (n / 4 + 255) / 256 + 1);
-    hipLaunchKernelGGL(ema_kernel, dim3(grid), dim3(256), 0, S_(stream), pk, pq, n, m);
+    hipLaunchKernelGGL(ema_kernel, dim3(grid), dim3(256), 0, S_(stream), pk, pq, n, m, static_cast<bf16*>(shadow));
     ASSL_LAUNCH_CHECK();
 }
 

@@ -278,12 +278,15 @@ def _wgrad_workspace(device):
 STAT_REPLICAS = 8
 
 
-def _conv_block_fwd(dtype, Pin, Nimg, Ti, Fi, W, bias, bn, train, update_running, col):
+def _conv_block_fwd(dtype, Pin, Nimg, Ti, Fi, W, bias, bn, train, update_running, col, packed=None):
     """3x3 conv -> BN -> ReLU -> pool.  bf16: implicit-GEMM kernel with the batch statistics fused into its epilogue;
     fp32 (validation path): im2col + exact-f32 MFMA GEMM + colstats.  Returns (Y, Pout, stats, Wf, Wd)."""
     td = N.torch_dtype(dtype)
-    Wf, Wd = _empty((64, 576), td, like=Pin), _empty((64, 576), td, like=Pin)
-    N.call("pack_conv_w", dtype, W, Wf, Wd)
+    if packed is not None:
+        Wf, Wd = packed
+    else:
+        Wf, Wd = _empty((64, 576), td, like=Pin), _empty((64, 576), td, like=Pin)
+        N.call("pack_conv_w", dtype, W, Wf, Wd)
     M = Nimg * Ti * Fi
     ad = _ad(dtype)
     Y = _empty((M, 64), N.torch_dtype(ad), like=Pin)          # BatchNorm input: fp32 on the fp32 and bf16_hp paths
@@ -374,12 +377,14 @@ def encoder_forward(P, x, dtype, keep=None, p_drop=0.3, train=True, update_runni
     N.call("conv1_fwd", dtype if (dtype == N.F32 or c.stem_mfma) else 2, img, Nimg, F, T, w1, b1, c.sc1, c.sh1, c.P1, x1_parts)
     col = _col_buffer(dtype, Nimg, T1, F1, x)
     bn2 = (P["features_2.1.weight"], P["features_2.1.bias"], P["features_2.1.running_mean"], P["features_2.1.running_var"])
+    packs = [_empty((64, 576), td, like=x) for _ in range(4)]         # both layers' (forward, data-gradient) layouts: one launch
+    N.call("pack_conv_w2", dtype, P["features_2.0.weight"], packs[0], packs[1], P["features_3.0.weight"], packs[2], packs[3])
     c.Y2, c.P2, c.st2, c.W2f, c.W2d = _conv_block_fwd(dtype, c.P1, Nimg, T1, F1, P["features_2.0.weight"],
-                                                       P["features_2.0.bias"], bn2, train, update_running, col)
+                                                       P["features_2.0.bias"], bn2, train, update_running, col, packed=packs[:2])
     T2, F2 = T1 // 2, F1 // 2
     bn3 = (P["features_3.1.weight"], P["features_3.1.bias"], P["features_3.1.running_mean"], P["features_3.1.running_var"])
     c.Y3, c.P3, c.st3, c.W3f, c.W3d = _conv_block_fwd(dtype, c.P2, Nimg, T2, F2, P["features_3.0.weight"],
-                                                       P["features_3.0.bias"], bn3, train, update_running, col)
+                                                       P["features_3.0.bias"], bn3, train, update_running, col, packed=packs[2:])
     del col
     T3, F3 = T2 // 2, F2 // 2
     c.dims = (T1, F1, T2, F2, T3, F3)
@@ -770,10 +775,8 @@ def moco_forward_backward(dtype, q, k, queue, queue_shadow, temperature, loss_ou
     qn, kn = _empty((B, dim), td, like=q), _empty((B, dim), td, like=q)
     qn32, kn32 = _empty((B, dim), torch.float32, like=q), _empty((B, dim), torch.float32, like=q)
     qinv, kinv = _empty((B,), torch.float32, like=q), _empty((B,), torch.float32, like=q)
-    N.call("l2norm_fwd", dtype, q, B, dim, qn, qn32, qinv)
-    N.call("l2norm_fwd", dtype, k, B, dim, kn, kn32, kinv)
     lpos = _empty((B,), torch.float32, like=q)
-    N.call("rowdot", qn32, kn32, B, dim, 1.0 / temperature, lpos)
+    N.call("moco_prep", dtype, q, k, B, dim, 1.0 / temperature, qn, qn32, qinv, kn, kn32, kinv, lpos)
     lse = _empty((B,), torch.float32, like=q)
     dlpos = _empty((B,), torch.float32, like=q)
     Pm = None

@@ -67,6 +67,17 @@ class FlatGroup:
             return
         N.call("cast", dtype, self.data, self._shadow, self.numel)
 
+    def fresh_shadow_buffer(self, dtype):
+        """The bf16 shadow buffer for a kernel that is about to fill it itself (EMA pass); None on the fp32 path.  The next
+        refresh_shadow() is then a no-op."""
+        from src import _native as N
+        if dtype == N.F32:
+            return None
+        if self._shadow is None or self._shadow.device != self.data.device:
+            self._shadow = torch.empty(self.numel, dtype=torch.bfloat16, device=self.data.device)
+        self._fresh_shadow = True
+        return self._shadow
+
     def shadow_dict(self, prefix=""):
         """name (prefix stripped) -> weight in the activation dtype (the fp32 parameter itself on the fp32 path)."""
         src = self.data if self._shadow is None else self._shadow

@@ -260,9 +260,12 @@ class MocoQueueMixin:
         self.flat_k = FlatGroup([(n, p) for n, p in self.encoder_k.named_parameters()])
 
     @torch.no_grad()
-    def _momentum_update_key_encoder(self):
+    def _momentum_update_key_encoder(self, shadow_dtype=None):
+        """EMA of the key encoder (`delores_m/upstream_expert.py:93-99`); with shadow_dtype = bf16 the same pass leaves the bf16
+        copy of the updated weights (the cast launch of `flat_k.refresh_shadow` is then skipped)."""
         self.ensure_flat()
-        N.call("ema_update", self.flat_k.data, self.flat.data, self.flat_k.numel, float(self.hparams.encoder_momentum))
+        sh = self.flat_k.fresh_shadow_buffer(shadow_dtype) if shadow_dtype is not None else None
+        N.call("ema_update", self.flat_k.data, self.flat.data, self.flat_k.numel, float(self.hparams.encoder_momentum), sh)
 
     def queue_shadow(self, dtype):
         """bf16 copy of the negatives' queue, kept current by `enqueue` (which writes the new keys into both): one full cast

@@ -103,7 +103,7 @@ class Upstream_Expert(MocoQueueMixin, FusedExpertMixin, UpstreamModule):
 
         # ---- key encoder (no gradient) on its own stream, concurrent with the query encoder: EMA first, then forward
         def key_phase(x):
-            self._momentum_update_key_encoder()
+            self._momentum_update_key_encoder(shadow_dtype=dt)
             self.flat_k.refresh_shadow(dt)
             Wk = self.flat_k.shadow_dict()
             keepk = ek.encoder.next_keep_mask(B, x.shape[-1])

@@ -58,7 +58,7 @@ class Upstream_Expert(MocoQueueMixin, FusedExpertMixin, UpstreamModule):
     def _momentum_update_key_encoder(self, epoch=None):
         self.ensure_flat()
         em = adjust_moco_momentum((self._epoch() if epoch is None else epoch) + 1)
-        N.call("ema_update", self.flat_k.data, self.flat.data, self.flat_k.numel, float(em))
+        N.call("ema_update", self.flat_k.data, self.flat.data, self.flat_k.numel, float(em), None)
 
     def graph_key(self):
         return (self._epoch(),)                   # the EMA momentum is a launch argument: a new epoch re-captures the graph

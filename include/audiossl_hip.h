@@ -178,6 +178,8 @@ int audiossl_colbn_bwd_apply(int dtype, int adtype, int gdtype, const void* a, c
                              const double* sums, double count, void* da, void* stream);
 int audiossl_im2col3x3(int dtype, const void* X, void* col, int N, int Ti, int Fi, void* stream);
 int audiossl_pack_conv_w(int dtype, const float* W, void* Wf, void* Wd, void* stream);
+/* the two 3x3 layers of one encoder (features_2.0 / features_3.0, audiontt.py:52-60) in one launch */
+int audiossl_pack_conv_w2(int dtype, const float* Wa, void* Wfa, void* Wda, const float* Wb, void* Wfb, void* Wdb, void* stream);
 int audiossl_unpack_conv_dw(const float* dWp, float* dW, void* stream);
 
 /* Implicit-GEMM 3x3 / 64->64 convolution on the bf16 MFMA pipe (no im2col buffer); bf16 only, Fi in {32, 16}.
@@ -255,6 +257,9 @@ int audiossl_barlow_loss(int dtype, const float* c, int D, float coef, float dsc
 
 /* ---- K12/K13 MoCo head: delores_m/upstream_expert.py:147-172, 231-264, 270 -------------------------------- */
 int audiossl_l2norm_fwd(int dtype, const float* q, int B, int D, void* qn, float* qn32, float* inv_norm, void* stream);
+/* l2norm_fwd of q and of k and rowdot(qn, kn) * scale in one launch (the MoCo head's prologue) */
+int audiossl_moco_prep(int dtype, const float* q, const float* k, int B, int D, float scale, void* qn, float* qn32, float* qinv,
+                       void* kn, float* kn32, float* kinv, float* lpos, void* stream);
 int audiossl_rowdot(const float* a, const float* b, int B, int D, float scale, float* out, void* stream);
 int audiossl_moco_ce_fwd(const float* lpos, const float* lneg, int B, int K, float* lse, float* loss_out, void* stream);
 int audiossl_moco_ce_bwd(int dtype, const float* lpos, const float* lneg, const float* lse, int B, int K, float gscale,
@@ -273,7 +278,8 @@ int audiossl_l2norm_bwd(int dtype, const float* dqn, const float* dlpos, const f
  * from it and advanced by B (mod K) on the device, so the call can sit inside a captured hipGraph; `ptr` is then ignored. */
 int audiossl_enqueue(int dtype, const float* keys, int B, int D, int K, int ptr, long long* ptr_dev, float* queue, void* shadow,
                      void* stream);
-int audiossl_ema_update(float* pk, const float* pq, long n, float m, void* stream);
+/* shadow (optional): bf16 [n], the updated pk as the key encoder's MFMA operands, written in the same pass */
+int audiossl_ema_update(float* pk, const float* pq, long n, float m, void* shadow, void* stream);
 
 /* Host-side switch: 1 = every scratch pointer handed to the entry points below is already zero (the caller cleared its whole
  * scratch arena with one memset), so they skip their own hipMemsetAsync; 0 (default) = they zero their scratch themselves. */

@@ -216,10 +216,30 @@ def test_vectorised_elementwise_kernels_match_scalar_definitions():
         N.call("cast", 1, src[off:], dst[off:], n)
         pk, pq = torch.randn(n + off, generator=g).cuda(), torch.randn(n + off, generator=g).cuda()
         want = pk[off:] * 0.99 + pq[off:] * (1.0 - 0.99)
-        N.call("ema_update", pk[off:], pq[off:], n, 0.99)
+        N.call("ema_update", pk[off:], pq[off:], n, 0.99, None)
         torch.cuda.synchronize()
         assert torch.equal(dst[off:], src[off:].bfloat16())
         np.testing.assert_allclose(pk[off:].cpu().numpy(), want.cpu().numpy(), rtol=1e-6, atol=1e-7)
+        sh = torch.zeros(n + off + 8, dtype=torch.bfloat16, device="cuda")      # the same pass also leaves the bf16 copy
+        pk2 = pk.clone()
+        N.call("ema_update", pk2[off:], pq[off:], n, 0.5, sh[off:off + n])
+        torch.cuda.synchronize()
+        assert torch.equal(sh[off:off + n], pk2[off:].bfloat16()) and float(sh[off + n:].abs().sum()) == 0.0
+    # moco_prep = l2norm_fwd(q), l2norm_fwd(k), rowdot in one launch: bit-identical
+    B, D = 37, 128
+    q, k = torch.randn(B, D, generator=g).cuda() * 3, torch.randn(B, D, generator=g).cuda()
+    o1 = [torch.empty(B, D, device="cuda", dtype=torch.bfloat16), torch.empty(B, D, device="cuda"), torch.empty(B, device="cuda"),
+          torch.empty(B, D, device="cuda", dtype=torch.bfloat16), torch.empty(B, D, device="cuda"), torch.empty(B, device="cuda"),
+          torch.empty(B, device="cuda")]
+    o2 = [torch.empty_like(t) for t in o1]
+    N.call("l2norm_fwd", 1, q, B, D, o1[0], o1[1], o1[2])
+    N.call("l2norm_fwd", 1, k, B, D, o1[3], o1[4], o1[5])
+    N.call("rowdot", o1[1], o1[4], B, D, 1.0 / 0.2, o1[6])
+    N.call("moco_prep", 1, q, k, B, D, 1.0 / 0.2, *o2)
+    torch.cuda.synchronize()
+    for u, v in zip(o1[:6], o2[:6]):
+        assert torch.equal(u, v)
+    np.testing.assert_allclose(o2[6].cpu().numpy(), o1[6].cpu().numpy(), rtol=1e-6, atol=1e-7)      # sum order / contraction only
     for K in (64, 100):                                            # K % 8 != 0 takes the scalar path
         B = 5
         lpos, lneg = torch.randn(B, generator=g).cuda(), torch.randn(B, K, generator=g).cuda()

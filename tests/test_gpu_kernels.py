@@ -429,6 +429,13 @@ def test_conv3x3_implicit_gemm_fwd_dgrad_wgrad(N, shape):
     Wf = torch.empty(64, 576, device="cuda", dtype=torch.bfloat16)
     Wd = torch.empty_like(Wf)
     N.call("pack_conv_w", 1, w, Wf, Wd)
+    w2 = torch.from_numpy(fill.uniform((64, 64, 3, 3), 66, -0.05, 0.05)).cuda()
+    pk = [torch.empty_like(Wf) for _ in range(4)]
+    N.call("pack_conv_w2", 1, w, pk[0], pk[1], w2, pk[2], pk[3])            # both layers in one launch = two single packs
+    Wf2, Wd2 = torch.empty_like(Wf), torch.empty_like(Wf)
+    N.call("pack_conv_w", 1, w2, Wf2, Wd2)
+    torch.cuda.synchronize()
+    assert torch.equal(pk[0], Wf) and torch.equal(pk[1], Wd) and torch.equal(pk[2], Wf2) and torch.equal(pk[3], Wd2)
     wq = Wf.float().view(64, 9, 64).permute(0, 2, 1).reshape(64, 64, 3, 3)                        # bf16-rounded [co][ci][kh][kw]
     x_nchw = x.float().permute(0, 3, 2, 1).contiguous()                                           # [N][C][F][T]
     ref = Fnn.conv2d(x_nchw.double(), wq.double(), b.double(), padding=1)                         # [N][co][F][T]
