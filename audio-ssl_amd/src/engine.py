@@ -451,10 +451,11 @@ def _conv_block_bwd(dtype, Y, dP, dxl, st, Nimg, Ti, Fi, Pin, Wd, G_w, G_gamma, 
     return dPin
 
 
-def encoder_backward(c, G, dA2=None, dH2=None, dx1=None, dx2=None, dx3=None):
+def encoder_backward(c, G, dA2=None, dH2=None, dx1=None, dx2=None, dx3=None, dx_late=None):
     """Accumulate parameter gradients of one encoder_forward call into G (dict keyed like P, fp32).
     dA2: grad w.r.t. the pre-ReLU output of fc.3 (already ReLU-gated), or dH2: grad w.r.t. H2.
-    dx1..dx3: grads w.r.t. the temporal layer means (fp32) or None."""
+    dx1..dx3: grads w.r.t. the temporal layer means (fp32) or None; dx_late: callable -> (dx1, dx2, dx3), called after the
+    fully connected layers' backward has been issued (it may order the stream after the producer of those gradients)."""
     dtype, Nimg, M, d, kin = c.dtype, c.N, c.M, c.d, c.kin
     T1, F1, T2, F2, T3, F3 = c.dims
     td = N.torch_dtype(dtype)
@@ -478,6 +479,8 @@ def encoder_backward(c, G, dA2=None, dH2=None, dx1=None, dx2=None, dx3=None):
         colsum_add(dtype, dA1, M, d, G["fc.0.bias"])
     WGRAD.run(dev, w1)
     dP3 = linear_bwd_x(dtype, dA1, c.fw1, M, d, kin, out_f32=1)
+    if dx_late is not None:
+        dx1, dx2, dx3 = dx_late()
     col = _col_buffer(dtype, Nimg, T1, F1, c.H2)
     keep = []
     dP2 = _conv_block_bwd(dtype, c.Y3, dP3, dx3, c.st3, Nimg, T2, F2, c.P2, c.W3d, G["features_3.0.weight"],
