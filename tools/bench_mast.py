@@ -11,10 +11,12 @@ CFG = {"run": {"batch_size": 8, "precision": "bf16"},
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 128
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 10
 graph = (sys.argv[3] != "eager") if len(sys.argv) > 3 else True
+T = int(sys.argv[4]) if len(sys.argv) > 4 else 101          # frames: 101 = 1 s (108 patches), 1001 = 10 s (1,188 patches: block-walking attention)
+CFG["pretrain"]["input"]["length_wave"] = (T - 1) / 100.0
 torch.manual_seed(0)
 ex = Upstream_Expert(copy.deepcopy(CFG), num_negatives=65536).cuda().train()
 opt = ex.configure_optimizers()
-a, b = torch.randn(B, 1, 128, 101, device="cuda"), torch.randn(B, 1, 128, 101, device="cuda")
+a, b = torch.randn(B, 1, 128, T, device="cuda"), torch.randn(B, 1, 128, T, device="cuda")
 if graph:
     step = ex.graphed_step(opt, eager_steps=1)
 else:
@@ -27,4 +29,4 @@ for _ in range(steps): loss = step(a, b)
 torch.cuda.synchronize()
 dt = (time.perf_counter() - t) / steps
 flops = 2 * B * 3 * 2 * (108 * (256 * 768 + 12 * (4 * 768 * 768 + 2 * 768 * 3072 + 2 * 108 * 768)))   # 2 q passes fwd+bwd(x3) ... approx
-print(f"B={B} graph={graph}: {dt * 1e3:.2f} ms/step, {B / dt:.0f} clips/s, loss {float(loss):.4f}, mem {torch.cuda.max_memory_allocated() / 2**30:.1f} GiB")
+print(f"B={B} T={T} graph={graph}: {dt * 1e3:.2f} ms/step, {B / dt:.0f} clips/s, loss {float(loss):.4f}, mem {torch.cuda.max_memory_allocated() / 2**30:.1f} GiB")
