@@ -136,11 +136,13 @@ def linear_fwd(dtype, X, W, M, Nout, K, bias=None, relu=0, keep=None, keep_scale
     return out
 
 
-def linear_bwd_w(dtype, dY, X, dW, M, Nout, K):
-    """dW[Nout,K] += dY[M,Nout]^T @ X[M,K]   (split-K, fp32 atomics)"""
+def linear_bwd_w(dtype, dY, X, dW, M, Nout, K, dw_zero=False):
+    """dW[Nout,K] += dY[M,Nout]^T @ X[M,K]   (split-K, fp32 atomics).  dw_zero: the caller guarantees dW is zero and has this one
+    writer in the step - an unsplit bf16 launch then stores its result instead of reading the zeros to add to them."""
     # every dW of the step is written by one stream at a time, so without split-K the accumulation needs no atomics
     ks = _ksplit(Nout, K, M)
-    gemm(dtype, 1, 1, Nout, K, M, dY, Nout, X, K, dW, K, out_f32=1, atomic=1 if (ks > 1 or dtype != N.BF16) else 2, ksplit=ks)
+    atomic = 1 if (ks > 1 or dtype != N.BF16) else (0 if dw_zero else 2)
+    gemm(dtype, 1, 1, Nout, K, M, dY, Nout, X, K, dW, K, out_f32=1, atomic=atomic, ksplit=ks)
 
 
 def linear_bwd_x(dtype, dY, W, M, Nout, K, alpha=1.0, gate=None, out=None, out_f32=0):
@@ -451,7 +453,7 @@ def _conv_block_bwd(dtype, Y, dP, dxl, st, Nimg, Ti, Fi, Pin, Wd, G_w, G_gamma, 
     return dPin
 
 
-def encoder_backward(c, G, dA2=None, dH2=None, dx1=None, dx2=None, dx3=None, dx_late=None):
+def encoder_backward(c, G, dA2=None, dH2=None, dx1=None, dx2=None, dx3=None, dx_late=None, grads_zero=False):
     """Accumulate parameter gradients of one encoder_forward call into G (dict keyed like P, fp32).
     dA2: grad w.r.t. the pre-ReLU output of fc.3 (already ReLU-gated), or dH2: grad w.r.t. H2.
     dx1..dx3: grads w.r.t. the temporal layer means (fp32) or None; dx_late: callable -> (dx1, dx2, dx3), called after the
@@ -468,14 +470,14 @@ def encoder_backward(c, G, dA2=None, dH2=None, dx1=None, dx2=None, dx3=None, dx_
     # only hangs off it, so those launches go to a second stream and overlap the chain.
     # fc.3
     def w2():
-        linear_bwd_w(dtype, dA2, c.H1, G["fc.3.weight"], M, d, d)
+        linear_bwd_w(dtype, dA2, c.H1, G["fc.3.weight"], M, d, d, dw_zero=grads_zero)
         colsum_add(dtype, dA2, M, d, G["fc.3.bias"])
     WGRAD.run(dev, w2)
     scale = 1.0 / (1.0 - c.p_drop) if c.keep is not None else 1.0
     dA1 = linear_bwd_x(dtype, dA2, c.fw2, M, d, d, alpha=scale, gate=c.H1)
     # fc.0
     def w1():
-        linear_bwd_w(dtype, dA1, c.P3, G["fc.0.weight"], M, d, kin)
+        linear_bwd_w(dtype, dA1, c.P3, G["fc.0.weight"], M, d, kin, dw_zero=grads_zero)
         colsum_add(dtype, dA1, M, d, G["fc.0.bias"])
     WGRAD.run(dev, w1)
     dP3 = linear_bwd_x(dtype, dA1, c.fw1, M, d, kin, out_f32=1)
@@ -675,7 +677,7 @@ def gemm_multi(ta, tb, M, Nn, Ks, As, ldas, Bs, ldbs, Cs, ldc, alpha=1.0, out_f3
 
 
 def barlow_heads_forward_backward(PPs, Gs, Ys, dtype, lambds, scale_losses, loss_outs, update_running=True, backward=True,
-                                  Wcs=None):
+                                  Wcs=None, grads_zero=False):
     """`barlow_forward_backward` for several heads in lock-step: every step of the chain - GEMM, train-mode BatchNorm, loss -
     is ONE multi-problem launch over the heads (they differ only in the width of the first layer's input).
     Ys[h]: [2B, in_h] stacked views; returns dY_h [B, in_h] (gradient of view 1's input) per head, fp32.
@@ -750,8 +752,10 @@ def barlow_heads_forward_backward(PPs, Gs, Ys, dtype, lambds, scale_losses, loss
 
     def wgrad(dys, xs, name, ks):                        # dW_h [D, k_h] += dy_h^T x_h; one writer per dW, so no atomics unless split
         split = _ksplit(D, max(ks), M, max(256 // nh, 1))
+        # grads_zero: the caller guarantees the gradient buffers are zero and written once in this step, so the single writer
+        # stores its result instead of reading 50 MB of zeros per launch to add to them
         gemm_multi(1, 1, D, ks, [M] * nh, dys, [D] * nh, xs, ks, [Gs[h][name] for h in H], ks, out_f32=1,
-                   atomic=1 if split > 1 else 2, ksplit=split)
+                   atomic=1 if split > 1 else (0 if grads_zero else 2), ksplit=split)
 
     def dgrad(dys, ws, Ks, rows):
         out = [torch.empty(rows, k, dtype=torch.float32, device=dev) for k in Ks]

@@ -25,6 +25,7 @@ from src.utils import concat_all_gather
 
 _PREP_ASIDE = os.environ.get("AUDIOSSL_PREP_ASIDE", "1") != "0"
 _HEADS_ASIDE = os.environ.get("AUDIOSSL_HEADS_ASIDE", "1") != "0"        # 0: the grouped Barlow heads are issued on the main stream
+_GRADS_ZERO = os.environ.get("AUDIOSSL_GRADS_ZERO", "1") != "0"          # 0: weight-gradient GEMMs of the heads add to the (zero) buffers
 _LATE_JOIN = os.environ.get("AUDIOSSL_LATE_JOIN", "1") != "0"            # 0: join the heads before the whole encoder backward
 _SGD_ASIDE = os.environ.get("AUDIOSSL_SGD_ASIDE", "1") != "0"            # 0: the early head-segment SGD is issued on the main stream
 
@@ -181,7 +182,8 @@ class Upstream_Expert(MocoQueueMixin, FusedExpertMixin, UpstreamModule):
                 return E.barlow_heads_forward_backward(
                     [p.param_dict() for p in heads], [G(f"p{i + 1}.") for i in range(3)], Ys, dt, [p.lambd for p in heads],
                     [p.scale_loss for p in heads], [loss[i + 1:i + 2] for i in range(3)], update_running=self.training,
-                    backward=need_grad, Wcs=[tuple(Wp[f"projector.{j}.weight"] for j in (0, 3, 6)) for Wp in Wps])
+                    backward=need_grad, Wcs=[tuple(Wp[f"projector.{j}.weight"] for j in (0, 3, 6)) for Wp in Wps],
+                    grads_zero=need_grad and _GRADS_ZERO)          # prep() cleared the flat gradient; each dW has one writer
             hs = streams[0] if _HEADS_ASIDE else main
             if not E.ONE_STREAM and _HEADS_ASIDE:
                 streams[0].wait_stream(main)
@@ -238,9 +240,10 @@ class Upstream_Expert(MocoQueueMixin, FusedExpertMixin, UpstreamModule):
         if need_grad:
             def backward_phase():
                 if late:
-                    E.encoder_backward(cq, G("encoder_q.encoder."), dA2=dA2, dx_late=join_heads)
+                    E.encoder_backward(cq, G("encoder_q.encoder."), dA2=dA2, dx_late=join_heads, grads_zero=_GRADS_ZERO)
                 else:
-                    E.encoder_backward(cq, G("encoder_q.encoder."), dA2=dA2, dx1=dys[0], dx2=dys[1], dx3=dys[2])
+                    E.encoder_backward(cq, G("encoder_q.encoder."), dA2=dA2, dx1=dys[0], dx2=dys[1], dx3=dys[2],
+                                       grads_zero=_GRADS_ZERO)
                 return loss.sum()
             total = R.phase("encoder_bwd", backward_phase)
             if early_box[0] is not None and not E.ONE_STREAM and _SGD_ASIDE:
