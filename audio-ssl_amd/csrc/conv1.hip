@@ -69,12 +69,12 @@ __global__ __launch_bounds__(256) void conv1_moments_kernel(const float* __restr
         for (int kh = 0; kh < 3; ++kh)
 #pragma unroll
             for (int kw = 0; kw < 3; ++kw) x[kh * 3 + kw] = c[kh * ld + kw];
-        int q = 9;
 #pragma unroll
         for (int a = 0; a < 9; ++a) {
             acc[a] += x[a];
 #pragma unroll
-            for (int b = a; b < 9; ++b) acc[q++] += x[a] * x[b];
+            for (int b = 0; b < 9; ++b)                           // (a <= b) pairs; the index is a constant after unrolling - a running
+                if (b >= a) acc[9 + tri(a, b)] += x[a] * x[b];    // counter (acc[q++]) left the array in scratch memory: 46 MB of traffic
         }
         t += dt; f += df;
         if (t >= tc) { t -= tc; ++f; }
@@ -425,11 +425,12 @@ __global__ __launch_bounds__(256) void conv1_fwd_mfma_kernel(const float* __rest
 // G[c][tap] = sum_pixels dz[pixel][c] * x_tap[pixel] as a second MFMA: A = x taps (row = tap, k = pixel), B = the routed
 // gradient straight out of the accumulator registers (lane = channel, k = pixel in the register order - the A operand reads
 // its pixels from the LDS patch in that same order).
-template <bool SLAB>
+// TP: type of the pooled gradient dP (fp32, or bf16 - half the bytes of the largest tensor this kernel reads); dxl is fp32
+template <bool SLAB, typename TP>
 __global__ __launch_bounds__(256, 3) void conv1_bwd_mfma_kernel(const float* __restrict__ img, const float* __restrict__ w,
                                                              const float* __restrict__ bias, const float* __restrict__ scale,
                                                              const float* __restrict__ shift, const float* __restrict__ mean,
-                                                             const float* __restrict__ rstd, const float* __restrict__ dP,
+                                                             const float* __restrict__ rstd, const TP* __restrict__ dP,
                                                              const float* __restrict__ dxl, float inv_To, float* __restrict__ accg,
                                                              int N, int F, int T) {
     // SLAB (n_mels = 64): the item's 8 KB slab of pooled gradients [32 rows][64 ch] fp32 is DMA'd straight into LDS
@@ -446,11 +447,12 @@ __global__ __launch_bounds__(256, 3) void conv1_bwd_mfma_kernel(const float* __r
     auto slab_dma = [&](int it, int slot) {
         typedef __attribute__((address_space(1))) const void* gptr_t;
         typedef __attribute__((address_space(3))) void* lptr_t;
-        const float* src = dP + (long)it * Fo * 64;                       // (n, tp) items are contiguous [Fo][64] slabs
+        const char* src = reinterpret_cast<const char*>(dP + (long)it * Fo * 64);   // (n, tp) items are contiguous [Fo][64] slabs
+        char* dst = reinterpret_cast<char*>(dyn + slot * 2048);
 #pragma unroll
-        for (int k = 0; k < 2; ++k)
-            __builtin_amdgcn_global_load_lds((gptr_t)(src + (k * 4 + wv) * 256 + lane * 4),
-                                             (lptr_t)(dyn + slot * 2048 + (k * 4 + wv) * 256), 16, 0, 0);
+        for (int k = 0; k < (int)sizeof(TP) / 2; ++k)                      // 4 KB (bf16) or 8 KB (fp32) per item: 1 KB per wave and trip
+            __builtin_amdgcn_global_load_lds((gptr_t)(src + ((k * 4 + wv) * 64 + lane) * 16),
+                                             (lptr_t)(dst + (k * 4 + wv) * 1024), 16, 0, 0);
     };
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
@@ -464,7 +466,6 @@ __global__ __launch_bounds__(256, 3) void conv1_bwd_mfma_kernel(const float* __r
     const int tap = l31, kh = tap / 3, kw = tap - 3 * kh;               // A2 row of this lane (taps >= 9: zero rows)
     // pooled gradients of this lane's 2 channels x 4 pooled pixels of one (item, tile)
     // dxl term (gradient of the layer-mean output, [N][Fo*64], shared by all time columns) of one (item, tile)
-    const float* dxp = dxl ? dxl : dP;                                  // no branch in the loop: a null dxl reads (and ignores) dP
     const float dxs = dxl ? inv_To : 0.f;
     auto fetch_dxl = [&](int it, int tile, float (&gx)[2][4]) {
         const int n = it / To;
@@ -472,7 +473,7 @@ __global__ __launch_bounds__(256, 3) void conv1_bwd_mfma_kernel(const float* __r
         for (int q = 0; q < 4; ++q) {
             const int fpo = min(tile * 8 + 2 * q + half, Fo - 1);
 #pragma unroll
-            for (int j = 0; j < 2; ++j) gx[j][q] = dxp[(long)n * Fo * 64 + fpo * 64 + 32 * j + l31];    // raw: scaled at use
+            for (int j = 0; j < 2; ++j) gx[j][q] = dxl ? dxl[(long)n * Fo * 64 + fpo * 64 + 32 * j + l31] : 0.f;   // raw: scaled at use
         }
     };
     // pooled gradients of this lane's 2 channels x 4 pooled pixels of one (item, tile)
@@ -485,8 +486,8 @@ __global__ __launch_bounds__(256, 3) void conv1_bwd_mfma_kernel(const float* __r
             for (int j = 0; j < 2; ++j) {
                 float g = 0.f;
                 if (fpo < Fo)
-                    g = (SLAB ? dyn[slot * 2048 + fpo * 64 + 32 * j + l31]
-                              : dP[(((long)n * To + tp) * Fo + fpo) * 64 + 32 * j + l31]) + gx[j][q] * dxs;
+                    g = (float)(SLAB ? reinterpret_cast<const TP*>(dyn + slot * 2048)[fpo * 64 + 32 * j + l31]
+                                     : dP[(((long)n * To + tp) * Fo + fpo) * 64 + 32 * j + l31]) + gx[j][q] * dxs;
                 gp[j][q] = g;
             }
         }
@@ -707,19 +708,25 @@ static int conv1_bwd_main(int dtype, int conv_dtype, const float* img, int N, in
                                   void* stream) {
     ASSL_REQUIRE(img && w && bias && gamma && scale && shift && mean && rstd && mom && dP && acc);
     ASSL_REQUIRE(N > 0 && F >= 2 && F <= 64 && T >= 2 && (F % 2) == 0 && (dtype == 0 || dtype == 1));
-    ASSL_REQUIRE(conv_dtype == 0 || (conv_dtype == 1 && dtype == 0));     // the MFMA recompute takes fp32 gradients
+    // conv_dtype 1 (MFMA recompute): dtype is the type of dP alone (fp32 or bf16), dxl is fp32 either way
     hipStream_t s = static_cast<hipStream_t>(stream);
     ASSL_ZERO(acc, sizeof(float) * 32 * 64 * 11, s);
     static const int bwd_grid = getenv("AUDIOSSL_CONV1_BWD_GRID") ? atoi(getenv("AUDIOSSL_CONV1_BWD_GRID")) : 2048;
     const int grid = min(N * (T / 2), bwd_grid);
     const size_t lds = sizeof(float) * (F + 2) * 4;
     const float inv_To = 1.f / (float)(T / 2);
-    if (conv_dtype == 1 && F == 64)
-        hipLaunchKernelGGL(conv1_bwd_mfma_kernel<true>, dim3(grid), dim3(256), lds + 2 * 2048 * sizeof(float), s, img, w, bias, scale,
+    if (conv_dtype == 1 && F == 64 && dtype == 0)
+        hipLaunchKernelGGL((conv1_bwd_mfma_kernel<true, float>), dim3(grid), dim3(256), lds + 2 * 2048 * sizeof(float), s, img, w, bias, scale,
                            shift, mean, rstd, static_cast<const float*>(dP), static_cast<const float*>(dxl), inv_To, acc, N, F, T);
-    else if (conv_dtype == 1)
-        hipLaunchKernelGGL(conv1_bwd_mfma_kernel<false>, dim3(grid), dim3(256), lds, s, img, w, bias, scale, shift, mean, rstd,
+    else if (conv_dtype == 1 && F == 64)
+        hipLaunchKernelGGL((conv1_bwd_mfma_kernel<true, bf16>), dim3(grid), dim3(256), lds + 2 * 2048 * sizeof(float), s, img, w, bias, scale,
+                           shift, mean, rstd, static_cast<const bf16*>(dP), static_cast<const float*>(dxl), inv_To, acc, N, F, T);
+    else if (conv_dtype == 1 && dtype == 0)
+        hipLaunchKernelGGL((conv1_bwd_mfma_kernel<false, float>), dim3(grid), dim3(256), lds, s, img, w, bias, scale, shift, mean, rstd,
                            static_cast<const float*>(dP), static_cast<const float*>(dxl), inv_To, acc, N, F, T);
+    else if (conv_dtype == 1)
+        hipLaunchKernelGGL((conv1_bwd_mfma_kernel<false, bf16>), dim3(grid), dim3(256), lds, s, img, w, bias, scale, shift, mean, rstd,
+                           static_cast<const bf16*>(dP), static_cast<const float*>(dxl), inv_To, acc, N, F, T);
     else if (dtype == 0)
         hipLaunchKernelGGL(conv1_bwd_kernel<float>, dim3(grid), dim3(256), lds, s, img, w, bias, scale, shift, mean, rstd,
                            static_cast<const float*>(dP), static_cast<const float*>(dxl), inv_To, acc, N, F, T);

@@ -278,6 +278,7 @@ def _wgrad_workspace(device):
 
 
 STAT_REPLICAS = 8
+_DP1_BF16 = os.environ.get("AUDIOSSL_DP1_BF16", "1") != "0"      # 0: the gradient into the stem backward stays fp32
 
 
 def _conv_block_fwd(dtype, Pin, Nimg, Ti, Fi, W, bias, bn, train, update_running, col, packed=None):
@@ -410,7 +411,7 @@ def encoder_forward(P, x, dtype, keep=None, p_drop=0.3, train=True, update_runni
     return x1, x2, x3, c.H2.view(Nimg, T3, d), c
 
 
-def _conv_block_bwd(dtype, Y, dP, dxl, st, Nimg, Ti, Fi, Pin, Wd, G_w, G_gamma, G_beta, need_dx, col, keep):
+def _conv_block_bwd(dtype, Y, dP, dxl, st, Nimg, Ti, Fi, Pin, Wd, G_w, G_gamma, G_beta, need_dx, col, keep, dx_bf16=False):
     """BN/ReLU/pool backward + conv wgrad (+ dgrad).  Returns dPin or None.  `keep`: list that holds the tensors the
     side-stream weight gradient still reads until the caller joins the streams."""
     td = N.torch_dtype(dtype)
@@ -444,9 +445,12 @@ def _conv_block_bwd(dtype, Y, dP, dxl, st, Nimg, Ti, Fi, Pin, Wd, G_w, G_gamma, 
     if not need_dx:
         return None
     # dgrad: dPin[pix][ci] = sum_{tap,co} dY[pix + off(tap)][co] * W[co][ci][8 - tap]
-    dPin = _empty((Nimg, Ti, Fi, 64), torch.float32, like=Y)            # feeds the previous block's BN backward: fp32
+    # feeds the previous block's BN backward: fp32 - except into the MFMA stem backward, which takes this (the largest gradient
+    # tensor of the step: 210 MB in fp32 at B = 512) in bf16: its sums run over 3.3 M pixels, the rounding averages out
+    dx_bf16 = dx_bf16 and fused
+    dPin = _empty((Nimg, Ti, Fi, 64), torch.bfloat16 if dx_bf16 else torch.float32, like=Y)
     if fused:
-        N.call("conv3x3_fwd", dY, Wd, None, dPin, 1, None, None, 1, Nimg, Ti, Fi)
+        N.call("conv3x3_fwd", dY, Wd, None, dPin, 0 if dx_bf16 else 1, None, None, 1, Nimg, Ti, Fi)
     else:
         N.call("im2col3x3", dtype, dY, col, Nimg, Ti, Fi)
         gemm(dtype, 0, 0, M, 64, 576, col, 576, Wd, 576, dPin, 64)
@@ -488,17 +492,18 @@ def encoder_backward(c, G, dA2=None, dH2=None, dx1=None, dx2=None, dx3=None, dx_
     dP2 = _conv_block_bwd(dtype, c.Y3, dP3, dx3, c.st3, Nimg, T2, F2, c.P2, c.W3d, G["features_3.0.weight"],
                           G["features_3.1.weight"], G["features_3.1.bias"], True, col, keep)
     dP1 = _conv_block_bwd(dtype, c.Y2, dP2, dx2, c.st2, Nimg, T1, F1, c.P1, c.W2d, G["features_2.0.weight"],
-                          G["features_2.1.weight"], G["features_2.1.bias"], True, col, keep)
+                          G["features_2.1.weight"], G["features_2.1.bias"], True, col, keep, dx_bf16=bool(c.stem_mfma) and _DP1_BF16)
+    gd1 = N.BF16 if dP1.dtype == torch.bfloat16 else GD
     acc = ARENA.scratch((32 * 64 * 11,), torch.float32, c.H2)
     P = c.P
     w1, b1, g1 = P["features_1.0.weight"].reshape(64, 9), P["features_1.0.bias"], P["features_1.1.weight"]
     gw, gb = G["features_1.0.weight"].view(64, 9), G["features_1.0.bias"]
     if SYNC_BN is None:
-        N.call("conv1_bwd", GD, int(c.stem_mfma), c.img, Nimg, c.F, c.T, w1, b1, g1, c.sc1, c.sh1, c.mean1, c.rstd1, c.mom1, dP1, dx1,
+        N.call("conv1_bwd", gd1, int(c.stem_mfma), c.img, Nimg, c.F, c.T, w1, b1, g1, c.sc1, c.sh1, c.mean1, c.rstd1, c.mom1, dP1, dx1,
                acc, gw, gb, G["features_1.1.weight"], G["features_1.1.bias"])
     else:
         lstat = _empty((128,), torch.float32, like=c.H2)
-        N.call("conv1_bwd_sums", GD, int(c.stem_mfma), c.img, Nimg, c.F, c.T, w1, b1, g1, c.sc1, c.sh1, c.mean1, c.rstd1, c.mom1, dP1,
+        N.call("conv1_bwd_sums", gd1, int(c.stem_mfma), c.img, Nimg, c.F, c.T, w1, b1, g1, c.sc1, c.sh1, c.mean1, c.rstd1, c.mom1, dP1,
                dx1, acc, lstat)
         gstat = SYNC_BN.all_reduce(lstat.clone())
         N.call("conv1_bwd_finalize", acc, c.mom1, w1, b1, g1, c.mean1, c.rstd1, float(Nimg * c.F * c.T * SYNC_BN.world), gstat, gw, gb,

@@ -111,6 +111,8 @@ int audiossl_conv1_stats(const float* img, int N, int F, int T, const float* w, 
 #define AUDIOSSL_CONV1_XL_PARTS 4
 int audiossl_conv1_fwd(int dtype, const float* img, int N, int F, int T, const float* w, const float* bias,
                        const float* scale, const float* shift, void* out, float* xl, void* stream);
+/* conv1_bwd: dtype = type of the pooled gradient dP (0 fp32, 1 bf16); with conv_dtype 1 (MFMA recompute) dxl stays fp32 whatever
+ * dtype says, with conv_dtype 0 dP and dxl share it */
 int audiossl_conv1_bwd(int dtype, int conv_dtype, const float* img, int N, int F, int T, const float* w, const float* bias,
                        const float* gamma, const float* scale, const float* shift, const float* mean, const float* rstd,
                        const double* mom, const void* dP, const void* dxl, float* acc, float* dW, float* dbias,

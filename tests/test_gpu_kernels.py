@@ -393,6 +393,13 @@ def test_conv1_block_fwd_bwd(N, dtype, T):
     assert rel_l2(dg.cpu(), bn.weight.grad) < tol
     assert rel_l2(dbt.cpu(), bn.bias.grad) < tol
     assert float(conv.bias.grad.abs().max()) < 1e-3 and float(db.abs().max()) == 0.0
+    if dtype == 1:
+        # the MFMA flavour also takes the pooled gradient in bf16 (dxl stays fp32): same result up to the rounding of dP
+        dW2, db2, dg2, dbt2 = (torch.zeros(s, device="cuda") for s in ((64, 9), (64,), (64,), (64,)))
+        N.call("conv1_bwd", 1, 1, img, Nimg, F_, T, w, b, gamma, scale, shift, mean, rstd, mom, dP.bfloat16().contiguous(), dxl, acc,
+               dW2, db2, dg2, dbt2)
+        torch.cuda.synchronize()
+        assert rel_l2(dW2.cpu(), dW.cpu()) < 5e-3 and rel_l2(dg2.cpu(), dg.cpu()) < 5e-3 and rel_l2(dbt2.cpu(), dbt.cpu()) < 5e-3
 
 
 @pytest.mark.parametrize("shape", [(5, 40, 300), (2, 64, 129), (3, 8, 2), (7, 64, 101), (2, 120, 128)])
