@@ -50,6 +50,11 @@ struct GemmArgs {
     const float* lse;         // mode 2: [M]
     float gscale;
     int nslot;                // ceil(N / 64)
+    // Barlow-twins epilogue (audiossl_gemm_multi_barlow): c = alpha*acc is the cross-correlation; the launch stores
+    // dc = bl_dscale * (c - I) (bf16) and adds bl_coef * sum (c - I)^2 into one of 32 replicas of the loss - c itself never reaches memory
+    int bl_mode;
+    float* bl_loss;           // [32] fp32 replicas (workgroup i adds into replica i & 31; the caller sums them)
+    float bl_coef, bl_dscale;
 };
 
 template <typename T> struct Mma;
@@ -152,6 +157,7 @@ __device__ __forceinline__ void epilogue_vec(const GemmArgs& g, f32x16 (&acc)[MI
     }
     const float floor_ = g.relu ? 0.f : -3.4e38f;
     const bf16* gate = static_cast<const bf16*>(g.gate);
+    float bl_acc = 0.f;
 #pragma unroll 2
     for (int r0 = 0; r0 < 32 * MI; r0 += 8) {
         const int rl = r0 + rr;
@@ -160,6 +166,14 @@ __device__ __forceinline__ void epilogue_vec(const GemmArgs& g, f32x16 (&acc)[MI
         float v[8];
 #pragma unroll
         for (int u = 0; u < 8; ++u) v[u] = fmaxf(g.alpha * ct[rl * EPI_PITCH + c8 + u] + bias[u], floor_);
+        if (g.bl_mode) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const float d = v[u] - (row == col + u ? 1.f : 0.f);
+                bl_acc += d * d;
+                v[u] = g.bl_dscale * d;
+            }
+        }
         if (g.keep) {
             const unsigned long long k8 = *reinterpret_cast<const unsigned long long*>(g.keep + row * g.ldk + col);
 #pragma unroll
@@ -192,6 +206,10 @@ __device__ __forceinline__ void epilogue_vec(const GemmArgs& g, f32x16 (&acc)[MI
             for (int u = 0; u < 8; ++u) out.set(u, v[u]);
             out.store(static_cast<bf16*>(g.C) + o);
         }
+    }
+    if (g.bl_mode) {                                          // N % 64 == 0 here: no lane left the function early
+        bl_acc = wave_sum(bl_acc);
+        if (lane == 0) atomicAdd(g.bl_loss + (blockIdx.x & 31), g.bl_coef * bl_acc);
     }
 }
 
@@ -1099,30 +1117,8 @@ int epi_vectorisable(const GemmArgs& g, int dtype) {
 
 }  // namespace
 
-extern "C" int audiossl_gemm_multi(int count, int trans_a, int trans_b, int M, const int* Nv, const int* K, float alpha,
-                                   const void* const* A, const long* lda, const void* const* B, const long* ldb,
-                                   void* const* C, const long* ldcv, int out_f32, int atomic, int ksplit, void* stream) {
-    ASSL_REQUIRE(count >= 1 && count <= MAX_MULTI && Nv && K && A && B && C && lda && ldb && ldcv && M > 0 && ksplit >= 1);
-    int N = 0;                                               // widest problem: sizes the grid, narrower ones leave blocks idle
-    for (int i = 0; i < count; ++i) { ASSL_REQUIRE(Nv[i] > 0); N = max(N, Nv[i]); }
-    ASSL_REQUIRE(atomic >= 0 && atomic <= 2);
-    ASSL_REQUIRE(!atomic || out_f32);
-    ASSL_REQUIRE(ksplit == 1 || atomic == 1);
-    GemmMulti gm;
-    int kmin = 1 << 30;
-    for (int i = 0; i < count; ++i) {
-        ASSL_REQUIRE(A[i] && B[i] && C[i] && K[i] > 0);
-        ASSL_REQUIRE((trans_a ? M : K[i]) % 8 == 0 && (trans_b ? Nv[i] : K[i]) % 8 == 0);
-        if (!ASSL_ALIGNED16(A[i]) || !ASSL_ALIGNED16(B[i]) || lda[i] % 8 || ldb[i] % 8) return ASSL_EALIGN;
-        const long a_ext = (trans_a ? ((long)(K[i] - 1) * lda[i] + M) : ((long)(M - 1) * lda[i] + K[i])) * 2;
-        const long b_ext = (trans_b ? ((long)(K[i] - 1) * ldb[i] + Nv[i]) : ((long)(Nv[i] - 1) * ldb[i] + K[i])) * 2;
-        ASSL_REQUIRE(a_ext < 0xFFFFFF00L && b_ext < 0xFFFFFF00L);
-        gm.p[i] = GemmArgs{A[i], B[i], C[i], M, Nv[i], K[i], lda[i], ldb[i], ldcv[i], alpha, nullptr, 0, nullptr, 0, 1.f, nullptr, 0,
-                           out_f32, atomic, ksplit, nullptr, 0, (unsigned)a_ext, (unsigned)b_ext, 0};
-        gm.p[i].vec_epi = epi_vectorisable(gm.p[i], 1);
-        kmin = min(kmin, K[i]);
-    }
-    hipStream_t s = static_cast<hipStream_t>(stream);
+static int dispatch_multi(const GemmMulti& gm, int count, int M, int N, int kmin, int ksplit, int trans_a, int trans_b, hipStream_t s,
+                          const int* K, const int* Nv) {
     const long blocks = (long)ceil_div(M, BM) * ceil_div(N, BN) * ksplit * count;
     const bool small = blocks <= 128 && M > 64;
     const int max_tiles = ceil_div(M, small ? 64 : BM) * ceil_div(N, BN);
@@ -1146,6 +1142,60 @@ extern "C" int audiossl_gemm_multi(int count, int trans_a, int trans_b, int M, c
     if (blocks <= 256 && kmin >= 512) MULTI(128, 2, 4, max_tiles);
     MULTI(64, 2, 4, max_tiles);
 #undef MULTI
+}
+
+
+extern "C" int audiossl_gemm_multi(int count, int trans_a, int trans_b, int M, const int* Nv, const int* K, float alpha,
+                                   const void* const* A, const long* lda, const void* const* B, const long* ldb,
+                                   void* const* C, const long* ldcv, int out_f32, int atomic, int ksplit, void* stream) {
+    ASSL_REQUIRE(count >= 1 && count <= MAX_MULTI && Nv && K && A && B && C && lda && ldb && ldcv && M > 0 && ksplit >= 1);
+    int N = 0;                                               // widest problem: sizes the grid, narrower ones leave blocks idle
+    for (int i = 0; i < count; ++i) { ASSL_REQUIRE(Nv[i] > 0); N = max(N, Nv[i]); }
+    ASSL_REQUIRE(atomic >= 0 && atomic <= 2);
+    ASSL_REQUIRE(!atomic || out_f32);
+    ASSL_REQUIRE(ksplit == 1 || atomic == 1);
+    GemmMulti gm;
+    int kmin = 1 << 30;
+    for (int i = 0; i < count; ++i) {
+        ASSL_REQUIRE(A[i] && B[i] && C[i] && K[i] > 0);
+        ASSL_REQUIRE((trans_a ? M : K[i]) % 8 == 0 && (trans_b ? Nv[i] : K[i]) % 8 == 0);
+        if (!ASSL_ALIGNED16(A[i]) || !ASSL_ALIGNED16(B[i]) || lda[i] % 8 || ldb[i] % 8) return ASSL_EALIGN;
+        const long a_ext = (trans_a ? ((long)(K[i] - 1) * lda[i] + M) : ((long)(M - 1) * lda[i] + K[i])) * 2;
+        const long b_ext = (trans_b ? ((long)(K[i] - 1) * ldb[i] + Nv[i]) : ((long)(Nv[i] - 1) * ldb[i] + K[i])) * 2;
+        ASSL_REQUIRE(a_ext < 0xFFFFFF00L && b_ext < 0xFFFFFF00L);
+        gm.p[i] = GemmArgs{A[i], B[i], C[i], M, Nv[i], K[i], lda[i], ldb[i], ldcv[i], alpha, nullptr, 0, nullptr, 0, 1.f, nullptr, 0,
+                           out_f32, atomic, ksplit, nullptr, 0, (unsigned)a_ext, (unsigned)b_ext, 0};
+        gm.p[i].vec_epi = epi_vectorisable(gm.p[i], 1);
+        kmin = min(kmin, K[i]);
+    }
+    return dispatch_multi(gm, count, M, N, kmin, ksplit, trans_a, trans_b, static_cast<hipStream_t>(stream), K, Nv);
+}
+
+// The Barlow-twins cross-correlation of several heads, c_h = alpha * A_h^T B_h (A_h, B_h: [K_h][M] / [K_h][N] row-major, i.e. the
+// two normalised views), with the loss and its gradient folded into the epilogue (`delores_s/upstream_expert.py:118-131`):
+// dc_h = dscale_h * (c_h - I) in bf16, loss_rep_h[0..31] += coef_h * sum (c_h - I)^2 (32 replicas, the caller sums them; zeroed by
+// the caller).  c_h is never stored (50 MB written + read per launch at D = 2048, three heads).
+extern "C" int audiossl_gemm_multi_barlow(int count, int D, const int* K, float alpha, const void* const* A, const long* lda,
+                                          const void* const* B, const long* ldb, void* const* dc, const float* coef, const float* dscale,
+                                          float* const* loss_rep, void* stream) {
+    ASSL_REQUIRE(count >= 1 && count <= MAX_MULTI && K && A && B && dc && lda && ldb && coef && dscale && loss_rep && D > 0 && D % 64 == 0);
+    GemmMulti gm;
+    int kmin = 1 << 30;
+    int Nv[MAX_MULTI];
+    for (int i = 0; i < count; ++i) {
+        ASSL_REQUIRE(A[i] && B[i] && dc[i] && loss_rep[i] && K[i] > 0 && K[i] % 8 == 0);
+        if (!ASSL_ALIGNED16(A[i]) || !ASSL_ALIGNED16(B[i]) || !ASSL_ALIGNED16(dc[i]) || lda[i] % 8 || ldb[i] % 8) return ASSL_EALIGN;
+        const long a_ext = ((long)(K[i] - 1) * lda[i] + D) * 2, b_ext = ((long)(K[i] - 1) * ldb[i] + D) * 2;
+        ASSL_REQUIRE(a_ext < 0xFFFFFF00L && b_ext < 0xFFFFFF00L);
+        gm.p[i] = GemmArgs{A[i], B[i], dc[i], D, D, K[i], lda[i], ldb[i], D, alpha, nullptr, 0, nullptr, 0, 1.f, nullptr, 0,
+                           0, 0, 1, nullptr, 0, (unsigned)a_ext, (unsigned)b_ext, 0};
+        gm.p[i].vec_epi = epi_vectorisable(gm.p[i], 1);
+        ASSL_REQUIRE(gm.p[i].vec_epi);
+        gm.p[i].bl_mode = 1; gm.p[i].bl_loss = loss_rep[i]; gm.p[i].bl_coef = coef[i]; gm.p[i].bl_dscale = dscale[i];
+        kmin = min(kmin, K[i]);
+        Nv[i] = D;
+    }
+    return dispatch_multi(gm, count, D, D, kmin, 1, 1, 1, static_cast<hipStream_t>(stream), K, Nv);
 }
 
 // kernel choice for bf16 operands (measured rules, see the comments inside)

@@ -278,6 +278,7 @@ def _wgrad_workspace(device):
 
 
 STAT_REPLICAS = 8
+LOSS_REPLICAS = 32          # replicas of a Barlow loss term accumulated by the correlation GEMM's epilogue (gemm_multi_barlow)
 _DP1_BF16 = os.environ.get("AUDIOSSL_DP1_BF16", "1") != "0"      # 0: the gradient into the stem backward stays fp32
 
 
@@ -732,14 +733,26 @@ def barlow_heads_forward_backward(PPs, Gs, Ys, dtype, lambds, scale_losses, loss
     a2, st2, h2 = layer(h1, [W[h][1] for h in H], [D] * nh, "projector.4", True, 1)
     z, st0, zn = layer(h2, [W[h][2] for h in H], [D] * nh, "bn", False, 0)
     # correlation c_h = zn1^T zn2 / B, loss, dc
-    cm = new(D, D, torch.float32)
-    gemm_multi(1, 1, D, D, [B] * nh, [zn[h][:B] for h in H], [D] * nh, [zn[h][B:] for h in H], [D] * nh, cm, D,
-               alpha=1.0 / B, out_f32=1)
     dc = new(D, D, td)
     coefs = [(lambds[h] if lambds[h] else 1.0) * scale_losses[h] for h in H]
-    arrs = (_harr(vp, cm), _harr(fl, coefs), _harr(fl, [2.0 * c / B for c in coefs]), _harr(vp, dc), _harr(vp, list(loss_outs)))
-    _multi_check(list(loss_outs))
-    N.call("barlow_loss_multi", nh, adr(arrs[0]), D, adr(arrs[1]), adr(arrs[2]), adr(arrs[3]), adr(arrs[4]))
+    dsc = [2.0 * c / B for c in coefs]
+    if all(l.numel() == LOSS_REPLICAS for l in loss_outs) and D % 64 == 0:
+        # loss and dc come out of the GEMM's epilogue; c (three D x D fp32 matrices: 50 MB written and read back) is never stored
+        _multi_check([zn[h] for h in H], dc, list(loss_outs))
+        arrs = (_harr(ctypes.c_int, [B] * nh), _harr(vp, [zn[h][:B] for h in H]), _harr(ctypes.c_long, [D] * nh),
+                _harr(vp, [zn[h][B:] for h in H]), _harr(ctypes.c_long, [D] * nh), _harr(vp, dc), _harr(fl, coefs), _harr(fl, dsc),
+                _harr(vp, list(loss_outs)))
+        if N.PROFILE is not None:
+            N.PROFILE_NOTE = float(nh * 2.0 * D * D * B)
+        N.call("gemm_multi_barlow", nh, D, adr(arrs[0]), 1.0 / B, adr(arrs[1]), adr(arrs[2]), adr(arrs[3]), adr(arrs[4]), adr(arrs[5]),
+               adr(arrs[6]), adr(arrs[7]), adr(arrs[8]))
+    else:
+        cm = new(D, D, torch.float32)
+        gemm_multi(1, 1, D, D, [B] * nh, [zn[h][:B] for h in H], [D] * nh, [zn[h][B:] for h in H], [D] * nh, cm, D,
+                   alpha=1.0 / B, out_f32=1)
+        arrs = (_harr(vp, cm), _harr(fl, coefs), _harr(fl, dsc), _harr(vp, dc), _harr(vp, list(loss_outs)))
+        _multi_check(list(loss_outs))
+        N.call("barlow_loss_multi", nh, adr(arrs[0]), D, adr(arrs[1]), adr(arrs[2]), adr(arrs[3]), adr(arrs[4]))
     if not backward:
         return [None] * nh
     dzn = new(M, D, torch.float32)

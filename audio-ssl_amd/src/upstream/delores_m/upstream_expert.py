@@ -141,7 +141,10 @@ class Upstream_Expert(MocoQueueMixin, FusedExpertMixin, UpstreamModule):
                 prep()
             Wq = flat.shadow_dict("encoder_q.")
             wq = Wq["fc.weight"]
-            loss = torch.zeros(4, dtype=torch.float32, device=dev)          # [ce, barlow1, barlow2, barlow3]
+            # [ce, barlow1, barlow2, barlow3]; grouped heads: the Barlow terms are accumulated by the correlation GEMM's epilogue
+            # into 32 replicas each, stored behind the four slots (the step's loss is the sum of everything either way)
+            fold = not (self.high_precision or dt == N.F32 or not self.grouped_heads)
+            loss = torch.zeros(4 + (3 * E.LOSS_REPLICAS if fold else 0), dtype=torch.float32, device=dev)
             keep = eq.encoder.next_keep_mask(B, img_q.shape[-1])
             _, _, _, Hq, cq = E.encoder_forward(eq.encoder.param_dict(), img_q, dt, keep=keep, p_drop=0.3, train=self.training,
                                                 Wc=strip(Wq, "encoder."), layer_out=tuple(y[:B] for y in Ys),
@@ -181,7 +184,8 @@ class Upstream_Expert(MocoQueueMixin, FusedExpertMixin, UpstreamModule):
                 Wps = [flat.shadow_dict(f"p{i + 1}.") for i in range(3)]
                 return E.barlow_heads_forward_backward(
                     [p.param_dict() for p in heads], [G(f"p{i + 1}.") for i in range(3)], Ys, dt, [p.lambd for p in heads],
-                    [p.scale_loss for p in heads], [loss[i + 1:i + 2] for i in range(3)], update_running=self.training,
+                    [p.scale_loss for p in heads],
+                    [loss[4 + i * E.LOSS_REPLICAS:4 + (i + 1) * E.LOSS_REPLICAS] for i in range(3)], update_running=self.training,
                     backward=need_grad, Wcs=[tuple(Wp[f"projector.{j}.weight"] for j in (0, 3, 6)) for Wp in Wps],
                     grads_zero=need_grad and _GRADS_ZERO)          # prep() cleared the flat gradient; each dW has one writer
             hs = streams[0] if _HEADS_ASIDE else main
@@ -252,7 +256,7 @@ class Upstream_Expert(MocoQueueMixin, FusedExpertMixin, UpstreamModule):
         else:
             total = loss.sum()
         if parts is not None:
-            parts["losses"] = loss
+            parts["losses"] = loss if loss.numel() == 4 else torch.cat([loss[:1], loss[4:].view(3, E.LOSS_REPLICAS).sum(1)])
         return total
 
     def _streams(self, dev):

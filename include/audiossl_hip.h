@@ -217,6 +217,13 @@ int audiossl_gemm(int dtype, int trans_a, int trans_b, int M, int N, int K, floa
 int audiossl_gemm_multi(int count, int trans_a, int trans_b, int M, const int* N, const int* K, float alpha,
                         const void* const* A, const long* lda, const void* const* B, const long* ldb, void* const* C,
                         const long* ldc, int out_f32, int atomic, int ksplit, void* stream);
+/* The Barlow-twins cross-correlation of up to four heads with the loss folded into the epilogue (`delores_s/upstream_expert.py:118-131`,
+ * `delores_m/upstream_expert.py:266-269`): c_h = alpha * A_h^T B_h, A_h / B_h = the two normalised views [K_h][D] (row-major, K_h =
+ * batch rows); stores dc_h = dscale_h * (c_h - I) in bf16 [D][D] and adds coef_h * sum (c_h - I)^2 into loss_rep_h[0..31] (32 fp32
+ * replicas the caller zeroes and sums: same-address atomics serialise).  c_h itself is never stored.  D % 64 == 0. */
+int audiossl_gemm_multi_barlow(int count, int D, const int* K, float alpha, const void* const* A, const long* lda,
+                               const void* const* B, const long* ldb, void* const* dc, const float* coef, const float* dscale,
+                               float* const* loss_rep, void* stream);
 
 /* ---- encoder tail: delores_s/upstream_encoder.py:26-28 ---------------------------------------------------- */
 int audiossl_maxmean_fwd(int dtype, int out_f32, const void* H, void* y, uint8_t* arg, int N, int Tt, int D, void* stream);

@@ -615,6 +615,33 @@ def test_multi_head_launches_equal_single_ones(N):
             assert torch.equal(u, v)
 
 
+def test_gemm_multi_barlow_epilogue(N):
+    """Cross-correlation GEMM of three heads with the Barlow loss and its gradient folded into the epilogue
+    (`delores_s/upstream_expert.py:118-131`): dc = dscale (c - I) in bf16, loss replicas summing to coef * sum (c - I)^2,
+    c = A^T B / rows never stored."""
+    import ctypes
+    from src import engine as E
+    g = torch.Generator().manual_seed(23)
+    D, nh = 256, 3
+    Ks = [512, 512, 512]
+    A = [(torch.randn(k, D, generator=g) * 0.7).cuda().bfloat16() for k in Ks]
+    Bm = [(0.6 * a.float().cpu() + 0.8 * torch.randn(a.shape, generator=g) * 0.7).cuda().bfloat16() for a in A]
+    dc = [torch.full((D, D), float("nan"), device="cuda", dtype=torch.bfloat16) for _ in range(nh)]
+    rep = torch.zeros(nh, 32, device="cuda")
+    coef, dsc = [0.5, 1.0, 2.0], [0.01, 0.02, 0.03]
+    vp, fl, adr = ctypes.c_void_p, ctypes.c_float, ctypes.addressof
+    arrs = (E._harr(ctypes.c_int, Ks), E._harr(vp, A), E._harr(ctypes.c_long, [D] * nh), E._harr(vp, Bm), E._harr(ctypes.c_long, [D] * nh),
+            E._harr(vp, dc), E._harr(fl, coef), E._harr(fl, dsc), E._harr(vp, [rep[h] for h in range(nh)]))
+    N.call("gemm_multi_barlow", nh, D, adr(arrs[0]), 1.0 / 512, adr(arrs[1]), adr(arrs[2]), adr(arrs[3]), adr(arrs[4]), adr(arrs[5]),
+           adr(arrs[6]), adr(arrs[7]), adr(arrs[8]))
+    torch.cuda.synchronize()
+    for h in range(nh):
+        c = (A[h].double().T @ Bm[h].double()) / 512
+        d = c - torch.eye(D, dtype=torch.float64, device="cuda")
+        assert abs(float(rep[h].sum()) - coef[h] * float((d * d).sum())) <= 1e-4 * coef[h] * float((d * d).sum())
+        assert rel_l2(dc[h].float().cpu(), (dsc[h] * d).float().cpu()) < 5e-3                     # bf16 output rounding
+
+
 def test_gemm_multi_per_problem_shapes(N):
     """audiossl_gemm_multi with per-problem N / K / leading dimensions (the first projector layer of the three Barlow heads:
     widths 2048 / 1024 / 512) in every transpose mode, plain and exclusive-accumulate outputs."""
