@@ -683,7 +683,7 @@ def gemm_multi(ta, tb, M, Nn, Ks, As, ldas, Bs, ldbs, Cs, ldc, alpha=1.0, out_f3
 
 
 def barlow_heads_forward_backward(PPs, Gs, Ys, dtype, lambds, scale_losses, loss_outs, update_running=True, backward=True,
-                                  Wcs=None, grads_zero=False):
+                                  Wcs=None, grads_zero=False, dy_ready=None):
     """`barlow_forward_backward` for several heads in lock-step: every step of the chain - GEMM, train-mode BatchNorm, loss -
     is ONE multi-problem launch over the heads (they differ only in the width of the first layer's input).
     Ys[h]: [2B, in_h] stacked views; returns dY_h [B, in_h] (gradient of view 1's input) per head, fp32.
@@ -779,15 +779,25 @@ def barlow_heads_forward_backward(PPs, Gs, Ys, dtype, lambds, scale_losses, loss
         out = [torch.empty(rows, k, dtype=torch.float32, device=dev) for k in Ks]
         gemm_multi(0, 1, rows, Ks, [D] * nh, [dy[:rows] for dy in dys], [D] * nh, ws, Ks, out, Ks, out_f32=1)
         return out
+    # dy_ready (callable): the weight gradients hang off the data-gradient chain (bn_bwd -> dgrad -> bn_bwd ...) and nobody but the
+    # optimiser needs them, so they are issued AFTER the chain and dy_ready() is called in between - the caller can let another
+    # stream continue from there (an event) while this one still works through the three weight-gradient launches
+    later = []
+    defer = (lambda fn: later.append(fn)) if dy_ready is not None else (lambda fn: fn())
     dz = bn_bwd(z, dzn, st0, 0, None)
-    wgrad(dz, h2, "projector.6.weight", [D] * nh)
+    defer(lambda: wgrad(dz, h2, "projector.6.weight", [D] * nh))
     dh2 = dgrad(dz, [W[h][2] for h in H], [D] * nh, M)
     da2 = bn_bwd(a2, dh2, st2, 1, ("projector.4.weight", "projector.4.bias"))
-    wgrad(da2, h1, "projector.3.weight", [D] * nh)
+    defer(lambda: wgrad(da2, h1, "projector.3.weight", [D] * nh))
     dh1 = dgrad(da2, [W[h][1] for h in H], [D] * nh, M)
     da1 = bn_bwd(a1, dh1, st1, 1, ("projector.1.weight", "projector.1.bias"))
-    wgrad(da1, ycs, "projector.0.weight", kins)
-    return dgrad(da1, [W[h][0] for h in H], kins, B)      # dY for view 1 only (rows [0, B)); widths differ per head
+    defer(lambda: wgrad(da1, ycs, "projector.0.weight", kins))
+    dy = dgrad(da1, [W[h][0] for h in H], kins, B)        # dY for view 1 only (rows [0, B)); widths differ per head
+    if dy_ready is not None:
+        dy_ready()
+        for fn in later:
+            fn()
+    return dy
 
 
 # =============================================================================================== MoCo head

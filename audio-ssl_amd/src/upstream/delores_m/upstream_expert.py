@@ -26,6 +26,7 @@ from src.utils import concat_all_gather
 _PREP_ASIDE = os.environ.get("AUDIOSSL_PREP_ASIDE", "1") != "0"
 _HEADS_ASIDE = os.environ.get("AUDIOSSL_HEADS_ASIDE", "1") != "0"        # 0: the grouped Barlow heads are issued on the main stream
 _GRADS_ZERO = os.environ.get("AUDIOSSL_GRADS_ZERO", "1") != "0"          # 0: weight-gradient GEMMs of the heads add to the (zero) buffers
+_DY_EVENT = os.environ.get("AUDIOSSL_DY_EVENT", "1") != "0"              # 0: the main stream waits for the whole heads stream
 _LATE_JOIN = os.environ.get("AUDIOSSL_LATE_JOIN", "1") != "0"            # 0: join the heads before the whole encoder backward
 _SGD_ASIDE = os.environ.get("AUDIOSSL_SGD_ASIDE", "1") != "0"            # 0: the early head-segment SGD is issued on the main stream
 
@@ -161,6 +162,7 @@ class Upstream_Expert(MocoQueueMixin, FusedExpertMixin, UpstreamModule):
         #      ran them back to back, 2.1 ms instead of 0.5 ms - tools/timeline.py)
         streams = self._streams(dev)
         dys = [None, None, None]
+        dy_event = None
 
         def head_phase(i, p):
             Wp = flat.shadow_dict(f"p{i + 1}.")
@@ -187,10 +189,15 @@ class Upstream_Expert(MocoQueueMixin, FusedExpertMixin, UpstreamModule):
                     [p.scale_loss for p in heads],
                     [loss[4 + i * E.LOSS_REPLICAS:4 + (i + 1) * E.LOSS_REPLICAS] for i in range(3)], update_running=self.training,
                     backward=need_grad, Wcs=[tuple(Wp[f"projector.{j}.weight"] for j in (0, 3, 6)) for Wp in Wps],
-                    grads_zero=need_grad and _GRADS_ZERO)          # prep() cleared the flat gradient; each dW has one writer
+                    grads_zero=need_grad and _GRADS_ZERO,          # prep() cleared the flat gradient; each dW has one writer
+                    dy_ready=(lambda: dy_event.record()) if dy_event is not None else None)
             hs = streams[0] if _HEADS_ASIDE else main
             if not E.ONE_STREAM and _HEADS_ASIDE:
                 streams[0].wait_stream(main)
+            # one rank: the encoder backward only waits for the heads' data gradients (an event recorded before their weight-
+            # gradient launches); the head-segment SGD is issued on the heads' own stream, i.e. after those launches
+            if need_grad and not ddp and not E.ONE_STREAM and _HEADS_ASIDE and _SGD_ASIDE and _DY_EVENT:
+                dy_event = torch.cuda.Event()
             with torch.cuda.stream(hs):
                 dys = list(R.phase("heads", heads_phase))
 
@@ -214,8 +221,12 @@ class Upstream_Expert(MocoQueueMixin, FusedExpertMixin, UpstreamModule):
         def join_heads():
             """Order the main stream after the loss heads, then start what only waited for them: the all-reduce of the head
             gradients (data-parallel) or, on one rank, the SGD step of the head segment on a side stream."""
-            for st in streams:
-                if not E.ONE_STREAM:
+            for i, st in enumerate(streams):
+                if E.ONE_STREAM:
+                    continue
+                if i == 0 and dy_event is not None:
+                    main.wait_event(dy_event)               # the data gradients are there; the weight gradients may still run
+                else:
                     main.wait_stream(st)
             for d in dys:
                 if d is not None:
@@ -227,7 +238,7 @@ class Upstream_Expert(MocoQueueMixin, FusedExpertMixin, UpstreamModule):
                 # single rank: the head parameters can be updated right now, on a side stream under the encoder backward
                 # (nothing reads the fp32 head weights or their gradients again in this step)
                 early = streams[0] if _SGD_ASIDE else main
-                if not E.ONE_STREAM and _SGD_ASIDE:
+                if not E.ONE_STREAM and _SGD_ASIDE and dy_event is None:
                     early.wait_stream(main)
                 with torch.cuda.stream(early):
                     if R.phase("sgd_heads", lambda: optimizer.step_tail(flat, self.head_offset())):
