@@ -484,9 +484,16 @@ __global__ __launch_bounds__(256, 1) void conv3x3_ws_kernel(ConvArgs a) {
     }
 }
 
+// accumulator n (0..8) of wave w (0..3 inside its pixel half) -> (channel-out tile, (tap, ci-half) column tile): n < 8 walks
+// the wave's four column tiles 4w..4w+3 with both channel-out tiles (each X fragment feeds two MFMAs), n = 8 is one of the four
+// left-over (column tile 16 / 17, channel-out tile) pairs.  7 fragments per 9 MFMAs instead of 10.
+__host__ __device__ __forceinline__ int wg_cot(int w, int n) { return n < 8 ? (n & 1) : (w & 1); }
+__host__ __device__ __forceinline__ int wg_nt(int w, int n) { return n < 8 ? 4 * w + (n >> 1) : 16 + (w >> 1); }
+
 struct WgradArgs {
     const bf16* dY; const bf16* X; float* dW; int Ti, rows_total, tiles;
     float* partial;           // [gridDim.x * KG][64 * 576] per-(workgroup, pixel-half) results, or null: fp32 atomics into dW
+    int dbg;                  // AUDIOSSL_CONV_DBG: 2 no loads of the next tile, 4 no k-loop (tools/conv_bench.py)
 };
 
 // KG = 2: 8 waves; waves 4-7 take the second half of each tile's pixels (the contraction dimension) with their own 9
@@ -503,8 +510,6 @@ __global__ __launch_bounds__(256 * KG, 1) void conv3x3_wgrad_kernel(WgradArgs a)
 
     const int lane = threadIdx.x & 63, wave = (threadIdx.x >> 6) & 3, grp = threadIdx.x >> 8;
     const int h = lane >> 5, half = (lane >> 4) & 1, q = (lane & 15) >> 2, p = lane & 3;
-    const int cot = wave & 1;                                     // channel-out tile of this wave
-    const int n0 = (wave >> 1) * 9;                               // first of its 9 (tap, ci-half) column tiles
     H::zero_border(hl);
 
     f32x16 acc[9];
@@ -537,33 +542,41 @@ __global__ __launch_bounds__(256 * KG, 1) void conv3x3_wgrad_kernel(WgradArgs a)
     for (; tile < a.tiles; tile += gridDim.x) {
         const int g0 = tile * TT;
         const int next = tile + gridDim.x;
-        if (next < a.tiles) { halo.load(a.X, next * TT, a.rows_total); load_y(next * TT); }
+        if (next < a.tiles && !(a.dbg & 2)) { halo.load(a.X, next * TT, a.rows_total); load_y(next * TT); }
 
 #pragma unroll 1
-        for (int ks = grp * (16 / KG); ks < (grp + 1) * (16 / KG); ++ks) {   // 16 pixels per k-step, all inside one t-row
+        for (int ks = grp * (16 / KG); ks < (grp + 1) * (16 / KG) && !(a.dbg & 4); ++ks) {   // 16 pixels per k-step, all inside one t-row
             const int t_local = FI == 32 ? (ks >> 1) : ks;
             const int f0 = FI == 32 ? (ks & 1) * 16 : 0;
             const int g = g0 + t_local;
             if (g >= a.rows_total) break;                         // wave-uniform: the remaining rows are padding
             const int ti = g % a.Ti;
             const bool okt[3] = {ti - 1 >= 0, true, ti + 1 < a.Ti};          // wave-uniform: tap row inside the image in t
-            // A = dY^T: rows = co, k = pixel.  lane gets co = cot*32 + (lane&31), pixels 8h + {0..7}
-            const bf16* ay = yl + (ks * 16 + 8 * h + q) * PIXW + cot * 32 + 16 * half + 4 * p;
-            const bf16x4 a0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds4_t)ay);
-            const bf16x4 a1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds4_t)(ay + 4 * PIXW));
-            const bf16x8 fa = bf16x8{a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
+            // A = dY^T: rows = co, k = pixel.  lane gets co = cot*32 + (lane&31), pixels 8h + {0..7}; both channel-out tiles
+            bf16x8 fa[2];
+#pragma unroll
+            for (int c2 = 0; c2 < 2; ++c2) {
+                const bf16* ay = yl + (ks * 16 + 8 * h + q) * PIXW + c2 * 32 + 16 * half + 4 * p;
+                const bf16x4 a0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds4_t)ay);
+                const bf16x4 a1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds4_t)(ay + 4 * PIXW));
+                fa[c2] = bf16x8{a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
+            }
+            bf16x8 fb;
 #pragma unroll
             for (int n = 0; n < 9; ++n) {
-                const int nt = n0 + n, tap = nt >> 1, cih = nt & 1;
-                const int dt = tap % 3, df = tap / 3;
-                // no branch around a tap that leaves the image (the halo row exists in LDS, it belongs to the neighbouring
-                // image): the fragment is zeroed instead, so the 18 transposing reads of a k-step can all be in flight
-                const bf16* bx = hl + ((t_local + dt) * COLS + f0 + df + 8 * h + q) * PIXW + cih * 32 + 16 * half + 4 * p;
-                const bf16x4 b0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds4_t)bx);
-                const bf16x4 b1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds4_t)(bx + 4 * PIXW));
-                const bf16 z = (bf16)0.f;
-                const bf16x8 fb = okt[dt] ? bf16x8{b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3]} : bf16x8{z, z, z, z, z, z, z, z};
-                acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb, acc[n], 0, 0, 0);
+                if (n == 8 || (n & 1) == 0) {                     // a new column tile: its X fragment (shared by the pair n, n + 1)
+                    const int nt = wg_nt(wave, n), tap = nt >> 1, cih = nt & 1;
+                    const int dt = tap % 3, df = tap / 3;
+                    // no branch around a tap that leaves the image (the halo row exists in LDS, it belongs to the neighbouring
+                    // image): the fragment is zeroed instead, so the transposing reads of a k-step can all be in flight
+                    const bf16* bx = hl + ((t_local + dt) * COLS + f0 + df + 8 * h + q) * PIXW + cih * 32 + 16 * half + 4 * p;
+                    const bf16x4 b0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds4_t)bx);
+                    const bf16x4 b1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds4_t)(bx + 4 * PIXW));
+                    const bf16 z = (bf16)0.f;
+                    fb = okt[dt] ? bf16x8{b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3]} : bf16x8{z, z, z, z, z, z, z, z};
+                }
+                const int c2 = wg_cot(wave, n);
+                acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(c2 ? fa[1] : fa[0], fb, acc[n], 0, 0, 0);
             }
         }
         __syncthreads();
@@ -575,8 +588,32 @@ __global__ __launch_bounds__(256 * KG, 1) void conv3x3_wgrad_kernel(WgradArgs a)
     // 36,864 addresses with device-scope atomics took longer than the MFMAs of the whole pass.
     if (a.partial) {
         // workspace layout = accumulator layout, element ((wave * 9 + n) * 4 + r / 4) * 64 + lane holds registers 4(r/4)..+3:
-        // 16-byte stores, 1 KB contiguous per wave-instruction; wgrad_reduce_kernel undoes the map
-        f32x4* part = reinterpret_cast<f32x4*>(a.partial + ((long)blockIdx.x * KG + grp) * (CH * KTOT));
+        // 16-byte stores, 1 KB contiguous per wave-instruction; wgrad_reduce_kernel undoes the map.  The two pixel halves of
+        // the workgroup (KG = 2) are added through LDS first (the tile buffers are free now): one 147 KB result per workgroup
+        // instead of two - half the partial traffic and half the work of the fold
+        if (KG == 2) {
+            f32x4* xch = reinterpret_cast<f32x4*>(smem);
+            __syncthreads();
+            if (grp == 1) {
+#pragma unroll
+                for (int n = 0; n < 9; ++n)
+#pragma unroll
+                    for (int r4 = 0; r4 < 4; ++r4)
+                        xch[((wave * 9 + n) * 4 + r4) * 64 + lane] = f32x4{acc[n][4 * r4], acc[n][4 * r4 + 1], acc[n][4 * r4 + 2], acc[n][4 * r4 + 3]};
+            }
+            __syncthreads();
+            if (grp == 1) return;
+            f32x4* part = reinterpret_cast<f32x4*>(a.partial + (long)blockIdx.x * (CH * KTOT));
+#pragma unroll
+            for (int n = 0; n < 9; ++n)
+#pragma unroll
+                for (int r4 = 0; r4 < 4; ++r4) {
+                    const f32x4 o = xch[((wave * 9 + n) * 4 + r4) * 64 + lane];
+                    part[((wave * 9 + n) * 4 + r4) * 64 + lane] = f32x4{acc[n][4 * r4] + o[0], acc[n][4 * r4 + 1] + o[1], acc[n][4 * r4 + 2] + o[2], acc[n][4 * r4 + 3] + o[3]};
+                }
+            return;
+        }
+        f32x4* part = reinterpret_cast<f32x4*>(a.partial + (long)blockIdx.x * (CH * KTOT));
 #pragma unroll
         for (int n = 0; n < 9; ++n)
 #pragma unroll
@@ -586,11 +623,11 @@ __global__ __launch_bounds__(256 * KG, 1) void conv3x3_wgrad_kernel(WgradArgs a)
     }
 #pragma unroll
     for (int n = 0; n < 9; ++n) {
-        const int nt = n0 + n, tap = nt >> 1, cih = nt & 1;
+        const int nt = wg_nt(wave, n), tap = nt >> 1, cih = nt & 1;
         const int col = tap * 64 + cih * 32 + (lane & 31);
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const int co = cot * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+            const int co = wg_cot(wave, n) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
             atomicAdd(&a.dW[co * KTOT + col], acc[n][r]);
         }
     }
@@ -613,9 +650,9 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
     // i = (((wave * 9 + n) * 4 + r4) * 64 + lane) * 4 + e  ->  dW[co][tap * 64 + ci]
     const int e = i & 3, lane = (i >> 2) & 63, r4 = (i >> 8) & 3, wn = i >> 10;
     const int wave = wn / 9, n = wn - wave * 9;
-    const int nt = (wave >> 1) * 9 + n, tap = nt >> 1, cih = nt & 1;
+    const int nt = wg_nt(wave, n), tap = nt >> 1, cih = nt & 1;
     const int col = tap * 64 + cih * 32 + (lane & 31);
-    const int co = (wave & 1) * 32 + e + 8 * r4 + 4 * (lane >> 5);
+    const int co = wg_cot(wave, n) * 32 + e + 8 * r4 + 4 * (lane >> 5);
     atomicAdd(&dW[co * KTOT + col], (s0 + s1) + (s2 + s3));
 }
 
@@ -694,8 +731,9 @@ extern "C" int audiossl_conv3x3_wgrad(const void* dY, const void* X, float* dWp,
     const int rows = N * Ti, TT = 256 / Fi, tiles = (rows + TT - 1) / TT;
     const int grid = tiles < 256 ? tiles : 256;
     // workspace (optional): 2 * 256 * 64 * 576 floats cover every launch shape; without it the results go through atomics
-    const bool two_stage = workspace != nullptr && workspace_floats >= 2L * grid * CH * KTOT;
-    WgradArgs a{static_cast<const bf16*>(dY), static_cast<const bf16*>(X), dWp, Ti, rows, tiles, two_stage ? workspace : nullptr};
+    const bool two_stage = workspace != nullptr && workspace_floats >= (long)grid * CH * KTOT;
+    static const int wg_dbg = getenv("AUDIOSSL_CONV_DBG") ? atoi(getenv("AUDIOSSL_CONV_DBG")) : 0;
+    WgradArgs a{static_cast<const bf16*>(dY), static_cast<const bf16*>(X), dWp, Ti, rows, tiles, two_stage ? workspace : nullptr, wg_dbg};
     // measured in isolation (tools/conv_bench.py, B = 512): two-stage with the pixel split 122 / 46 us (32- / 16-wide layer),
     // without it 140 / 51 us; atomics 147 / 67 us without the split and 155 / 91 us with it (twice the atomics)
     static const int kg_env = getenv("AUDIOSSL_WGRAD_KG") ? atoi(getenv("AUDIOSSL_WGRAD_KG")) : 0;
@@ -703,7 +741,7 @@ extern "C" int audiossl_conv3x3_wgrad(const void* dY, const void* X, float* dWp,
     static bool attr[4] = {false, false, false, false};
 #define WGRAD_LAUNCH(FI_, KG_, SLOT)                                                                      \
     do {                                                                                                  \
-        const size_t lds = sizeof(bf16) * (256 * PIXW + Halo<FI_, PIXW>::ELEMS);                          \
+        const size_t lds = max(sizeof(bf16) * (256 * PIXW + Halo<FI_, PIXW>::ELEMS), (size_t)(KG_ == 2 ? 4 * 9 * 16 * 64 * 4 : 0)); \
         if (!attr[SLOT]) { if (set_lds(conv3x3_wgrad_kernel<FI_, KG_>, lds)) return ASSL_ELAUNCH; attr[SLOT] = true; } \
         hipLaunchKernelGGL((conv3x3_wgrad_kernel<FI_, KG_>), dim3(grid), dim3(256 * KG_), lds, s, a);    \
     } while (0)
@@ -711,6 +749,6 @@ extern "C" int audiossl_conv3x3_wgrad(const void* dY, const void* X, float* dWp,
     else          { if (kg == 2) WGRAD_LAUNCH(16, 2, 2); else WGRAD_LAUNCH(16, 1, 3); }
 #undef WGRAD_LAUNCH
     if (two_stage)
-        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(CH * KTOT / 256, 8), dim3(256), 0, s, workspace, grid * kg, dWp);
+        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(CH * KTOT / 256, 8), dim3(256), 0, s, workspace, grid, dWp);
     ASSL_LAUNCH_CHECK();
 }

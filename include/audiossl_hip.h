@@ -190,7 +190,7 @@ int audiossl_unpack_conv_dw(const float* dWp, float* dW, void* stream);
  *               stat_replicas > 1: sum -> [stat_replicas][128] doubles (replica r: sums at r*128, sums of squares at r*128 + 64;
  *               sumsq == sum + 64): workgroup i adds into replica i % stat_replicas, bn_relu_pool_train_fwd folds them.
  * conv3x3_wgrad: dWp fp32 [64][576] += dY^T * patches(X) (caller zeroes; unpack_conv_dw maps back to [co][ci][3][3]).
- *   workspace (optional, 2 * 256 * 64 * 576 floats = 75.5 MB covers every shape): per-workgroup results are stored there and
+ *   workspace (optional, 256 * 64 * 576 floats = 37.7 MB covers every shape): per-workgroup results are stored there and
  *   folded by a second kernel; null = every workgroup adds its result to dWp with fp32 atomics. */
 int audiossl_conv3x3_fwd(const void* X, const void* W, const float* bias, void* Y, int out_f32, double* sum,
                          double* sumsq, int stat_replicas, int N, int Ti, int Fi, void* stream);
