@@ -36,6 +36,9 @@ static inline hipError_t assl_zero_async(void* p, size_t bytes, hipStream_t s) {
 #define ASSL_ZERO_ALWAYS(ptr, bytes, s) \
     do { if (assl_zero_async((ptr), (bytes), (s)) != hipSuccess) return ASSL_ELAUNCH; } while (0)
 
+// Name of the kernel the most recent GEMM-family entry point launched (the dispatch rules pick among several instantiations);
+// read back through audiossl_last_kernel by bench.py so that its per-kernel table joins to rocprofv3's kernel names.
+extern const char* g_assl_last_kernel;
 #define ASSL_LAUNCH_CHECK() do { if (hipGetLastError() != hipSuccess) return ASSL_ELAUNCH; return ASSL_OK; } while (0)
 
 typedef __bf16 bf16;

@@ -12,6 +12,8 @@
 // Fragment K-order: lane half h owns k in [8h, 8h+8) of every 16-wide k-step for both operands; for
 // bf16 that is the hardware map of 32x32x16, for f32 the 8 k's are fed to 8 successive 32x32x2 MFMAs
 // (any bijection k->(step,half) is valid as long as A and B agree).
+#include <cstdarg>
+#include <cstdio>
 #include <cstdlib>
 #include "common.h"
 
@@ -56,6 +58,19 @@ struct GemmArgs {
     float* bl_loss;           // [32] fp32 replicas (workgroup i adds into replica i & 31; the caller sums them)
     float bl_coef, bl_dscale;
 };
+
+// kernel names as rocprofv3 prints them (demangled, except for instantiations on __bf16, which its demangler leaves mangled)
+template <typename T> const char* type_code();
+template <> const char* type_code<bf16>() { return "DF16b"; }
+template <> const char* type_code<float>() { return "f"; }
+static const char* note_name(char (&buf)[96], const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    return buf;
+}
+#define TF(b) ((b) ? "true" : "false")
 
 template <typename T> struct Mma;
 template <> struct Mma<bf16> {
@@ -355,7 +370,7 @@ struct Stage {
 // NW = 8 waves (4 x 2): 256 x 128 tile - twice the MFMA work per byte staged (the 128 x 128 tile needs as many L1->LDS cycles
 // per k-step as MFMA cycles) and two waves per SIMD, so one wave's MFMAs cover the other's LDS reads and staging stores.
 template <typename T, bool TA, bool TB, int BK, int MI, int NW = 4, bool SPLIT_EPI = false>
-__device__ __forceinline__ void gemm_body(const GemmArgs& g, char* smem) {
+__device__ __forceinline__ void gemm_body(const GemmArgs& g, char* smem, int wg) {
     constexpr int BMv = 16 * MI * NW;
     using SA = Stage<T, TA, BK, BMv, 64 * NW>;
     using SB = Stage<T, TB, BK, BN, 64 * NW>;
@@ -363,11 +378,6 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g, char* smem) {
     T* const ldsB0 = ldsA0 + 2 * SA::LDS_ELEMS;
 
     const int tiles_n = (g.N + BN - 1) / BN;
-    // Workgroups are dealt to the 8 XCDs round-robin (id mod 8), each with its own 4 MB L2.  Give every XCD a CONTIGUOUS run
-    // of tiles (whole tile rows: one A row panel is then fetched into one L2 instead of all eight) - operand re-reads
-    // that miss L2 are served by the Infinity Cache at about half the L2 rate, which bounded the 6144-row GEMMs.
-    int wg = blockIdx.x;
-    if (g.xcd_remap) wg = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
     const int bm = (wg / tiles_n) * BMv, bn = (wg % tiles_n) * BN;
     // split-K range, in whole BK steps
     const int ksteps = (g.K + BK - 1) / BK;
@@ -435,7 +445,10 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g, char* smem) {
 template <typename T, bool TA, bool TB, int BK, int MI, int NW = 4>
 __global__ __launch_bounds__(64 * NW) void gemm_kernel(GemmArgs g) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    gemm_body<T, TA, TB, BK, MI, NW>(g, smem);
+    // Workgroups are dealt to the 8 XCDs round-robin (id mod 8), each with its own 4 MB L2.  Give every XCD a CONTIGUOUS run
+    // of tiles (whole tile rows: one A row panel is then fetched into one L2 instead of all eight) - operand re-reads
+    // that miss L2 are served by the Infinity Cache at about half the L2 rate, which bounded the 6144-row GEMMs.
+    gemm_body<T, TA, TB, BK, MI, NW>(g, smem, g.xcd_remap ? (int)((blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3)) : (int)blockIdx.x);
 }
 
 // 256 x 256 output tile, 512 threads = 8 waves (2 x 4), each wave 128 x 64 = 4 x 2 accumulators: per 64-deep k-step the
@@ -520,6 +533,7 @@ int launch256(const GemmArgs& g, hipStream_t s) {
     const int tiles = ceil_div(g.M, 256) * ceil_div(g.N, 256);
     GemmArgs ga = g;
     ga.xcd_remap = tiles % 8 == 0 && tiles >= 64;
+    { static char nm[96]; g_assl_last_kernel = note_name(nm, "gemm256_kernel<%s, %s>", TF(TA), TF(TB)); }
     hipLaunchKernelGGL((gemm256_kernel<TA, TB>), dim3(tiles, 1, g.ksplit), dim3(512), lds, s, ga);
     ASSL_LAUNCH_CHECK();
 }
@@ -535,15 +549,40 @@ int dispatch256(const GemmArgs& g, int ta, int tb, hipStream_t s) {
 // the same chain of GEMMs on different operands; issued as separate launches on separate streams they were serialised by
 // the hardware-queue mapping of the graph executor (1.6 ms of a 3.3 ms step), and each launch filled half the chip at best.
 constexpr int MAX_MULTI = 4;
-struct GemmMulti { GemmArgs p[MAX_MULTI]; };
+// tile_end: running totals of the problems' tile counts for the tile shape of the kernel that is launched (set by multi_grid)
+struct GemmMulti { GemmArgs p[MAX_MULTI]; int tile_end[MAX_MULTI]; int total; };
+
+// One-dimensional grid over the tiles of ALL problems, padded to a multiple of 8 workgroups.  Workgroup ids go to the XCDs round-
+// robin, so id -> (id & 7) * (grid / 8) + (id >> 3) hands every XCD a CONTIGUOUS run of the concatenated tile list: whole tile
+// rows of ONE problem (its A panels and its B operand meet in one L2) instead of a slice of every tile row of every problem -
+// the multi-problem launches of round 2 re-fetched their operands 4.2 x (86.6 MB per launch against 21 MB, PMC), and the grid was
+// sized for the widest problem (idle workgroups for the narrower ones).  -> problem index (-1: padding), tile index in `wg`.
+__device__ __forceinline__ int multi_locate(const GemmMulti& gm, int& wg) {
+    const int v = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+    if (v >= gm.total) return -1;
+    int p = 0;
+    while (v >= gm.tile_end[p]) ++p;
+    wg = v - (p ? gm.tile_end[p - 1] : 0);
+    return p;
+}
+// host side: fills tile_end / total for BMt x BNt tiles, returns the grid size
+static int multi_grid(GemmMulti& gm, int count, int BMt, int BNt) {
+    int tot = 0;
+    for (int i = 0; i < MAX_MULTI; ++i) {
+        if (i < count) tot += ceil_div(gm.p[i].M, BMt) * ceil_div(gm.p[i].N, BNt);
+        gm.tile_end[i] = tot;
+    }
+    gm.total = tot;
+    return (tot + 7) / 8 * 8;
+}
 
 template <typename T, bool TA, bool TB, int BK, int MI, int NW = 4>
 __global__ __launch_bounds__(64 * NW) void gemm_multi_kernel(GemmMulti gm) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const GemmArgs& g = gm.p[blockIdx.y];
-    const int tiles = ((g.M + 16 * MI * NW - 1) / (16 * MI * NW)) * ((g.N + BN - 1) / BN);
-    if ((int)blockIdx.x >= tiles) return;
-    gemm_body<T, TA, TB, BK, MI, NW>(g, smem);
+    int wg;
+    const int p = multi_locate(gm, wg);
+    if (p < 0) return;
+    gemm_body<T, TA, TB, BK, MI, NW>(gm.p[p], smem, wg);
 }
 
 template <typename T, bool TA, bool TB, int BK, int MI, int NW>
@@ -554,7 +593,9 @@ constexpr size_t gemm_lds() {
 }
 
 template <typename T, bool TA, bool TB, int BK, int MI, int NW = 4>
-int launch_multi(const GemmMulti& gm, int count, int max_tiles, int ksplit, hipStream_t s) {
+int launch_multi(const GemmMulti& gm_, int count, int ksplit, hipStream_t s) {
+    GemmMulti gm = gm_;
+    const int grid = multi_grid(gm, count, 16 * MI * NW, BN);
     const size_t lds = gemm_lds<T, TA, TB, BK, MI, NW>();
     static bool attr_set = false;
     if (!attr_set) {
@@ -562,7 +603,8 @@ int launch_multi(const GemmMulti& gm, int count, int max_tiles, int ksplit, hipS
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return ASSL_ELAUNCH;
         attr_set = true;
     }
-    hipLaunchKernelGGL((gemm_multi_kernel<T, TA, TB, BK, MI, NW>), dim3(max_tiles, count, ksplit), dim3(64 * NW), lds, s, gm);
+    { static char nm[96]; g_assl_last_kernel = note_name(nm, "gemm_multi_kernelI%sLb%dELb%dELi%dELi%dELi%dE", type_code<T>(), (int)TA, (int)TB, BK, MI, NW); }
+    hipLaunchKernelGGL((gemm_multi_kernel<T, TA, TB, BK, MI, NW>), dim3(grid, 1, ksplit), dim3(64 * NW), lds, s, gm);
     ASSL_LAUNCH_CHECK();
 }
 
@@ -579,6 +621,7 @@ int launch(const GemmArgs& g, hipStream_t s) {
     static const bool remap = getenv("AUDIOSSL_GEMM_XCD") ? atoi(getenv("AUDIOSSL_GEMM_XCD")) != 0 : true;
     GemmArgs ga = g;
     ga.xcd_remap = remap && tiles % 8 == 0 && tiles >= 64;
+    { static char nm[96]; g_assl_last_kernel = note_name(nm, "gemm_kernelI%sLb%dELb%dELi%dELi%dELi%dE", type_code<T>(), (int)TA, (int)TB, BK, MI, NW); }
     hipLaunchKernelGGL((gemm_kernel<T, TA, TB, BK, MI, NW>), dim3(tiles, 1, g.ksplit), dim3(64 * NW), lds, s, ga);
     ASSL_LAUNCH_CHECK();
 }
@@ -757,6 +800,7 @@ int launch_ring(const GemmArgs& g, hipStream_t s) {
         attr_set = true;
     }
     const int tiles = ceil_div(g.M, 64 * MI) * ceil_div(g.N, BN);
+    { static char nm[96]; g_assl_last_kernel = note_name(nm, "gemm_ring_kernel<%s, %s, %d, %d>", TF(TA), TF(TB), MI, NST); }
     hipLaunchKernelGGL((gemm_ring_kernel<TA, TB, MI, NST>), dim3(tiles, 1, g.ksplit), dim3(256), lds, s, g);
     ASSL_LAUNCH_CHECK();
 }
@@ -787,9 +831,11 @@ int dispatch_ring(const GemmArgs& g, int ta, int tb, hipStream_t s) {
 // Two buffers x four parts = 128 KB of LDS; accumulators 128 VGPRs + 64 of fragments.  Operand layouts as the ring kernel
 // (K-contiguous: [row][64 k] image, 16-byte chunk ^= (row >> 1) & 7; row-contiguous: [64 k][128 rows] image read with
 // ds_read_b64_tr_b16, 64-byte group ^= k & 3), the swizzle applied to the DMA's source address.  K % 64 == 0.
-template <bool TRANS, bool IS_A>
+// GROUP = rows of ONE wave row (column) inside a part, STRIDE = tile rows between consecutive wave rows: part-row p of part X is
+// tile row (p / GROUP) * STRIDE + X * GROUP + p % GROUP.  256 x 256 kernel: A <64, 128>, B <32, 64>; 256 x 128 kernel: A <32, 64>, B <64, 64>.
+template <bool TRANS, int GROUP, int STRIDE>
 struct PartOp {
-    static constexpr int NBLK = IS_A ? 2 : 1;                // 32-row fragment blocks of this wave inside a part
+    static constexpr int NBLK = GROUP / 32;                  // 32-row fragment blocks of this wave inside a part
     // DMA = buffer_load_dwordx4 ... lds: 32-bit per-lane byte offsets (two instructions per part), everything that is uniform -
     // tile origin, K-tile, part - in the scalar offset; rows / columns past the matrix read zeros or other valid elements of the
     // buffer (the descriptor bounds the access), their results are never stored
@@ -799,18 +845,17 @@ struct PartOp {
     int foff[NBLK], fsw[NBLK];
     __device__ __forceinline__ void init(const void* base_, unsigned bytes, long ld, int r0, int k0, int wave, int lane, int wsel) {
         rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base_), 0, bytes, 0x00020000);
-        const int w0 = wsel * (IS_A ? 64 : 32);              // this wave's first part-row
-        // part-row p of part X <-> row of the 256-row tile: A: (p >> 6) * 128 + X * 64 + (p & 63); B: (p >> 5) * 64 + X * 32 + (p & 31)
+        const int w0 = wsel * GROUP;                         // this wave's first part-row
         if (!TRANS) {
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
                 const int p = wave * 16 + i * 8 + (lane >> 3);
                 const int sc = (lane & 7) ^ ((p >> 1) & 7);
-                const int row = IS_A ? (p >> 6) * 128 + (p & 63) : (p >> 5) * 64 + (p & 31);
+                const int row = (p / GROUP) * STRIDE + (p % GROUP);
                 voff[i] = (int)(((long)row * ld + sc * 8) * 2);
             }
             kstride = GBK * 2;
-            part_delta = (int)((IS_A ? 64 : 32) * ld * 2);
+            part_delta = (int)(GROUP * ld * 2);
             base_off = (int)(((long)r0 * ld + k0) * 2);
 #pragma unroll
             for (int b = 0; b < NBLK; ++b) {
@@ -822,11 +867,11 @@ struct PartOp {
             for (int i = 0; i < 2; ++i) {
                 const int kl = wave * 8 + i * 4 + (lane >> 4), pc = lane & 15;
                 const int roff = ((((pc >> 2) ^ (kl & 3)) << 2) + (pc & 3)) * 8;
-                const int row = IS_A ? (roff >> 6) * 128 + (roff & 63) : (roff >> 5) * 64 + (roff & 31);
+                const int row = (roff / GROUP) * STRIDE + (roff % GROUP);
                 voff[i] = (int)(((long)kl * ld + row) * 2);
             }
             kstride = (int)(GBK * ld * 2);
-            part_delta = (IS_A ? 64 : 32) * 2;
+            part_delta = GROUP * 2;
             base_off = (int)(((long)k0 * ld + r0) * 2);
             const int q = (lane & 15) >> 2, pp = lane & 3, h4 = (lane >> 4) & 1, half = lane >> 5;
 #pragma unroll
@@ -860,12 +905,16 @@ struct PartOp {
 
 constexpr int P8_PART = 16384, P8_BUF = 4 * P8_PART;         // slot order inside a buffer: A(r0) B(c0) B(c1) A(r1)
 
+// Workgroup ids are dealt to the 8 XCDs round-robin (id mod 8): give every XCD a CONTIGUOUS run of tiles, so that the tiles of a
+// row (one A panel) and neighbouring rows meet in one L2.  Bijective for any grid size.
+__device__ __forceinline__ int xcd_contiguous(int id, int nwg) {
+    const int xcd = id & 7, q8 = nwg >> 3, r8 = nwg & 7;
+    return (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (id >> 3);
+}
+
 template <bool TA, bool TB, int DBG = 0>
-__device__ __forceinline__ void p8_body(const GemmArgs& g, char* smem) {
+__device__ __forceinline__ void p8_body(const GemmArgs& g, char* smem, int wg) {
     const int tiles_n = (g.N + 255) / 256;
-    const int nwg = gridDim.x, xcd = blockIdx.x & 7, q8 = nwg >> 3, r8 = nwg & 7;
-    const int wg = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (blockIdx.x >> 3);
-    if (wg >= tiles_n * ((g.M + 255) / 256)) return;         // multi-problem launches: the grid is sized for the widest problem
     const int bm = (wg / tiles_n) * 256, bn = (wg % tiles_n) * 256;
     const int ksteps = g.K / GBK;
     const int per = (ksteps + g.ksplit - 1) / g.ksplit;
@@ -875,7 +924,7 @@ __device__ __forceinline__ void p8_body(const GemmArgs& g, char* smem) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, half = lane >> 5;
     const int wr = wave >> 2, wc = wave & 3;
 
-    PartOp<TA, true> oa; PartOp<TB, false> ob;
+    PartOp<TA, 64, 128> oa; PartOp<TB, 32, 64> ob;
     oa.init(g.A, g.a_bytes, g.lda, bm, ks0 * GBK, wave, lane, wr);
     ob.init(g.B, g.b_bytes, g.ldb, bn, ks0 * GBK, wave, lane, wc);
     char* const wdst = smem + wave * 2048;                   // this wave's 2 KB slice of every part image
@@ -1006,7 +1055,7 @@ __device__ __forceinline__ void p8_body(const GemmArgs& g, char* smem) {
 template <bool TA, bool TB, int DBG = 0>
 __global__ __launch_bounds__(512) void gemm_p8_kernel(GemmArgs g) {
     extern __shared__ __attribute__((aligned(1024))) char smem[];
-    p8_body<TA, TB, DBG>(g, smem);
+    p8_body<TA, TB, DBG>(g, smem, xcd_contiguous(blockIdx.x, gridDim.x));
 }
 
 template <bool TA, bool TB, int DBG = 0>
@@ -1019,16 +1068,22 @@ int launch_p8(const GemmArgs& g, hipStream_t s) {
         attr_set = true;
     }
     const int tiles = ceil_div(g.M, 256) * ceil_div(g.N, 256);
+    { static char nm[96]; g_assl_last_kernel = note_name(nm, "gemm_p8_kernel<%s, %s, %d>", TF(TA), TF(TB), DBG); }
     hipLaunchKernelGGL((gemm_p8_kernel<TA, TB, DBG>), dim3(tiles, 1, g.ksplit), dim3(512), lds, s, g);
     ASSL_LAUNCH_CHECK();
 }
 template <bool TA, bool TB>
 __global__ __launch_bounds__(512) void gemm_p8_multi_kernel(GemmMulti gm) {
     extern __shared__ __attribute__((aligned(1024))) char smem[];
-    p8_body<TA, TB, 0>(gm.p[blockIdx.y], smem);
+    int wg;
+    const int p = multi_locate(gm, wg);
+    if (p < 0) return;
+    p8_body<TA, TB, 0>(gm.p[p], smem, wg);
 }
 template <bool TA, bool TB>
-int launch_p8_multi(const GemmMulti& gm, int count, int max_tiles, int ksplit, hipStream_t s) {
+int launch_p8_multi(const GemmMulti& gm_, int count, int ksplit, hipStream_t s) {
+    GemmMulti gm = gm_;
+    const int grid = multi_grid(gm, count, 256, 256);
     const size_t lds = max((size_t)2 * P8_BUF, EPI_LDS * 2);
     static bool attr_set = false;
     if (!attr_set) {
@@ -1036,14 +1091,15 @@ int launch_p8_multi(const GemmMulti& gm, int count, int max_tiles, int ksplit, h
                                 (int)lds) != hipSuccess) return ASSL_ELAUNCH;
         attr_set = true;
     }
-    hipLaunchKernelGGL((gemm_p8_multi_kernel<TA, TB>), dim3(max_tiles, count, ksplit), dim3(512), lds, s, gm);
+    { static char nm[96]; g_assl_last_kernel = note_name(nm, "gemm_p8_multi_kernel<%s, %s>", TF(TA), TF(TB)); }
+    hipLaunchKernelGGL((gemm_p8_multi_kernel<TA, TB>), dim3(grid, 1, ksplit), dim3(512), lds, s, gm);
     ASSL_LAUNCH_CHECK();
 }
-int dispatch_p8_multi(const GemmMulti& gm, int count, int max_tiles, int ksplit, int ta, int tb, hipStream_t s) {
-    if (!ta && !tb) return launch_p8_multi<false, false>(gm, count, max_tiles, ksplit, s);
-    if (!ta && tb) return launch_p8_multi<false, true>(gm, count, max_tiles, ksplit, s);
-    if (ta && tb) return launch_p8_multi<true, true>(gm, count, max_tiles, ksplit, s);
-    return launch_p8_multi<true, false>(gm, count, max_tiles, ksplit, s);
+int dispatch_p8_multi(const GemmMulti& gm, int count, int ksplit, int ta, int tb, hipStream_t s) {
+    if (!ta && !tb) return launch_p8_multi<false, false>(gm, count, ksplit, s);
+    if (!ta && tb) return launch_p8_multi<false, true>(gm, count, ksplit, s);
+    if (ta && tb) return launch_p8_multi<true, true>(gm, count, ksplit, s);
+    return launch_p8_multi<true, false>(gm, count, ksplit, s);
 }
 
 int dispatch_p8(const GemmArgs& g, int ta, int tb, hipStream_t s) {
@@ -1064,12 +1120,175 @@ int dispatch_p8(const GemmArgs& g, int ta, int tb, hipStream_t s) {
     return launch_p8<true, false>(g, s);
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// 256 x 128 output tile, 8 waves (4 x 2, wave tile 64 x 64): the hand-scheduled loop for the M = 1,024 problems of the projector
+// heads.  There the 256 x 256 kernel has 96 tiles for 256 CUs (three heads, 32 tiles each) and the 128 x 128 kernels need as many
+// L2 -> LDS staging cycles per K-tile as MFMA cycles; this tile gives 192 workgroups and 0.75 staging cycles per MFMA cycle.
+//   * a K-tile (64 deep) is THREE 16 KB parts - A(r0), B, A(r1): the 32-row halves of every wave's 64 rows and the wave's 64
+//     columns - staged by direct-to-LDS DMA (two 1 KB instructions per wave and part), three buffers = 144 KB of LDS;
+//   * a phase = one 32-row half of every wave's tile over the K-tile (8 MFMA 32x32x16): phase 1 reads the fragments of A(r0) and
+//     B (which stay in registers for phase 2), phase 2 those of A(r1); LOAD and MFMA sections closed by raw s_barriers, the two
+//     waves of a SIMD (waves 0-3 / 4-7) one section apart, as in the 256 x 256 kernel;
+//   * phase 1 of K-tile t stages A(r0) and B of K-tile t + 2, phase 2 stages A(r1) of t + 2: every part is re-staged two phases
+//     after its last fragment read (WAR: the barrier behind the later wave group's completed reads lies in between) and is read
+//     four phases after its issue, one phase after the counted wait that retired it in every wave (RAW) - all but the five
+//     youngest parts at the end of a phase-1 LOAD section (vmcnt(10)), all but the four youngest at the end of phase 2 (vmcnt(8));
+//   * K-tiles past the end are staged from an offset beyond the buffer (zeros, no traffic): the counts stay uniform.
+constexpr int P6_PART = 16384, P6_BUF = 3 * P6_PART, P6_NBUF = 3;      // slot order inside a buffer: A(r0) B A(r1)
+
+template <bool TA, bool TB>
+__device__ __forceinline__ void p6_body(const GemmArgs& g, char* smem, int wg) {
+    const int tiles_n = (g.N + 127) / 128;
+    const int bm = (wg / tiles_n) * 256, bn = (wg % tiles_n) * 128;
+    const int ksteps = g.K / GBK;
+    const int per = (ksteps + g.ksplit - 1) / g.ksplit;
+    const int ks0 = blockIdx.z * per, ks1 = min(ksteps, ks0 + per);
+    if (ks0 >= ks1) return;
+    const int nk = ks1 - ks0;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, half = lane >> 5;
+    const int wr = wave >> 1, wc = wave & 1;
+
+    PartOp<TA, 32, 64> oa; PartOp<TB, 64, 64> ob;
+    oa.init(g.A, g.a_bytes, g.lda, bm, ks0 * GBK, wave, lane, wr);
+    ob.init(g.B, g.b_bytes, g.ldb, bn, ks0 * GBK, wave, lane, wc);
+    char* const wdst = smem + wave * 2048;                   // this wave's 2 KB slice of every part image
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    auto issue = [&](int slot, int t, int boff) {            // slot: 0 A(r0), 1 B, 2 A(r1)
+        char* d = wdst + boff + slot * P6_PART;
+        const bool live = t < nk;
+        if (slot == 1) ob.issue(0, t, d, live); else oa.issue(slot >> 1, t, d, live);
+    };
+    Vec8<bf16> fa[4], fb[2][4];
+    auto loadA = [&](const char* img) {
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) fa[kk] = oa.frag(img, 0, kk, half);
+    };
+    auto loadB = [&](const char* img) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) fb[j][kk] = ob.frag(img, j, kk, half);
+    };
+    auto mfma_half = [&](int X) {
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) Mma<bf16>::run(acc[X][j], fa[kk], fb[j][kk]);
+        __builtin_amdgcn_s_setprio(0);
+    };
+    auto sync = [&]() {                                      // end of an MFMA section
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+    };
+
+    // prologue: K-tiles 0 and 1 whole; A(r0) and B of K-tile 0 have landed when all but the four youngest parts have
+    issue(0, 0, 0); issue(1, 0, 0); issue(2, 0, 0);
+    issue(0, 1, P6_BUF); issue(1, 1, P6_BUF); issue(2, 1, P6_BUF);
+    wait_vm<8>();
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    if (wave >= 4) { __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); }   // the second wave of every SIMD: one section behind
+    int cb = 0, ib = 2 * P6_BUF;                             // buffer of K-tile t / of K-tile t + 2 (byte offsets)
+    for (int t = 0; t < nk; ++t) {
+        const char* const img = smem + cb;
+        // ---- phase 1: rows r0
+        loadA(img); loadB(img + P6_PART);
+        issue(0, t + 2, ib); issue(1, t + 2, ib);
+        wait_vm<10>();
+        __builtin_amdgcn_s_barrier();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_half(0);
+        sync();
+        // ---- phase 2: rows r1
+        loadA(img + 2 * P6_PART);
+        issue(2, t + 2, ib);
+        wait_vm<8>();
+        __builtin_amdgcn_s_barrier();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_half(1);
+        sync();
+        cb = cb + P6_BUF == P6_NBUF * P6_BUF ? 0 : cb + P6_BUF;
+        ib = ib + P6_BUF == P6_NBUF * P6_BUF ? 0 : ib + P6_BUF;
+    }
+    if (wave < 4) { __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); }
+    wait_vm<0>();
+    epilogue<bf16, 2>(g, acc, smem, bm + wr * 64, bn + wc * 64, lane, wave);
+}
+
+template <bool TA, bool TB>
+__global__ __launch_bounds__(512) void gemm_p6_kernel(GemmArgs g) {
+    extern __shared__ __attribute__((aligned(1024))) char smem[];
+    p6_body<TA, TB>(g, smem, xcd_contiguous(blockIdx.x, gridDim.x));
+}
+template <bool TA, bool TB>
+__global__ __launch_bounds__(512) void gemm_p6_multi_kernel(GemmMulti gm) {
+    extern __shared__ __attribute__((aligned(1024))) char smem[];
+    int wg;
+    const int p = multi_locate(gm, wg);
+    if (p < 0) return;
+    p6_body<TA, TB>(gm.p[p], smem, wg);
+}
+constexpr size_t P6_LDS = (size_t)P6_NBUF * P6_BUF > EPI_LDS * 2 ? (size_t)P6_NBUF * P6_BUF : EPI_LDS * 2;
+
+template <bool TA, bool TB>
+int launch_p6(const GemmArgs& g, hipStream_t s) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_p6_kernel<TA, TB>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)P6_LDS) != hipSuccess) return ASSL_ELAUNCH;
+        attr_set = true;
+    }
+    const int tiles = ceil_div(g.M, 256) * ceil_div(g.N, 128);
+    { static char nm[96]; g_assl_last_kernel = note_name(nm, "gemm_p6_kernel<%s, %s>", TF(TA), TF(TB)); }
+    hipLaunchKernelGGL((gemm_p6_kernel<TA, TB>), dim3(tiles, 1, g.ksplit), dim3(512), P6_LDS, s, g);
+    ASSL_LAUNCH_CHECK();
+}
+template <bool TA, bool TB>
+int launch_p6_multi(const GemmMulti& gm_, int count, int ksplit, hipStream_t s) {
+    GemmMulti gm = gm_;
+    const int grid = multi_grid(gm, count, 256, 128);
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_p6_multi_kernel<TA, TB>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)P6_LDS) != hipSuccess) return ASSL_ELAUNCH;
+        attr_set = true;
+    }
+    { static char nm[96]; g_assl_last_kernel = note_name(nm, "gemm_p6_multi_kernel<%s, %s>", TF(TA), TF(TB)); }
+    hipLaunchKernelGGL((gemm_p6_multi_kernel<TA, TB>), dim3(grid, 1, ksplit), dim3(512), P6_LDS, s, gm);
+    ASSL_LAUNCH_CHECK();
+}
+int dispatch_p6(const GemmArgs& g, int ta, int tb, hipStream_t s) {
+    if (!ta && !tb) return launch_p6<false, false>(g, s);
+    if (!ta && tb) return launch_p6<false, true>(g, s);
+    if (ta && tb) return launch_p6<true, true>(g, s);
+    return launch_p6<true, false>(g, s);
+}
+int dispatch_p6_multi(const GemmMulti& gm, int count, int ksplit, int ta, int tb, hipStream_t s) {
+    if (!ta && !tb) return launch_p6_multi<false, false>(gm, count, ksplit, s);
+    if (!ta && tb) return launch_p6_multi<false, true>(gm, count, ksplit, s);
+    if (ta && tb) return launch_p6_multi<true, true>(gm, count, ksplit, s);
+    return launch_p6_multi<true, false>(gm, count, ksplit, s);
+}
+
 // BK = 32 with a register budget for THREE workgroups per CU (41 KB of LDS each; the epilogue runs on half-height tiles so
 // that it fits the same 41 KB); AUDIOSSL_GEMM_BK32=0 disables, =2 also uses it for transposed-A problems.
 template <bool TA, bool TB>
 __global__ __launch_bounds__(256, 3) void gemm_bk32_kernel(GemmArgs g) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    gemm_body<bf16, TA, TB, 32, 2, 4, true>(g, smem);
+    gemm_body<bf16, TA, TB, 32, 2, 4, true>(g, smem, g.xcd_remap ? (int)((blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3)) : (int)blockIdx.x);
 }
 template <bool TA, bool TB>
 int launch_bk32(const GemmArgs& g, hipStream_t s) {
@@ -1084,6 +1303,7 @@ int launch_bk32(const GemmArgs& g, hipStream_t s) {
     const int tiles = ceil_div(g.M, 128) * ceil_div(g.N, BN);
     GemmArgs ga = g;
     ga.xcd_remap = tiles % 8 == 0 && tiles >= 64;
+    { static char nm[96]; g_assl_last_kernel = note_name(nm, "gemm_bk32_kernel<%s, %s>", TF(TA), TF(TB)); }
     hipLaunchKernelGGL((gemm_bk32_kernel<TA, TB>), dim3(tiles, 1, g.ksplit), dim3(256), lds, s, ga);
     ASSL_LAUNCH_CHECK();
 }
@@ -1121,26 +1341,35 @@ static int dispatch_multi(const GemmMulti& gm, int count, int M, int N, int kmin
                           const int* K, const int* Nv) {
     const long blocks = (long)ceil_div(M, BM) * ceil_div(N, BN) * ksplit * count;
     const bool small = blocks <= 128 && M > 64;
-    const int max_tiles = ceil_div(M, small ? 64 : BM) * ceil_div(N, BN);
-#define MULTI(BK_, MI_, NW_, TILES)                                                                       \
+#define MULTI(BK_, MI_, NW_)                                                                              \
     do {                                                                                                  \
-        if (!trans_a && !trans_b) return launch_multi<bf16, false, false, BK_, MI_, NW_>(gm, count, TILES, ksplit, s); \
-        if (!trans_a && trans_b) return launch_multi<bf16, false, true, BK_, MI_, NW_>(gm, count, TILES, ksplit, s);   \
-        if (trans_a && trans_b) return launch_multi<bf16, true, true, BK_, MI_, NW_>(gm, count, TILES, ksplit, s);     \
-        return launch_multi<bf16, true, false, BK_, MI_, NW_>(gm, count, TILES, ksplit, s);                            \
+        if (!trans_a && !trans_b) return launch_multi<bf16, false, false, BK_, MI_, NW_>(gm, count, ksplit, s); \
+        if (!trans_a && trans_b) return launch_multi<bf16, false, true, BK_, MI_, NW_>(gm, count, ksplit, s);   \
+        if (trans_a && trans_b) return launch_multi<bf16, true, true, BK_, MI_, NW_>(gm, count, ksplit, s);     \
+        return launch_multi<bf16, true, false, BK_, MI_, NW_>(gm, count, ksplit, s);                            \
     } while (0)
     static const int p8 = getenv("AUDIOSSL_GEMM_P8") ? atoi(getenv("AUDIOSSL_GEMM_P8")) : -1;
-    bool p8_ok = M >= 256 && N >= 256 && (!trans_a || M % 8 == 0);
-    for (int i = 0; i < count; ++i) p8_ok = p8_ok && K[i] % GBK == 0 && (!trans_b || Nv[i] % 8 == 0);
+    static const int p6 = getenv("AUDIOSSL_GEMM_P6") ? atoi(getenv("AUDIOSSL_GEMM_P6")) : -1;
+    bool hs_ok = M >= 256 && N >= 128 && (!trans_a || M % 8 == 0);           // the hand-scheduled kernels: K % 64, whole 16-byte rows
+    long t6 = 0, t8 = 0;
+    for (int i = 0; i < count; ++i) {
+        hs_ok = hs_ok && K[i] % GBK == 0 && (!trans_b || Nv[i] % 8 == 0);
+        t6 += (long)ceil_div(M, 256) * ceil_div(Nv[i], 128);
+        t8 += (long)ceil_div(M, 256) * ceil_div(Nv[i], 256);
+    }
+    // the 256 x 128 kernel: problems whose 256 x 256 tiles would leave more than half of the CUs idle while the 256 x 128 tiles
+    // fit the chip in one round (the M = 1,024 layers and data gradients of the three heads: 192 workgroups)
+    if (p6 != 0 && hs_ok && (p6 == 1 || (t6 * ksplit >= 128 && t6 * ksplit <= 288 && t8 * ksplit < 128 && kmin >= 512)))
+        return dispatch_p6_multi(gm, count, ksplit, trans_a, trans_b, s);
     // multi-problem launches: measured wins for the transposed-A weight gradients of the three heads (2048 x 2048 x 1024:
-    // 50.9 -> 43.9 us, x 512: 31.3 -> 29.0 us); NT / NN at M = 1024 stay on the 128-row kernels (44.5 vs 46.7 us)
-    if (p8 != 0 && p8 != 2 && p8_ok && (p8 == 1 || (trans_a && (long)ceil_div(M, 256) * ceil_div(N, 256) * count * ksplit >= 128 && kmin >= 512)))
-        return dispatch_p8_multi(gm, count, ceil_div(M, 256) * ceil_div(N, 256), ksplit, trans_a, trans_b, s);
+    // 50.9 -> 43.9 us, x 512: 31.3 -> 29.0 us)
+    if (p8 != 0 && p8 != 2 && hs_ok && N >= 256 && (p8 == 1 || (trans_a && t8 * ksplit >= 128 && kmin >= 512)))
+        return dispatch_p8_multi(gm, count, ksplit, trans_a, trans_b, s);
     static const int w8 = getenv("AUDIOSSL_GEMM_W8") ? atoi(getenv("AUDIOSSL_GEMM_W8")) : 0;
-    if (w8 && M >= 256) MULTI(64, 2, 8, ceil_div(M, 256) * ceil_div(N, BN));
-    if (small) MULTI(64, 1, 4, max_tiles);
-    if (blocks <= 256 && kmin >= 512) MULTI(128, 2, 4, max_tiles);
-    MULTI(64, 2, 4, max_tiles);
+    if (w8 && M >= 256) MULTI(64, 2, 8);
+    if (small) MULTI(64, 1, 4);
+    if (blocks <= 256 && kmin >= 512) MULTI(128, 2, 4);
+    MULTI(64, 2, 4);
 #undef MULTI
 }
 
@@ -1224,6 +1453,13 @@ static int run_bf16(const GemmArgs& g, int trans_a, int trans_b, hipStream_t s) 
         }
         const bool layout_ok = p8 != 2 || (!trans_a && !trans_b);            // AUDIOSSL_GEMM_P8=2: K-contiguous operands only
         if (p8 == 1 || (layout_ok && t256 * ga.ksplit >= 128 && K / ga.ksplit >= 1024)) return dispatch_p8(ga, trans_a, trans_b, s);
+    }
+    // the hand-scheduled 256 x 128 kernel (written for the multi-problem launches of the projector heads, see dispatch_multi):
+    // single problems whose 256 x 128 tiles fill the chip once while the 256 x 256 tiles would leave half of it idle
+    static const int p6 = getenv("AUDIOSSL_GEMM_P6") ? atoi(getenv("AUDIOSSL_GEMM_P6")) : -1;
+    if (p6 != 0 && p8_ok && !g.lse_mode && M >= 256 && N >= 128) {
+        const long t6 = (long)ceil_div(M, 256) * ceil_div(N, 128), t8 = (long)ceil_div(M, 256) * ceil_div(N, 256);
+        if (p6 == 1 || (t6 * ksplit >= 128 && t6 * ksplit <= 288 && t8 * ksplit < 128 && K / ksplit >= 512)) return dispatch_p6(g, trans_a, trans_b, s);
     }
     // grids of >= 2 workgroups per CU with a K-contiguous A operand: K-step 32 and THREE co-resident workgroups per CU (41 KB
     // of LDS each, 126 VGPRs) - 12 waves per CU hide the staged-load and barrier waits better than two workgroups at K-step

@@ -702,6 +702,14 @@ __global__ __launch_bounds__(256) void dropout_mask_kernel(uint8_t* __restrict__
 
 int g_assl_prezeroed = 0;
 extern "C" int audiossl_set_prezeroed(int on) { g_assl_prezeroed = on ? 1 : 0; return ASSL_OK; }
+const char* g_assl_last_kernel = "";
+extern "C" int audiossl_last_kernel(char* name, int capacity) {
+    ASSL_REQUIRE(name && capacity > 0);
+    int i = 0;
+    for (; g_assl_last_kernel[i] && i < capacity - 1; ++i) name[i] = g_assl_last_kernel[i];
+    name[i] = 0;
+    return ASSL_OK;
+}
 
 #define S_(stream) static_cast<hipStream_t>(stream)
 #define GRID1(n) dim3((unsigned)(((long)(n) + 255) / 256))

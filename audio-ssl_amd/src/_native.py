@@ -122,12 +122,26 @@ def call(name, *args):
     if prof is not None:
         e1.record()
         global PROFILE_NOTE
+        note = PROFILE_NOTE
+        if full in _GEMM_FAMILY:                # which instantiation the dispatch picked (joins bench.py's table to rocprofv3 names)
+            note = (note, last_kernel())
         # scalar arguments only (host addresses of the multi-problem pointer arrays are ints too: dropped by magnitude)
-        prof.append((e0, e1, tuple(a for a in args if isinstance(a, float) or (isinstance(a, int) and abs(a) < (1 << 40))),
-                     PROFILE_NOTE))
+        prof.append((e0, e1, tuple(a for a in args if isinstance(a, float) or (isinstance(a, int) and abs(a) < (1 << 40))), note))
         PROFILE_NOTE = None
     if rc != 0:
         raise RuntimeError(f"{full} failed: {ERRORS.get(rc, rc)}")
+
+
+_GEMM_FAMILY = {"audiossl_gemm", "audiossl_gemm_multi", "audiossl_gemm_multi_barlow", "audiossl_moco_logits"}
+
+
+def last_kernel():
+    """Name (rocprofv3 spelling) of the kernel the most recent GEMM-family call launched."""
+    buf = ctypes.create_string_buffer(128)
+    rc = lib().audiossl_last_kernel(ctypes.addressof(buf), 128)
+    if rc != 0:
+        raise RuntimeError(f"audiossl_last_kernel failed: {ERRORS.get(rc, rc)}")
+    return buf.value.decode()
 
 
 def call_host(name, *args):

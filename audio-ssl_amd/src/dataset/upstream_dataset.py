@@ -75,14 +75,17 @@ class UpstreamFrontEnd:
     #      step of batch i.  All front-end state (RunningNorm, mixup ring) is only ever touched on that stream, in order.
     _stream = None
 
-    def submit(self, waves, plan=None):
+    def submit(self, waves, plan=None, after=None):
         """Start the front end for `waves` on the front-end stream; -> ticket for `collect`.  Call it BEFORE launching the
-        training step it should overlap with (the front-end stream waits for what is already queued on the current one)."""
+        training step it should overlap with (the front-end stream waits for what is already queued on the current one).
+        after: event of an upload of `waves` issued on a copy stream of the caller (the front-end stream alone waits for it)."""
         if not waves.is_cuda:
             waves = waves.cuda(non_blocking=True)
         if self._stream is None:
             self._stream = torch.cuda.Stream(device=waves.device)
         self._stream.wait_stream(torch.cuda.current_stream(waves.device))
+        if after is not None:
+            self._stream.wait_event(after)
         with torch.cuda.stream(self._stream):
             views = self(waves, plan)
             ev = torch.cuda.Event()

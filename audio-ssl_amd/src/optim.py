@@ -5,7 +5,45 @@ import torch
 from src import _native as N
 
 
-class HipSGD(torch.optim.Optimizer):
+class FlatState:
+    """state_dict / load_state_dict of the flat optimisers.  Their state is not torch's per-parameter dict but one buffer per
+    flat group (momentum, or Adam's two moments + step count), so the schema is this package's own and says so
+    (`schema: audiossl-flat-v1`): a checkpoint written by Lightning / torch.optim (`{state, param_groups}`) is recognised and
+    declined - load_state_dict returns False and the optimiser starts with fresh state - instead of dying on a missing key."""
+    SCHEMA = "audiossl-flat-v1"
+    state_buffers = ("momentum",)
+
+    def state_dict(self):
+        sd = {"schema": self.SCHEMA, "kind": type(self).__name__, "steps": int(getattr(self, "steps", 0)),
+              "param_groups": [{k: v for k, v in g.items() if k != "params"} for g in self.param_groups]}
+        for name in self.state_buffers:
+            sd[name] = [None if getattr(fg, name, None) is None else getattr(fg, name).clone() for fg in self.flat_groups]
+        sc = getattr(self, "step_count", None)
+        if sc is not None:
+            sd["step_count"] = int(sc.item())
+        return sd
+
+    def load_state_dict(self, sd):
+        if not isinstance(sd, dict) or sd.get("schema") != self.SCHEMA or sd.get("kind") != type(self).__name__ or \
+                any(len(sd.get(n, ())) != len(self.flat_groups) for n in self.state_buffers):
+            import warnings
+            warnings.warn(f"{type(self).__name__}: optimiser state of another schema "
+                          f"({sorted(sd) if isinstance(sd, dict) else type(sd).__name__}); starting with fresh optimiser state")
+            return False
+        self.steps = int(sd["steps"])
+        for name in self.state_buffers:
+            for fg, m in zip(self.flat_groups, sd[name]):
+                if m is not None and m.numel() != fg.numel:
+                    raise ValueError(f"{name}: {m.numel()} elements in the checkpoint, {fg.numel} in the model")
+                setattr(fg, name, None if m is None else m.to(fg.data.device).clone())
+        for g, saved in zip(self.param_groups, sd.get("param_groups", ())):
+            g.update({k: v for k, v in saved.items() if k in g and k != "params"})
+        if "step_count" in sd and self.flat_groups:
+            self.step_count = torch.full((1,), int(sd["step_count"]), dtype=torch.int64, device=self.flat_groups[0].data.device)
+        return True
+
+
+class HipSGD(FlatState, torch.optim.Optimizer):
     def __init__(self, flat_groups, params, lr, momentum=0.9, weight_decay=0.0, grad_scale=1.0):
         super().__init__(params, dict(lr=lr, momentum=momentum, weight_decay=weight_decay))
         self.flat_groups = list(flat_groups)
@@ -66,17 +104,8 @@ class HipSGD(torch.optim.Optimizer):
             for p in fg.params:
                 p.grad = None
 
-    def state_dict(self):
-        return {"steps": self.steps, "momentum": [None if fg.momentum is None else fg.momentum.clone() for fg in self.flat_groups],
-                "param_groups": [{k: v for k, v in g.items() if k != "params"} for g in self.param_groups]}
 
-    def load_state_dict(self, sd):
-        self.steps = sd["steps"]
-        for fg, m in zip(self.flat_groups, sd["momentum"]):
-            fg.momentum = None if m is None else m.to(fg.data.device).clone()
-
-
-class HipLARS(torch.optim.Optimizer):
+class HipLARS(FlatState, torch.optim.Optimizer):
     """LARS of `extras/delores-s/multi_proc.py:4-43` on flat parameter groups: two launches per group (per-tensor
     norms, then the fused trust-ratio / momentum / update).  `lr_weights` applies to tensors with ndim > 1, `lr_biases`
     to 1-D tensors (the reference's two param groups, `adjust_learning_rate` :45-57)."""
@@ -124,11 +153,13 @@ class HipLARS(torch.optim.Optimizer):
                 p.grad = None
 
 
-class HipLARC(torch.optim.Optimizer):
+class HipLARC(FlatState, torch.optim.Optimizer):
     """apex `LARC(torch.optim.SGD(params, lr, momentum=0.9, weight_decay=wd), trust_coefficient=0.001, clip=False)` -
     the optimiser of `extras/decar-v2/main.py:92-97, 111` - on flat parameter groups: two launches per group (per-tensor
     norms, fused adaptive-rate / decay / momentum / update).  `skip` = indices of tensors without a gradient this step (the
     reference sets `p.grad = None` for the prototypes while they are frozen: neither LARC nor SGD touches them)."""
+
+    supports_skip = True           # step(skip=...) exists (torch wraps `step`, so its signature cannot be inspected through the instance)
 
     def __init__(self, flat_groups, params, lr, momentum=0.9, weight_decay=0.0, trust_coefficient=0.001, eps=1e-8, clip=False):
         super().__init__(params, dict(lr=lr, momentum=momentum, weight_decay=weight_decay, trust_coefficient=trust_coefficient,
@@ -213,9 +244,10 @@ def dcv2_lr_schedule(base_lr, final_lr, epochs, niter_per_ep, warmup_epochs=10):
     return np.concatenate((warm, cos))
 
 
-class HipAdamW(torch.optim.Optimizer):
+class HipAdamW(FlatState, torch.optim.Optimizer):
     """torch.optim.AdamW (`extras/mast_new/mast/moco_model.py:373-379`) as one launch per flat parameter group.  The step
     count lives in device memory and is advanced by a device op, so the optimiser step can sit inside a captured hipGraph."""
+    state_buffers = ("exp_avg", "exp_avg_sq")
 
     def __init__(self, flat_groups, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2, grad_scale=1.0):
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))

@@ -15,8 +15,8 @@ What the reference does per rank and what is done here:
   * per epoch: distributed spherical k-means over the memory bank (`cluster_memory`), then the prototype cross-entropy steps
     (`train`, `main.py:198-292`) with the prototype gradients dropped while it < freeze_prototypes_niters.
   * rank 0 writes `{'epoch', 'state_dict', 'optimizer'}` per epoch (`main.py:172-180`), every rank its memory bank.
-Data: a DistributedSampler-style contiguous shard of the CSV per rank; every batch is (dataset indices, [view1, view2]) with
-the two views produced on the GPU by `UpstreamFrontEnd` (log-mel + RunningNorm + MixupBYOLA + RandomResizeCrop).
+Data: `DistributedSampler`'s share of the CSV per rank (seeded permutation per epoch, strided over the ranks, `ShardedBatches`);
+every batch is (dataset indices, [view1, view2]) with the two views produced on the GPU by `UpstreamFrontEnd` (log-mel + RunningNorm + MixupBYOLA + RandomResizeCrop).
 """
 import argparse
 import os
@@ -45,19 +45,39 @@ def _world():
 
 
 class ShardedBatches:
-    """(indices, waveform batch) over this rank's contiguous shard, drop_last; waveforms come from `get_wave(i)`."""
+    """(indices, waveform batch) over this rank's share of the data set, drop_last; waveforms come from `get_wave(i)`.
+    The share is `torch.utils.data.DistributedSampler(dataset)`'s (`extras/decar-v2/main.py:102`, shuffle=True, seed 0): a
+    permutation of all items drawn from a generator seeded with seed + epoch (`sampler.set_epoch(epoch)`, `:158`), padded by
+    wrapping to a multiple of the world size, rank r taking positions r, r + world, ...  - so every rank sees a fresh, unbiased
+    subset every epoch instead of one fixed contiguous slice of the CSV in file order.  shuffle=False: strided, file order."""
 
-    def __init__(self, n_items, batch, get_wave, rank, world):
-        per = n_items // world
-        self.idx = np.arange(rank * per, (rank + 1) * per)
-        self.batch, self.get = batch, get_wave
+    def __init__(self, n_items, batch, get_wave, rank, world, shuffle=True, seed=0):
+        self.n, self.batch, self.get, self.rank, self.world = n_items, batch, get_wave, rank, world
+        self.shuffle, self.seed, self.epoch = shuffle, seed, 0
+        self.per = -(-n_items // world)                               # ceil, as DistributedSampler without drop_last
+
+    def set_epoch(self, epoch):
+        self.epoch = int(epoch)
+
+    def indices(self):
+        if self.shuffle:
+            g = torch.Generator()
+            g.manual_seed(self.seed + self.epoch)
+            idx = torch.randperm(self.n, generator=g).tolist()
+        else:
+            idx = list(range(self.n))
+        total = self.per * self.world
+        if total > len(idx):
+            idx += (idx * -(-(total - len(idx)) // len(idx)))[:total - len(idx)]
+        return np.asarray(idx[self.rank:total:self.world], dtype=np.int64)
 
     def __len__(self):
-        return len(self.idx) // self.batch
+        return self.per // self.batch
 
     def __iter__(self):
+        idx = self.indices()
         for b in range(len(self)):
-            ids = self.idx[b * self.batch:(b + 1) * self.batch]
+            ids = idx[b * self.batch:(b + 1) * self.batch]
             yield torch.from_numpy(ids), torch.stack([self.get(int(i)) for i in ids])
 
 
@@ -84,6 +104,7 @@ def run(args, n_items, get_wave, front_end, device=None, max_iters=None, log=pri
     init_memory(state, loader())
     history = []
     for epoch in range(args.epochs):
+        batches.set_epoch(epoch)                                      # main.py:158
         assignments = cluster_epoch(state, n_items, tuple(args.nmb_prototypes), args.nmb_kmeans_iters, tuple(args.crops_for_assign))
         start = 0
         for i, (ids, inputs) in enumerate(loader()):

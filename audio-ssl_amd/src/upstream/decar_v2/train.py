@@ -80,7 +80,7 @@ def train_step(state, idx, inputs, assignments, start_idx, nmb_crops=(1,), crops
         state.optimizer.grad_scale = 1.0 / dist.get_world_size()
     # "cancel some gradients": the reference sets p.grad = None for the prototypes, so neither LARC nor SGD touches them
     skip = [i for i, n in enumerate(flat.names) if "prototypes" in n] if state.iteration < freeze_prototypes_niters else []
-    if hasattr(state.optimizer, "step") and "skip" in state.optimizer.step.__code__.co_varnames:
+    if getattr(state.optimizer, "supports_skip", False):         # HipLARC: the kernel leaves flagged tensors and their momentum alone
         state.optimizer.step(skip=skip)
     else:
         frozen = [(i, flat.params[i].data.clone()) for i in skip]

@@ -263,6 +263,11 @@ class Upstream_Expert(MocoQueueMixin, FusedExpertMixin, UpstreamModule):
             total = R.phase("encoder_bwd", backward_phase)
             if early_box[0] is not None and not E.ONE_STREAM and _SGD_ASIDE:
                 main.wait_stream(early_box[0])
+            elif dy_event is not None:
+                # main has only waited for the event recorded BEFORE the heads' deferred weight-gradient GEMMs; without an early
+                # head-segment SGD on their stream (eager training_step, optimiser without step_tail, first graph step: no
+                # momentum yet) nothing else joins them before publish_grads / opt.step() read p1-p3's gradients
+                main.wait_stream(streams[0])
             self.reduce_begin("enc")
         else:
             total = loss.sum()

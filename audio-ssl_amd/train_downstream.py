@@ -90,6 +90,22 @@ class ProbeTrainer:
         return dict(epoch=epoch, loss=losses, accuracy=accuracy)
 
 
+def sync_replicas(model, world=None):
+    """What `DistributedDataParallel(model)` + `nn.SyncBatchNorm.convert_sync_batchnorm` give the reference
+    (`train_downstream.py:80-85`): every parameter and buffer of the model becomes rank 0's (the random `final` Linear - and the
+    encoder when no checkpoint is loaded - would otherwise differ per rank and only the gradients are all-reduced), and every
+    train-mode BatchNorm of the encoder normalises with the statistics of the GLOBAL batch (`engine.SyncBN`).  No-op on one rank."""
+    from src import engine as E
+    if world is None:
+        world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+    E.set_sync_bn(E.SyncBN() if world > 1 else None)
+    if world > 1:
+        with torch.no_grad():
+            for t in list(model.parameters()) + list(model.buffers()):
+                dist.broadcast(t.data, src=0)
+    return model
+
+
 def main(args):
     cfg_path = args.config or os.path.join(HERE, "src", "downstream", "downstream_config.yaml")
     with open(cfg_path, "r") as f:
@@ -122,6 +138,7 @@ def main(args):
         freeze_encoder(model)
     if args.checkpoint is not None:
         load_pretrained_encoder(model, args)
+    sync_replicas(model, world)                                   # DDP's rank-0 broadcast + SyncBatchNorm (reference :80-85)
     trainer = ProbeTrainer(model, config["run"]["lr"])
     test_accuracy, history = [], []
     for epoch in range(config["run"]["epochs"]):
@@ -137,6 +154,9 @@ def main(args):
             history.append(stats)
     if rank == 0:
         print("max valid accuracy : {}".format(max(test_accuracy)))
+    if world > 1:
+        from src import engine as E
+        E.set_sync_bn(None)
     return trainer, history
 
 

@@ -28,6 +28,7 @@ if HERE not in sys.path:
 
 from src.augmentations import AugmentationModule  # noqa: E402
 from src.dataset import BaselineDataModule  # noqa: E402
+from src.optim import FlatState  # noqa: E402
 
 
 class HipTrainer:
@@ -72,12 +73,20 @@ class HipTrainer:
             ck = torch.load(self.resume, map_location=dev, weights_only=True)
             model.load_state_dict(ck["state_dict"], strict=False)
             self.epoch, self.global_step = ck.get("epoch", 0), ck.get("global_step", 0)
-            # Lightning's resume_from_checkpoint restores the optimiser too (SGD momentum lives in FlatGroup.momentum here)
-            states = ck.get("optimizer_states")
+            # Lightning's resume_from_checkpoint restores the optimiser too.  The flat optimisers keep their state in FlatGroup
+            # buffers under their own schema (key `hip_optimizer_states`); a reference / Lightning checkpoint carries torch's
+            # per-parameter schema under `optimizer_states`: its weights load, its optimiser state is declined with a warning
+            states = ck.get("hip_optimizer_states") or ck.get("optimizer_states")
             if states and hasattr(opt, "load_state_dict"):
                 if hasattr(model, "ensure_flat"):
                     model.ensure_flat()
-                opt.load_state_dict(states[0])
+                if isinstance(opt, FlatState):
+                    opt.load_state_dict(states[0])
+                else:
+                    try:
+                        opt.load_state_dict(states[0])
+                    except (KeyError, ValueError) as e:
+                        print(f"optimiser state of the checkpoint not restored ({e!r}); fresh optimiser state")
         best = float("inf")
         # one rank: the step is a single hipGraph replay; data-parallel: one graph per collective-free phase
         gstep = None
@@ -135,7 +144,9 @@ class HipTrainer:
         ck["hyper_parameters"]["base_encoder"] = model.config["pretrain"]["base_encoder"]["type"]
         opt = getattr(self, "optimizer", None)
         if opt is not None and hasattr(opt, "state_dict"):
-            ck["optimizer_states"] = [opt.state_dict()]          # Lightning's key; a list with one entry per optimiser
+            # a list with one entry per optimiser, like Lightning's `optimizer_states`, but under a key of its own: the flat
+            # optimisers' schema is not torch's, and a Lightning loader must not mistake one for the other
+            ck["hip_optimizer_states" if isinstance(opt, FlatState) else "optimizer_states"] = [opt.state_dict()]
         torch.save(ck, path)
 
 

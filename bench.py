@@ -107,67 +107,111 @@ def _work(entry, a):
     return None
 
 
+GEMM_SYMBOL = {(0, 0): "NT", (0, 1): "NN", (1, 1): "TN", (1, 0): "TT"}
+# C-ABI entry -> substring of the kernel name rocprofv3 prints for it (profiles/*kernel_stats.csv); the GEMM family is resolved
+# at run time (audiossl_last_kernel: the dispatch picks among several instantiations), everything else launches <entry>_kernel
+SYMBOLS = {"sgd_momentum": ["sgd_kernel"], "conv3x3_fwd": ["conv3x3_ws_kernel"], "conv3x3_wgrad": ["conv3x3_wgrad_kernel", "wgrad_reduce_kernel"],
+           "conv1_fwd": ["conv1_fwd_mfma_kernel"], "conv1_bwd": ["conv1_bwd_mfma_kernel", "conv1_bwd_finalize_kernel"],
+           "conv1_stats": ["conv1_moments_kernel", "conv1_finalize_kernel"], "logmel_fwd": ["logmel2_kernel"], "ema_update": ["ema_kernel"],
+           "bn_relu_pool_bwd": ["bn_relu_pool_bwd_kernel"], "cast": ["cast_kernel"]}
+
+
+def _symbols(entry):
+    base = entry.split("[")[0]
+    return SYMBOLS.get(base, [base + "_kernel"])
+
+
 def per_kernel_report(prof, prof_steps, step_ms):
-    """-> (list of per-entry-point rows sorted by time, the GEMM groups).  Durations are HIP events around each C-ABI call on
-    the stream it was issued on, during an eager re-issue of the step; rocprofv3 --kernel-trace --stats of the same command
-    (profiles/) is the cross-check."""
-    rows, gemm_groups = {}, {}
+    """-> list of rows sorted by time.  One row per C-ABI entry point (GEMM family: per entry, operand layout AND kernel the
+    dispatch picked), each with the kernel symbols that join it to rocprofv3's kernel_stats.csv.  Durations are HIP events around
+    each call on the stream it was issued on, during an eager re-issue of the step."""
+    rows = {}
     for full, recs in prof.items():
         entry = full[len("audiossl_"):]
         for e0, e1, a, note in recs:
             sec = e0.elapsed_time(e1) * 1e-3
+            sym = None
+            if isinstance(note, tuple):
+                note, sym = note
             w = _work(entry, a)
-            if entry == "gemm_multi" and note:
-                w = ("mfma", note, 1)
             key = entry
             if entry == "gemm":
                 key = f"gemm<{'bf16' if a[0] else 'f32'},{GEMM_SYMBOL[(a[1], a[2])]}>"
-                g = gemm_groups.setdefault((a[0], a[1], a[2]), [0.0, 0.0, 0])
-                g[0] += sec; g[1] += 2.0 * a[3] * a[4] * a[5]; g[2] += 1
+            elif entry == "gemm_multi":
+                key = f"gemm_multi<{GEMM_SYMBOL[(a[1], a[2])]}>"
+                w = ("mfma", note, 1) if note else None
+            elif entry == "gemm_multi_barlow":
+                w = ("mfma", note, 1) if note else None
+            elif entry == "moco_logits":                      # (mode, B, K, dim, 1/T, gscale)
+                key = f"moco_logits[mode={a[0]}]"
+                w = ("mfma", 2.0 * a[1] * a[2] * a[3], 1)
             elif entry in ("conv3x3_fwd", "bn_relu_pool_fwd", "bn_relu_pool_train_fwd", "bn_relu_pool_bwd", "conv3x3_wgrad", "tmean_fwd"):
                 key = f"{entry}[F={a[-1]}]"
-            r = rows.setdefault(key, {"sec": 0.0, "work": 0.0, "n": 0, "bound": None, "dt": 0})
+            syms = [sym] if sym else _symbols(entry)
+            r = rows.setdefault((key, tuple(syms)), {"sec": 0.0, "work": 0.0, "n": 0, "bound": None, "dt": 0})
             r["sec"] += sec; r["n"] += 1
             if w is not None:
                 r["bound"], r["dt"] = w[0], w[2]
                 r["work"] += w[1]
     out = []
-    for key, r in sorted(rows.items(), key=lambda kv: -kv[1]["sec"]):
-        row = {"entry": key, "launches_per_step": round(r["n"] / prof_steps, 2), "avg_us": round(r["sec"] / r["n"] * 1e6, 2),
-               "share_of_step": round(r["sec"] / prof_steps / (step_ms * 1e-3), 4)}
+    for (key, syms), r in sorted(rows.items(), key=lambda kv: -kv[1]["sec"]):
+        row = {"entry": key, "kernel_symbols": list(syms), "launches_per_step": round(r["n"] / prof_steps, 2),
+               "avg_us": round(r["sec"] / r["n"] * 1e6, 2), "share_of_step": round(r["sec"] / prof_steps / (step_ms * 1e-3), 4)}
         if r["bound"] == "hbm" and r["sec"] > 0:
             ach = r["work"] / r["sec"] / 1e9
-            row.update(bound="hbm", achieved=round(ach, 1), unit="GB/s", frac=round(ach / PEAK_HBM_GBS, 4))
+            row.update(bound="hbm", achieved=round(ach, 1), unit="GB/s", frac=round(ach / PEAK_HBM_GBS, 4), peak=PEAK_HBM_GBS,
+                       work_per_launch=r["work"] / r["n"])
         elif r["bound"] == "mfma" and r["sec"] > 0:
             ach = r["work"] / r["sec"] / 1e12
-            row.update(bound="mfma", achieved=round(ach, 1), unit="TFLOP/s", frac=round(ach / PEAK_TFLOPS[r["dt"]], 4))
+            row.update(bound="mfma", achieved=round(ach, 1), unit="TFLOP/s", frac=round(ach / PEAK_TFLOPS[r["dt"]], 4),
+                       peak=PEAK_TFLOPS[r["dt"]], work_per_launch=r["work"] / r["n"])
         out.append(row)
-    return out, gemm_groups
-GEMM_SYMBOL = {(0, 0): "NT", (0, 1): "NN", (1, 1): "TN", (1, 0): "TT"}
+    return out
 
 
-def pmc_traffic(ta, tb):
-    """HBM bytes per launch of the bf16 GEMM instantiations with these transposes, from the committed PMC passes
-    (profiles/r02_pmc_traffic.json, made by tools/pmc_summary.py; counters cannot be read live from inside the process)."""
+def _latest_profile(suffix):
+    """newest committed profiles/rNN_<suffix> (by round number), or None"""
+    import glob
     import re
-    path = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
-    if not os.path.exists(path):
-        path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
-    if not os.path.exists(path):
+    best = None
+    for path in glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_" + suffix)):
+        n = int(re.match(r"r(\d+)_", os.path.basename(path)).group(1))
+        if best is None or n > best[0]:
+            best = (n, path)
+    return best[1] if best else None
+
+
+def in_graph_stats(symbols):
+    """(avg ns, calls, csv path, name of the CSV's top row) of the kernels whose rocprofv3 name contains one of `symbols`, from the
+    committed `rocprofv3 --kernel-trace --stats` summary of this same command (graph replays: kernels of different branches of
+    the step share the machine there, so these averages are longer than the isolated HIP-event ones)."""
+    import csv
+    path = _latest_profile("bench_b512_kernel_stats.csv")
+    if path is None:
+        return None
+    tot, calls, top = 0.0, 0, None
+    with open(path, newline="") as f:
+        for rec in csv.DictReader(f):
+            if top is None:
+                top = rec["Name"]
+            if any(sy in rec["Name"] for sy in symbols):
+                tot += float(rec["TotalDurationNs"]); calls += int(rec["Calls"])
+    return (tot / calls if calls else None, calls, os.path.relpath(path, ROOT), top)
+
+
+def pmc_traffic(symbols):
+    """HBM bytes (read + written) per launch of the kernels named by `symbols`, from the committed PMC passes
+    (profiles/rNN_pmc_traffic.json, made by tools/pmc_summary.py from separate --pmc FETCH_SIZE / WRITE_SIZE runs of this
+    command, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes; counters cannot be read live from inside the process)."""
+    path = _latest_profile("pmc_traffic.json")
+    if path is None:
         return None
     tot, n = 0.0, 0
     for name, v in json.load(open(path))["kernels"].items():
-        if not any(k in name for k in ("gemm_kernel", "gemm_ring_kernel", "gemm_bk32_kernel", "gemm_p8_kernel")) or v["read_bytes_per_launch"] is None:
+        if v.get("read_bytes_per_launch") is None or not any(sy in name for sy in symbols):
             continue
-        m = (re.search(r"gemm_kernelIDF16bLb(\d)ELb(\d)ELi\d+E", name) or re.search(r"gemm_ring_kernelILb(\d)ELb(\d)ELi\d+E", name)
-             or re.search(r"gemm_bk32_kernelILb(\d)ELb(\d)E", name) or re.search(r"gemm_p8_kernelILb(\d)ELb(\d)E", name))
-        key = (int(m.group(1)), int(m.group(2))) if m else ((1, 1) if re.search(r"E, true, \d+(, \d+)*>", name) else None)
-        d = re.search(r"gemm_(?:ring|bk32)_kernel<(false|true), (false|true)", name)    # demangled form of the ring / BK=32 kernels
-        if d:
-            key = (int(d.group(1) == "true"), int(d.group(2) == "true"))
-        if key == (ta, tb):
-            tot += (v["read_bytes_per_launch"] + (v["write_bytes_per_launch"] or 0)) * v["launches"]
-            n += v["launches"]
+        tot += (v["read_bytes_per_launch"] + (v["write_bytes_per_launch"] or 0)) * v["launches"]
+        n += v["launches"]
     return round(tot / n) if n else None
 
 
@@ -272,6 +316,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="issue the step kernel by kernel instead of replaying the hipGraph")
     ap.add_argument("--graph-phases", action="store_true", help="single rank: use the data-parallel variant (one graph per phase)")
+    ap.add_argument("--h2d", action="store_true", help="upload a fresh pinned host batch (B x 16000 fp32) every step on a copy stream, "
+                    "two batches ahead of the training step, instead of re-using the batch resident in HBM (reported as "
+                    "`h2d`; the contract's `value` is measured without it)")
     args = ap.parse_args()
 
     rank, world = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
@@ -284,9 +331,14 @@ def main():
         local = 0                                                  # cuda:0, gloo transport (RCCL refuses two ranks per device)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
+    rccl = None
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(os.environ.get("AUDIOSSL_DIST_BACKEND", "nccl"), rank=rank, world_size=world)
+        backend = os.environ.get("AUDIOSSL_DIST_BACKEND", "nccl")
+        dist.init_process_group(backend, rank=rank, world_size=world)
+        ones = torch.ones(1, device=dev)
+        dist.all_reduce(ones)                                       # every rank answers: the collective layer is alive
+        rccl = {"backend": "rccl (torch 'nccl')" if backend == "nccl" else backend, "ranks_in_all_reduce": int(ones.item())}
 
     from src import _native as N
     from src.augmentations import AugmentationModule
@@ -312,13 +364,46 @@ def main():
     # data-parallel ranks replay one graph per collective-free phase with the RCCL calls in between.
     gstep = None if args.no_graph else model.graphed_step(opt, phases=args.graph_phases)
 
-    ticket = [front.submit(waves)]
+    # --h2d: the loader's side of the boundary - a pinned host batch per step, uploaded on a copy stream two batches ahead of the
+    # training step that consumes it (ring of three device buffers), the front end waits for the upload's event only
+    if args.h2d:
+        host = [torch.from_numpy(synth_waves(B, 16000, 1234 + rank + 7 * j)).pin_memory() for j in range(3)]
+        ring = [torch.empty(B, 16000, device=dev) for _ in range(3)]
+        copy_stream = torch.cuda.Stream(device=dev)
+        uploads, fe_done = {}, {}
+
+        def upload(j):
+            if j - 3 in fe_done:
+                copy_stream.wait_event(fe_done.pop(j - 3))                # the buffer's previous reader: the front end of batch j - 3
+            with torch.cuda.stream(copy_stream):
+                ring[j % 3].copy_(host[j % 3], non_blocking=True)
+                ev = torch.cuda.Event()
+                ev.record()
+            uploads[j] = ev
+
+        def submit_next(j):
+            t = front.submit(ring[j % 3], after=uploads.pop(j))
+            fe_done[j] = t[1]
+            upload(j + 2)
+            return t
+        upload(0); upload(1)
+        nxt = [0]
+    else:
+        def submit_next(j):
+            return front.submit(waves)
+        nxt = [0]
+
+    def next_ticket():
+        t = submit_next(nxt[0])
+        nxt[0] += 1
+        return t
+    ticket = [next_ticket()]
 
     def step(i):
         # the front end of the NEXT batch is submitted (own stream) before this batch's training step is launched, so it
         # runs underneath it; every call does exactly one front end and one training step
         img_1, img_2 = front.collect(ticket[0])
-        ticket[0] = front.submit(waves)
+        ticket[0] = next_ticket()
         if gstep is not None:
             return gstep(img_1, img_2)
         opt.zero_grad()
@@ -356,7 +441,7 @@ def main():
         prof_steps = min(args.steps, 5)
         for i in range(prof_steps):
             img_1, img_2 = front.collect(ticket[0])
-            ticket[0] = front.submit(waves)
+            ticket[0] = next_ticket()
             gstep._eager(img_1, img_2)
         torch.cuda.synchronize()
     else:
@@ -372,18 +457,27 @@ def main():
     if rank != 0:
         return
 
-    # ---- per-kernel roofline (north_star: GB/s for the mel / augment kernels, TFLOP/s for the encoder GEMMs) and the
-    #      headline `roofline` object = the dominant GEMM instantiation group (largest total time)
-    per_kernel, groups = per_kernel_report(prof, prof_steps, dt / args.steps * 1e3)
-    (dtype, ta, tb), (tsec, flops, launches) = max(groups.items(), key=lambda kv: kv[1][0])
-    achieved = flops / tsec / 1e12
-    roofline = {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_TFLOPS[dtype], "unit": "TFLOP/s",
-                "frac": round(achieved / PEAK_TFLOPS[dtype], 4), "traffic": pmc_traffic(ta, tb) if dtype == 1 else None,
-                "kernel": f"gemm_kernel<{'bf16' if dtype else 'f32'},{GEMM_SYMBOL[(ta, tb)]}>", "launches_per_step": launches / prof_steps,
-                "avg_launch_us": round(tsec / launches * 1e6, 2), "flop_per_launch": flops / launches,
-                "share_of_step": round(tsec / prof_steps / (dt / args.steps), 3),
-                "timed_on": "eager re-issue of the step after the timed region" if gstep is not None else "the timed region",
-                "per_kernel": per_kernel[:28]}
+    # ---- per-kernel roofline (north_star: GB/s for the mel / augment kernels, TFLOP/s for the encoder GEMMs); the headline
+    #      `roofline` object = the row with the largest share of the step (the dominant kernel), named by its rocprofv3 symbol
+    per_kernel = per_kernel_report(prof, prof_steps, dt / args.steps * 1e3)
+    top = next(r for r in per_kernel if r.get("bound"))
+    roofline = {"bound": top["bound"], "achieved": top["achieved"], "peak": top["peak"], "unit": top["unit"], "frac": top["frac"],
+                "traffic": pmc_traffic(top["kernel_symbols"]), "kernel": top["kernel_symbols"][0], "entry": top["entry"],
+                "launches_per_step": top["launches_per_step"], "avg_launch_us": top["avg_us"],
+                "work_per_launch": top["work_per_launch"], "share_of_step": top["share_of_step"],
+                "timed_on": "eager re-issue of the step after the timed region" if gstep is not None else "the timed region"}
+    ig = in_graph_stats(top["kernel_symbols"])
+    if ig is not None and ig[0]:
+        # the same algorithmic work over the average duration rocprofv3 saw for this kernel INSIDE the replayed graph
+        per_s = top["work_per_launch"] / (ig[0] * 1e-9)
+        roofline.update(frac_in_graph=round(per_s / (top["peak"] * (1e12 if top["bound"] == "mfma" else 1e9)), 4),
+                        in_graph_avg_us=round(ig[0] * 1e-3, 2), in_graph_source=ig[2], profile_top_kernel=ig[3])
+        if not any(sy in ig[3] for sy in top["kernel_symbols"]):
+            print(f"[bench] note: the committed profile's top kernel is {ig[3][:90]}, this run's is {top['kernel_symbols']}",
+                  file=sys.stderr)
+    for r in per_kernel:
+        r.pop("peak", None)
+    roofline["per_kernel"] = per_kernel[:32]
     out = {"metric": "upstream clips/sec (1s@16kHz, 64-mel)", "value": round(B * world * args.steps / dt, 1), "unit": "clips/s",
            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16" if args.precision.startswith("bf16") else "f32",
@@ -392,13 +486,21 @@ def main():
                                   f"1 s @ 16 kHz, 64 mel, batch {B}/GPU, queue {args.queue}", "global_batch": B * world,
                       "parallelism": f"dp{world}"},
            "final_loss": final_loss, "roofline": roofline}
+    if gstep is not None:
+        ph = gstep.phases
+        out["graph_mode"] = ({"mode": "one hipGraph per collective-free phase", "phases": sorted(ph.graphs), "eager_fallback": ph.broken}
+                             if gstep.use_phases and ph is not None else {"mode": "single hipGraph"})
+    else:
+        out["graph_mode"] = {"mode": "eager"}
+    if rccl is not None:
+        out["collectives"] = rccl
+    if args.h2d:
+        out["h2d"] = {"bytes_per_step": B * 16000 * 4, "pinned": True, "prefetch_batches": 2}
     if world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args.cpu_batch, args.cpu_steps, args.queue)
     else:
         out["cpu_baseline"] = None
     print(json.dumps(out))
-    if world > 1:
-        pass
 
 
 if __name__ == "__main__":

@@ -293,6 +293,11 @@ int audiossl_ema_update(float* pk, const float* pq, long n, float m, void* shado
 /* Host-side switch: 1 = every scratch pointer handed to the entry points below is already zero (the caller cleared its whole
  * scratch arena with one memset), so they skip their own hipMemsetAsync; 0 (default) = they zero their scratch themselves. */
 int audiossl_set_prezeroed(int on);
+/* Host-side query (diagnostics): the kernel the most recent audiossl_gemm / gemm_multi / gemm_multi_barlow / moco_logits call
+ * launched, as a substring of the name rocprofv3 prints for it ("gemm_p6_multi_kernel<false, false>"; instantiations on the bf16
+ * type appear mangled there: "gemm_multi_kernelIDF16bLb0ELb0ELi64ELi2ELi4E").  The dispatch picks among several instantiations
+ * by shape; bench.py's per-kernel roofline table uses this to join its rows to profiles/ kernel_stats.csv. */
+int audiossl_last_kernel(char* name, int capacity);
 
 /* ---- K17 optimiser + plumbing: delores_s/upstream_expert.py:236-243 (torch.optim.SGD) ---------------------- */
 /* sgd_momentum: optional tail work of the same pass - shadow_bf16 (nullable): bf16 copy of the updated parameters (what

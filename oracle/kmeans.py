@@ -3,8 +3,10 @@
 CPU restatement of `extras/decar-v2/utils.py:276-346` (cluster_memory) for one head / one crop: E step
 `mm(mem, centroids.t()).max(1)`, M step per-cluster sum (the reference goes through scipy csr_matrix on the CPU),
 optional all-reduce hooks, `centroids[mask] = sums[mask] / counts[mask]` (empty clusters keep their centroid),
-`F.normalize`.  The reference function itself calls `.cuda()` and cannot run here: parity of this file is by reading,
-its collective logic is exercised with gloo in tests/test_distributed_cpu.py."""
+`F.normalize`.  PINNED (round 3): tests/golden/kmeans_ref.npz holds the outputs of the reference function itself, run on the CPU
+by tests/golden/make_goldens.py g16 (no-op `.cuda`, 1-process gloo group) - seeds, centroids after every iteration, assignments,
+an empty-cluster case; tests/test_oracle_golden.py checks this file against it.  The collective logic is exercised with gloo in
+tests/test_distributed_cpu.py."""
 import torch
 import torch.nn.functional as F
 

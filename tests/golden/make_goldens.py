@@ -589,6 +589,62 @@ def g15_mvit_block():
     save("mvit_block", **out)
 
 
+def g16_kmeans():
+    """The reference's own `cluster_memory` (extras/decar-v2/utils.py:276-346) on the CPU.  It is plain torch + scipy, but written
+    for a GPU rank: it calls `.cuda(non_blocking=True)` on fresh tensors and uses the process group.  Here: `torch.Tensor.cuda`
+    is a no-op for the duration of the call, the group is the 1-process gloo group the reference's own trainers create
+    (extras/delores-m/train_moco.py:18), `tensorflow` / `librosa` (imported at module level by utils.py, unused by this
+    function) are empty stand-in modules, and `nn.functional.normalize` is wrapped to record the centroids after every M step.
+    Case A: N = 4096 clips in a 4160-item data set, d = 64, K = 32, 10 iterations, a noisy mixture around 40 directions.
+    Case B: an empty-cluster case - 512 rows that are copies of 20 distinct directions, K = 32: duplicate seeds lose every
+    arg-max tie and keep their centroid (`centroids[mask] = ...`)."""
+    import socket
+    import torch.distributed as dist
+    sys.modules.setdefault("tensorflow", types.ModuleType("tensorflow"))
+    sys.modules.setdefault("librosa", types.ModuleType("librosa"))
+    U = _load_by_path("ref_decar_utils", os.path.join(REF, "extras/decar-v2/utils.py"))
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1)
+    real_cuda, real_nn = torch.Tensor.cuda, U.nn
+    trace = []
+
+    def rec_normalize(x, *a, **k):
+        y = real_nn.functional.normalize(x, *a, **k)
+        trace.append(y.clone())
+        return y
+    out = {}
+    try:
+        torch.Tensor.cuda = lambda self, *a, **k: self
+        U.nn = types.SimpleNamespace(functional=types.SimpleNamespace(normalize=rec_normalize))
+        for case, (N, size_dataset, d, K, iters, seed) in {"a": (4096, 4160, 64, 32, 10, 1234), "b": (512, 512, 16, 32, 4, 99)}.items():
+            if case == "a":
+                centres = fill.normalish((40, d), 1601)
+                x = centres[np.arange(N) % 40] + 0.45 * fill.normalish((N, d), 1602)
+            else:
+                x = fill.normalish((20, d), 1603)[(7 * np.arange(N)) % 20]
+            mem = torch.nn.functional.normalize(torch.from_numpy(x.astype(np.float32)), dim=1)
+            index = torch.from_numpy(((np.arange(N) * 37 + 11) % size_dataset).astype(np.int64))       # 37 is coprime to both sizes
+            assert len(set(index.tolist())) == N
+            proto = nn.Linear(d, K, bias=False)
+            model = types.SimpleNamespace(module=types.SimpleNamespace(prototypes=types.SimpleNamespace(prototypes0=proto)))
+            args = types.SimpleNamespace(nmb_prototypes=[K], feat_dim=d, rank=0, world_size=1, crops_for_assign=[0])
+            torch.manual_seed(seed)
+            seed_idx = torch.randperm(N)[:K]                            # the function's first draw from the global generator
+            torch.manual_seed(seed)
+            del trace[:]
+            assign = U.cluster_memory(args, model, index, mem[None].clone(), size_dataset, nmb_kmeans_iters=iters)
+            assert len(trace) == iters and torch.equal(trace[-1], proto.weight.detach())
+            out.update({f"{case}.mem": t2n(mem), f"{case}.index": t2n(index), f"{case}.seed_idx": t2n(seed_idx),
+                        f"{case}.centroids": np.stack([t2n(c) for c in trace]), f"{case}.assignments": t2n(assign[0]),
+                        f"{case}.dims": np.array([N, size_dataset, d, K, iters, seed])})
+    finally:
+        torch.Tensor.cuda, U.nn = real_cuda, real_nn
+        dist.destroy_process_group()
+    counts_b = np.bincount(out["b.assignments"][out["b.assignments"] >= 0], minlength=32)
+    assert (counts_b == 0).sum() >= 12, counts_b                        # case B really has empty clusters
+    save("kmeans_ref", **out)
+
+
 def main():
     _install_shims()
     sys.path.insert(0, REF)
@@ -617,6 +673,9 @@ def main():
     if len(sys.argv) > 1 and sys.argv[1] == "mvit":
         g15_mvit_block()
         return
+    if len(sys.argv) > 1 and sys.argv[1] == "kmeans":
+        g16_kmeans()
+        return
     g1_window(U)
     g2_runnorm(A)
     g3_aug(A_pkg)
@@ -632,6 +691,7 @@ def main():
     g13_schedules(MP)
     g14_kmix(A)
     g15_mvit_block()
+    g16_kmeans()
 
 
 if __name__ == "__main__":

@@ -146,7 +146,7 @@ def _worker_decar(rank, world, port, ret):
 
 
 def test_two_rank_deepcluster_v2_harness_keeps_replicas_identical():
-    """BASELINE config 3 plumbing at world size 2 (`extras/decar-v2/main.py:57-292`): contiguous shards, distributed k-means
+    """BASELINE config 3 plumbing at world size 2 (`extras/decar-v2/main.py:57-292`): DistributedSampler shards, distributed k-means
     (centroids broadcast, counts / sums all-reduced), prototype cross-entropy, ONE flat-gradient all-reduce, LARC, the
     warm-up learning-rate schedule - the two replicas end bit-identical, local losses differ, prototypes stay the centroids."""
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
@@ -158,7 +158,10 @@ def test_two_rank_deepcluster_v2_harness_keeps_replicas_identical():
     assert r0["losses"] != r1["losses"]
     for n in r0["w"]:
         np.testing.assert_array_equal(r0["w"][n], r1["w"][n], err_msg=n)
-    assert r0["shard"].tolist()[:48] == list(range(48)) and r1["shard"].tolist()[:48] == list(range(64, 112))   # 3 x 16 clips each
+    from torch.utils.data.distributed import DistributedSampler
+    for r, got in ((0, r0), (1, r1)):                               # 3 x 16 clips each, DistributedSampler's share at epoch 0
+        want = list(DistributedSampler(range(128), 2, r, shuffle=True, seed=0))[:48]
+        assert got["shard"].tolist()[:48] == want
     assert 0 < r0["lr"] < 0.3                                       # warm-up value of iteration 2, not base_lr
     np.testing.assert_allclose(np.linalg.norm(r0["w"]["prototypes.prototypes0.weight"], axis=1), 1.0, rtol=1e-4)
 

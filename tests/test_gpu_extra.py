@@ -90,6 +90,35 @@ def test_spherical_kmeans_vs_oracle():
     assert int((out == -100).sum()) == Nn and out[0] >= 0
 
 
+@pytest.mark.parametrize("case", ["a", "b"])
+def test_spherical_kmeans_vs_reference_cluster_memory(golden, case):
+    """The HIP k-means (GEMM + row_argmax E step, kmeans_accumulate / kmeans_update M step) against the fixture produced by the
+    reference's own `cluster_memory` (extras/decar-v2/utils.py:276-346; tests/golden/make_goldens.py g16): seeded exactly like
+    it (`torch.randperm` on the host generator, rank 0), centroids after every iteration, assignments in data-set order >= 99.9 %
+    identical (ties), unseen entries -100, empty clusters keep their centroid (case b)."""
+    from src.upstream.decar_v2.kmeans import cluster_memory, spherical_kmeans
+    g = golden("kmeans_ref")
+    N, size_dataset, d, K, iters, seed = (int(v) for v in g[f"{case}.dims"])
+    mem = torch.from_numpy(g[f"{case}.mem"]).cuda()
+    index = torch.from_numpy(g[f"{case}.index"]).cuda()
+    want_a = torch.from_numpy(g[f"{case}.assignments"])
+    for it in (1, iters):                                        # the centroid trajectory, first and last iteration
+        c, _ = spherical_kmeans(mem, K, it, centroids=mem[torch.from_numpy(g[f"{case}.seed_idx"]).cuda()])
+        np.testing.assert_allclose(c.cpu().numpy(), g[f"{case}.centroids"][it - 1], rtol=2e-5, atol=2e-6)
+    torch.manual_seed(seed)                                      # cluster_memory draws its own seeds, as the reference does
+    out, cent = cluster_memory(mem, index, size_dataset, K, iters)
+    out = out.cpu()
+    assert torch.equal(out == -100, want_a == -100) and int((want_a == -100).sum()) == size_dataset - N
+    assert float((out == want_a).float().mean()) >= 0.999
+    np.testing.assert_allclose(cent.cpu().numpy(), g[f"{case}.centroids"][-1], rtol=2e-5, atol=2e-6)
+    if case == "b":
+        seen = out[out >= 0]
+        empty = np.nonzero(np.bincount(seen.numpy(), minlength=K) == 0)[0]
+        assert len(empty) >= 12
+        seeds = mem[torch.from_numpy(g[f"{case}.seed_idx"]).cuda()].cpu().numpy()
+        np.testing.assert_allclose(cent.cpu().numpy()[empty], seeds[empty], rtol=1e-6, atol=1e-7)
+
+
 def test_prototype_cross_entropy():
     from src.upstream.decar_v2.kmeans import prototype_cross_entropy
     B, K = 96, 1024

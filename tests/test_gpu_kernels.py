@@ -666,6 +666,34 @@ def test_gemm_multi_per_problem_shapes(N):
             assert rel_l2(ca.cpu(), (c0 + 0.5 * r).cpu()) < 1e-5
 
 
+def test_gemm_multi_hand_scheduled_kernels(N):
+    """The multi-problem launches of the grouped Barlow heads at B = 512 (M = 1,024 stacked views) take the hand-scheduled
+    256 x 128 / 256 x 256 kernels behind audiossl_gemm_multi's one-dimensional, XCD-contiguous tile order; per-problem widths
+    2048 / 1024 / 512 as in the first projector layer (forward, data gradient, weight gradient), bf16 and fp32 outputs."""
+    from src import engine as E
+    g = torch.Generator().manual_seed(19)
+    D, M = 2048, 1024
+    cases = [(0, 0, M, [D] * 3, [2048, 1024, 512], 0, 0),        # first layer, forward
+             (0, 0, M, [D] * 3, [D] * 3, 0, 0),                  # layers 2, 3
+             (0, 1, M, [D] * 3, [D] * 3, 1, 0),                  # data gradients
+             (0, 1, M, [2048, 1024, 512], [D] * 3, 1, 0),        # (full-batch form of the last data gradient)
+             (1, 1, D, [D] * 3, [M] * 3, 1, 2),                  # weight gradients, exclusive accumulation
+             (1, 1, D, [2048, 1024, 512], [M] * 3, 1, 0),        # first layer's weight gradient, store-only
+             (1, 1, D, [D] * 3, [512] * 3, 1, 0)]                # cross-correlation
+    for ta, tb, m, Ns, Ks, f32, atomic in cases:
+        As = [(torch.randn((k, m) if ta else (m, k), generator=g) * 0.5).cuda().bfloat16() for k in Ks]
+        Bs = [(torch.randn((k, n) if tb else (n, k), generator=g) * 0.5).cuda().bfloat16() for n, k in zip(Ns, Ks)]
+        C0 = [torch.randn(m, n, generator=g).cuda().to(torch.float32 if f32 else torch.bfloat16) for n in Ns]
+        Cs = [c.clone() for c in C0]
+        E.gemm_multi(ta, tb, m, Ns, Ks, As, [a.shape[1] for a in As], Bs, [b.shape[1] for b in Bs], Cs, Ns, out_f32=f32, atomic=atomic)
+        torch.cuda.synchronize()
+        for a, b, c, c0 in zip(As, Bs, Cs, C0):
+            ref = (a.double().T if ta else a.double()) @ (b.double() if tb else b.double().T)
+            if atomic:
+                ref = ref + c0.double()
+            assert rel_l2(c.double().cpu(), ref.cpu()) < (1e-5 if f32 else 4e-3), (ta, tb, m, Ns, Ks)
+
+
 _VARIANT_SCRIPT = r"""
 import sys, torch
 sys.path[:0] = [{root!r}, {pkg!r}]
@@ -695,6 +723,11 @@ print("WORST", worst)
     ({"AUDIOSSL_GEMM_P8": "1"}, [("NT", 1100, 520, 64), ("NT", 1100, 520, 192), ("NT", 700, 264, 512), ("NN", 1100, 520, 192),
                                  ("NN", 700, 264, 512), ("TN", 1096, 520, 192), ("TN", 696, 264, 512), ("NT", 6144, 2048, 2048),
                                  ("NN", 1024, 2048, 1024), ("TN", 2048, 520, 1024)]),
+    # hand-scheduled 256 x 128 kernel (three buffers): 1, 2, 3, 4 and 7 K-tiles, partial tiles in M and N, the heads' shapes
+    ({"AUDIOSSL_GEMM_P6": "1", "AUDIOSSL_GEMM_P8": "0"},
+     [("NT", 1100, 392, 64), ("NT", 1100, 392, 128), ("NT", 700, 264, 192), ("NT", 520, 136, 256), ("NN", 1100, 392, 192),
+      ("NN", 700, 264, 448), ("TN", 1096, 392, 192), ("TN", 696, 264, 448), ("NT", 1024, 2048, 2048), ("NN", 1024, 2048, 2048),
+      ("TN", 2048, 1024, 1024)]),
 ])
 def test_gemm_tile_variants_in_subprocess(env, shapes):
     """The tile variants that the default dispatch does not pick for these shapes (ring of every layout, 256x256 and 256x128

@@ -436,6 +436,34 @@ def test_delores_m_grouped_heads_match_per_head_path(cfg_m):
         assert rel_l2(g1[n], g0[n]) < 2e-3, n
 
 
+def test_delores_m_eager_step_orders_main_stream_after_the_heads_weight_gradients(cfg_m):
+    """The grouped heads issue their three weight-gradient launches AFTER the event the encoder backward waits for.  Without an
+    early head-segment SGD on the heads' stream (eager `training_step`, optimizer=None) the step itself must join that stream
+    before it returns: a snapshot of p1-p3's gradients queued on the main stream right behind `fused_loss` has to see the
+    final values (it raced with the GEMMs before the join was added - zeros with the store-only weight gradients)."""
+    from src.encoder import AudioNTT2020Task6
+    from src.upstream.delores_m.upstream_expert import Upstream_Expert
+    B, T, Tp, K = 64, 96, 12, 256
+    em = Upstream_Expert(_cfg(cfg_m, "bf16"), base_encoder=AudioNTT2020Task6, num_negatives=K)
+    fill.fill_state_dict_(em, seed=12)
+    for pq, pk in zip(em.encoder_q.parameters(), em.encoder_k.parameters()):
+        pk.data.copy_(pq.data)
+    em.queue.copy_(closed_queue(128, K))
+    em = em.cuda().train()
+    assert em.grouped_heads
+    for rep in range(3):
+        a, b = views(B, T, 8910 + 2 * rep).cuda(), views(B, T, 8911 + 2 * rep).cuda()     # new gradients every repetition
+        em.encoder_q.encoder.dropout_masks.queue = [drop_mask((B, Tp, 2048), 8912)]
+        em.encoder_k.encoder.dropout_masks.queue = [drop_mask((B, Tp, 2048), 8913)]
+        em.fused_loss(a, b, True)                                  # optimizer=None: no early SGD, nothing else joins the heads
+        ho = em.head_offset()
+        snap = em.flat.grad[ho:].clone()                           # queued on the main stream, no host synchronisation in between
+        torch.cuda.synchronize()
+        final = em.flat.grad[ho:]
+        assert float(final.abs().max()) > 0
+        assert torch.equal(snap, final), f"repetition {rep}: the main stream read the head gradients before they were complete"
+
+
 # ------------------------------------------------------------------------------------------------ hipGraph replay
 @pytest.mark.parametrize("which", ["delores_m", "delores_s"])
 def test_graphed_step_matches_eager(cfg_m, cfg_s, which):
@@ -479,6 +507,53 @@ def test_graphed_step_matches_eager(cfg_m, cfg_s, which):
         assert graphed.encoder_q.encoder.dropout_masks.calls == eager.encoder_q.encoder.dropout_masks.calls == steps
     for (n, pe), (_, pg) in zip(eager.named_parameters(), graphed.named_parameters()):
         assert rel_l2(pg.detach().cpu(), pe.detach().cpu()) < 2e-2, n
+
+
+def test_resume_with_optimiser_state_continues_the_trajectory(cfg_s, tmp_path):
+    """save -> resume -> one step == the uninterrupted run (`resume_from_checkpoint`, train_upstream.py:54 of the reference): two SGD
+    steps, weights + HipSGD.state_dict() through torch.save / torch.load(weights_only=True), the third step on a fresh model.
+    Its update must equal the uninterrupted third step (fp32 atomic order only); with fresh momentum it is a different update."""
+    from src.encoder import AudioNTT2020Task6
+    from src.upstream.delores_s.upstream_expert import Upstream_Expert
+    B, T = 16, 96
+    def make():
+        m = Upstream_Expert(_cfg(cfg_s, "fp32"), base_encoder=AudioNTT2020Task6)
+        fill.fill_state_dict_(m, seed=51)
+        return m.cuda().train()
+    def step(m, opt, s):
+        m.encoder.encoder.dropout_masks.queue = [drop_mask((B, T // 8, 2048), 9700 + 2 * s), drop_mask((B, T // 8, 2048), 9701 + 2 * s)]
+        opt.zero_grad()
+        loss = m.training_step((views(B, T, 9710 + 2 * s).cuda(), views(B, T, 9711 + 2 * s).cuda()), s)
+        loss.backward()
+        opt.step()
+        return float(loss)
+    a = make()
+    oa = a.configure_optimizers()
+    for s in range(2):
+        step(a, oa, s)
+    torch.cuda.synchronize()
+    path = str(tmp_path / "resume.ckpt")
+    torch.save({"state_dict": a.state_dict(), "hip_optimizer_states": [oa.state_dict()]}, path)
+    w2 = {n: p.detach().clone() for n, p in a.named_parameters()}
+    la = step(a, oa, 2)
+    ck = torch.load(path, map_location="cuda", weights_only=True)
+    deltas = {}
+    for restore in (True, False):
+        b = make()
+        b.load_state_dict(ck["state_dict"])
+        ob = b.configure_optimizers()
+        if restore:
+            assert ob.load_state_dict(ck["hip_optimizer_states"][0]) is True and ob.steps == 2
+        lb = step(b, ob, 2)
+        assert abs(lb - la) <= 1e-5 * abs(la)
+        deltas[restore] = {n: (p.detach() - w2[n]) for n, p in b.named_parameters()}
+    for n, p in a.named_parameters():
+        want = p.detach() - w2[n]
+        if float(want.norm()) == 0:
+            continue
+        assert rel_l2(deltas[True][n].cpu(), want.cpu()) < 1e-3, n
+    n = "encoder.encoder.fc.3.weight"
+    assert rel_l2(deltas[False][n].cpu(), (dict(a.named_parameters())[n].detach() - w2[n]).cpu()) > 0.2     # momentum mattered
 
 
 # ------------------------------------------------------------------------------------------------ harness / checkpoints

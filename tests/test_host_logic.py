@@ -95,3 +95,72 @@ def test_train_upstream_cli_and_config(tmp_path):
     cfg = tu.load_config(args)
     assert cfg["pretrain"]["base_encoder"]["type"] == "AudioNTT2020Task6" and isinstance(cfg["pretrain"]["lambda_barlow"], float)
     assert tu.load_config(tu.get_args(["--input", "x.csv"]))["pretrain"]["loss_scale"] == "1/32"
+
+
+def test_decar_v2_shards_are_distributed_sampler_shares():
+    """`extras/decar-v2/main.py:102,158`: DistributedSampler(train_dataset) (shuffle, seed 0) + set_epoch(epoch) - the harness's
+    `ShardedBatches` yields exactly that sampler's indices for every rank and epoch (drop_last batching on top), including the
+    wrap-around padding when the data set is not a multiple of the world size."""
+    import torch
+    from torch.utils.data.distributed import DistributedSampler
+    from src.upstream.decar_v2.main import ShardedBatches
+    for n, world, batch in ((128, 2, 16), (101, 4, 5), (37, 8, 2)):
+        for rank in range(world):
+            sb = ShardedBatches(n, batch, lambda i: torch.tensor([float(i)]), rank, world)
+            ds = DistributedSampler(range(n), world, rank, shuffle=True, seed=0)
+            for epoch in (0, 1, 5):
+                sb.set_epoch(epoch)
+                ds.set_epoch(epoch)
+                want = list(ds)
+                assert sb.indices().tolist() == want
+                got = [int(i) for ids, _ in sb for i in ids]
+                assert got == want[:len(sb) * batch] and len(sb) == len(want) // batch
+            assert sb.indices().tolist() != list(range(rank * (n // world), (rank + 1) * (n // world)))
+        seen = set()
+        for rank in range(world):
+            seen |= set(ShardedBatches(n, batch, None, rank, world).indices().tolist())
+        assert seen == set(range(n))
+
+
+def test_flat_optimiser_state_schema_round_trip_and_foreign_checkpoints():
+    """Every flat optimiser saves / restores its own state (momentum; Adam moments + step count) under a schema of its own, and
+    declines - with a warning, not a KeyError - the per-parameter schema a Lightning / torch.optim checkpoint of the reference
+    carries under `optimizer_states` (`resume_from_checkpoint`, train_upstream.py:54)."""
+    import warnings
+    import torch
+    from src.flat import FlatGroup
+    from src.optim import FlatState, HipAdamW, HipLARC, HipLARS, HipSGD
+    def group():
+        ps = [torch.nn.Parameter(torch.randn(5, 7)), torch.nn.Parameter(torch.randn(9))]
+        return FlatGroup([("w", ps[0]), ("b", ps[1])]), ps
+    for make, bufs in ((lambda f, p: HipSGD([f], p, 0.1), ("momentum",)), (lambda f, p: HipLARS([f], p, 0.2), ("momentum",)),
+                       (lambda f, p: HipLARC([f], p, 0.3), ("momentum",)), (lambda f, p: HipAdamW([f], p, lr=1e-3), ("exp_avg", "exp_avg_sq"))):
+        fg, ps = group()
+        opt = make(fg, ps)
+        assert isinstance(opt, FlatState)
+        for i, b in enumerate(bufs):
+            setattr(fg, b, torch.full((fg.numel,), 1.5 + i))
+        opt.steps = 7
+        if isinstance(opt, HipAdamW):
+            opt.step_count = torch.tensor([7])
+        opt.param_groups[0]["lr"] = 0.0625
+        sd = opt.state_dict()
+        assert sd["schema"] == FlatState.SCHEMA and sd["kind"] == type(opt).__name__
+        fg2, ps2 = group()
+        opt2 = make(fg2, ps2)
+        assert opt2.load_state_dict(sd) is True
+        assert opt2.steps == 7 and opt2.param_groups[0]["lr"] == 0.0625
+        for i, b in enumerate(bufs):
+            assert torch.equal(getattr(fg2, b), torch.full((fg2.numel,), 1.5 + i))
+        if isinstance(opt, HipAdamW):
+            assert int(opt2.step_count) == 7
+        # torch's own schema (what the reference's Lightning checkpoint holds) and another flat optimiser's state are declined
+        foreign = torch.optim.SGD(ps, lr=0.1, momentum=0.9).state_dict()
+        fg3, ps3 = group()
+        opt3 = make(fg3, ps3)
+        with warnings.catch_warnings(record=True) as w:
+            warnings.simplefilter("always")
+            assert opt3.load_state_dict(foreign) is False
+            other = dict(sd, kind="SomethingElse")
+            assert opt3.load_state_dict(other) is False
+        assert len(w) == 2 and all(getattr(fg3, b, None) is None for b in bufs)

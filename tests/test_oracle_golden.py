@@ -401,3 +401,30 @@ def test_vit_oracle_block_is_the_unpooled_reference_block(golden):
     grads = dict(blk.named_parameters())
     for n, norm in zip(g["plain.g_names"], g["plain.g_norms"]):
         assert abs(float(grads[str(n)].grad.norm()) - norm) <= 1e-4 * norm + 1e-7, n
+
+
+@pytest.mark.parametrize("case", ["a", "b"])
+def test_kmeans_oracle_vs_reference_cluster_memory(golden, case):
+    """oracle/kmeans.py against the reference's own `cluster_memory` (extras/decar-v2/utils.py:276-346, run on the CPU by
+    make_goldens.py g16 with a no-op `.cuda` and a 1-process gloo group): same seeds -> the centroids after the last M step
+    and the assignments in data-set order, including the clusters that stay empty in case b (they keep their seed)."""
+    from oracle import kmeans as OK
+    g = golden("kmeans_ref")
+    N, size_dataset, d, K, iters, seed = (int(v) for v in g[f"{case}.dims"])
+    mem = torch.from_numpy(g[f"{case}.mem"])
+    torch.manual_seed(seed)
+    seed_idx = torch.randperm(N)[:K]                            # the draw the reference makes on rank 0
+    assert torch.equal(seed_idx, torch.from_numpy(g[f"{case}.seed_idx"]))
+    cent, assign = OK.cluster_memory(mem, mem[seed_idx], n_iters=iters)
+    want_c = torch.from_numpy(g[f"{case}.centroids"][-1])
+    np.testing.assert_allclose(cent.numpy(), want_c.numpy(), rtol=1e-5, atol=1e-6)
+    out = torch.full((size_dataset,), -100, dtype=torch.int64)
+    out[torch.from_numpy(g[f"{case}.index"])] = assign
+    want_a = torch.from_numpy(g[f"{case}.assignments"])
+    assert torch.equal(out == -100, want_a == -100)
+    assert float((out == want_a).float().mean()) >= 0.999
+    if case == "b":
+        counts = np.bincount(assign.numpy(), minlength=K)
+        empty = np.nonzero(counts == 0)[0]
+        assert len(empty) >= 12
+        np.testing.assert_allclose(cent[empty].numpy(), mem[seed_idx][empty].numpy(), rtol=1e-6, atol=1e-7)
