@@ -25,11 +25,12 @@ __global__ __launch_bounds__(256) void colstats_kernel(const T_* __restrict__ x,
     float s[8], q[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) { s[i] = 0.f; q[i] = 0.f; }
-    for (long r = row_begin + r0; r < row_end; r += 32) {
-        const Vec8<T_> v = Vec8<T_>::load(x + r * ld + col0);
+    if (col0 < C)                                            // C % 8 == 0: the last slab may be partial (the MViT widths are 96 * 2^k)
+        for (long r = row_begin + r0; r < row_end; r += 32) {
+            const Vec8<T_> v = Vec8<T_>::load(x + r * ld + col0);
 #pragma unroll
-        for (int i = 0; i < 8; ++i) { const float f = v.get(i); s[i] += f; if (SQ) q[i] += f * f; }
-    }
+            for (int i = 0; i < 8; ++i) { const float f = v.get(i); s[i] += f; if (SQ) q[i] += f * f; }
+        }
 #pragma unroll
     for (int i = 0; i < 8; ++i) { red[threadIdx.x][i] = s[i]; red[threadIdx.x][8 + i] = q[i]; }
     __syncthreads();
@@ -39,8 +40,10 @@ __global__ __launch_bounds__(256) void colstats_kernel(const T_* __restrict__ x,
             double t = 0.0;
             for (int r = 0; r < 32; ++r) t += (double)red[r * 8 + g][k];
             const int c = blockIdx.y * 64 + g * 8 + (k & 7);
-            if (k < 8) atomicAdd(&sum[c], t);
-            else       atomicAdd(&sumsq[c], t);
+            if (c < C) {
+                if (k < 8) atomicAdd(&sum[c], t);
+                else       atomicAdd(&sumsq[c], t);
+            }
         }
     }
 }
@@ -403,7 +406,7 @@ __global__ void unpack_conv_dw_kernel(const float* __restrict__ dWp, float* __re
 
 extern "C" int audiossl_colstats(int dtype, const void* x, int groups, long M, int C, long ld, int want_sq, double* sum,
                                  double* sumsq, void* stream) {
-    ASSL_REQUIRE(x && sum && groups > 0 && M > 0 && C > 0 && (C % 64) == 0 && (ld % 8) == 0);
+    ASSL_REQUIRE(x && sum && groups > 0 && M > 0 && C > 0 && (C % 8) == 0 && (ld % 8) == 0);
     ASSL_REQUIRE((dtype == 0 || dtype == 1) && (!want_sq || sumsq));
     hipStream_t s = static_cast<hipStream_t>(stream);
     const size_t nb = sizeof(double) * C * groups;
@@ -413,7 +416,7 @@ extern "C" int audiossl_colstats(int dtype, const void* x, int groups, long M, i
         ASSL_ZERO(sum, nb, s);
         if (want_sq) ASSL_ZERO(sumsq, nb, s);
     }
-    const int slabs = C / 64;
+    const int slabs = (C + 63) / 64;
     long it = (M * slabs * groups + 32L * 2048 - 1) / (32L * 2048);  // aim for ~2048 blocks in total, 1..128 iterations each
     it = it < 1 ? 1 : (it > 128 ? 128 : it);
     const int rpb = 32 * (int)it;

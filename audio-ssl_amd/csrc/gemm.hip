@@ -111,7 +111,7 @@ __device__ __forceinline__ void epilogue_lds(const GemmArgs& g, f32x16 (&acc)[MI
                 ct[(i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half) * EPI_PITCH + j * 32 + l31] = acc[i][j][r];
     const int col = col0 + lane;
     if (col >= g.N) return;
-    const float bias = g.bias ? g.bias[col] : 0.f;
+    const float bias = (g.bias && blockIdx.z == 0) ? g.bias[col] : 0.f;      // split-K: the first split adds the bias
     const float floor_ = g.relu ? 0.f : -3.4e38f;
     const T* gate = static_cast<const T*>(g.gate);
     const int rows = min(32 * MI, g.M - row0);
@@ -165,7 +165,7 @@ __device__ __forceinline__ void epilogue_vec(const GemmArgs& g, f32x16 (&acc)[MI
     float bias[8];
 #pragma unroll
     for (int u = 0; u < 8; ++u) bias[u] = 0.f;
-    if (g.bias) {
+    if (g.bias && blockIdx.z == 0) {
         const Vec8<float> b = Vec8<float>::load(g.bias + col);
 #pragma unroll
         for (int u = 0; u < 8; ++u) bias[u] = b.get(u);
@@ -1228,59 +1228,144 @@ __device__ __forceinline__ void p6_body(const GemmArgs& g, char* smem, int wg) {
     epilogue<bf16, 2>(g, acc, smem, bm + wr * 64, bn + wc * 64, lane, wave);
 }
 
+// 128 x 128 output tile, 8 waves (4 x 2, wave tile 32 x 64): the same loop for the M = 512 problems (the heads' dzn / last data
+// gradient launches: 96 tiles of 256 x 128, 192 of 128 x 128) and single problems with a narrow output.  A K-tile is TWO 16 KB parts
+// (A: every wave's 32 rows, B: every wave's 64 columns) and ONE phase (8 MFMA 32x32x16 per wave); K-tile t + 3 is staged in
+// phase t into a ring of five buffers (160 KB: the buffer it replaces was last read in phase t - 2, two phases back as the WAR rule
+// asks), and the wait at the end of phase t's LOAD section retires K-tile t + 1 (issued two phases earlier): all but the two
+// youngest K-tiles = vmcnt(8).  More LDS read bytes per MFMA than the 256-row kernels (12 fragment reads per 8 MFMAs).
+constexpr int P5_PART = 16384, P5_BUF = 2 * P5_PART, P5_NBUF = 5, P5_AHEAD = 3;
+
 template <bool TA, bool TB>
-__global__ __launch_bounds__(512) void gemm_p6_kernel(GemmArgs g) {
-    extern __shared__ __attribute__((aligned(1024))) char smem[];
-    p6_body<TA, TB>(g, smem, xcd_contiguous(blockIdx.x, gridDim.x));
+__device__ __forceinline__ void p5_body(const GemmArgs& g, char* smem, int wg) {
+    const int tiles_n = (g.N + 127) / 128;
+    const int bm = (wg / tiles_n) * 128, bn = (wg % tiles_n) * 128;
+    const int ksteps = g.K / GBK;
+    const int per = (ksteps + g.ksplit - 1) / g.ksplit;
+    const int ks0 = blockIdx.z * per, ks1 = min(ksteps, ks0 + per);
+    if (ks0 >= ks1) return;
+    const int nk = ks1 - ks0;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, half = lane >> 5;
+    const int wr = wave >> 1, wc = wave & 1;
+
+    PartOp<TA, 32, 32> oa; PartOp<TB, 64, 64> ob;
+    oa.init(g.A, g.a_bytes, g.lda, bm, ks0 * GBK, wave, lane, wr);
+    ob.init(g.B, g.b_bytes, g.ldb, bn, ks0 * GBK, wave, lane, wc);
+    char* const wdst = smem + wave * 2048;
+
+    f32x16 acc[1][2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[0][j][r] = 0.f;
+
+    auto issue = [&](int t, int boff) {
+        const bool live = t < nk;
+        oa.issue(0, t, wdst + boff, live);
+        ob.issue(0, t, wdst + boff + P5_PART, live);
+    };
+    Vec8<bf16> fa[4], fb[2][4];
+    issue(0, 0); issue(1, P5_BUF); issue(2, 2 * P5_BUF);
+    wait_vm<8>();                                            // K-tile 0 has landed
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    if (wave >= 4) { __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); }
+    int cb = 0, ib = P5_AHEAD * P5_BUF;
+    for (int t = 0; t < nk; ++t) {
+        const char* const img = smem + cb;
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) fa[kk] = oa.frag(img, 0, kk, half);
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) fb[j][kk] = ob.frag(img + P5_PART, j, kk, half);
+        issue(t + P5_AHEAD, ib);
+        wait_vm<8>();
+        __builtin_amdgcn_s_barrier();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) Mma<bf16>::run(acc[0][j], fa[kk], fb[j][kk]);
+        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        cb = cb + P5_BUF == P5_NBUF * P5_BUF ? 0 : cb + P5_BUF;
+        ib = ib + P5_BUF == P5_NBUF * P5_BUF ? 0 : ib + P5_BUF;
+    }
+    if (wave < 4) { __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); }
+    wait_vm<0>();
+    epilogue<bf16, 1>(g, acc, smem, bm + wr * 32, bn + wc * 64, lane, wave);
 }
-template <bool TA, bool TB>
-__global__ __launch_bounds__(512) void gemm_p6_multi_kernel(GemmMulti gm) {
+
+// KIND: 6 = 256 x 128 tiles (p6_body), 5 = 128 x 128 tiles (p5_body)
+template <bool TA, bool TB, int KIND>
+__device__ __forceinline__ void pk_body(const GemmArgs& g, char* smem, int wg) {
+    if constexpr (KIND == 6) p6_body<TA, TB>(g, smem, wg); else p5_body<TA, TB>(g, smem, wg);
+}
+
+template <bool TA, bool TB, int KIND>
+__global__ __launch_bounds__(512) void gemm_pk_kernel(GemmArgs g) {
+    extern __shared__ __attribute__((aligned(1024))) char smem[];
+    pk_body<TA, TB, KIND>(g, smem, xcd_contiguous(blockIdx.x, gridDim.x));
+}
+template <bool TA, bool TB, int KIND>
+__global__ __launch_bounds__(512) void gemm_pk_multi_kernel(GemmMulti gm) {
     extern __shared__ __attribute__((aligned(1024))) char smem[];
     int wg;
     const int p = multi_locate(gm, wg);
     if (p < 0) return;
-    p6_body<TA, TB>(gm.p[p], smem, wg);
+    pk_body<TA, TB, KIND>(gm.p[p], smem, wg);
 }
-constexpr size_t P6_LDS = (size_t)P6_NBUF * P6_BUF > EPI_LDS * 2 ? (size_t)P6_NBUF * P6_BUF : EPI_LDS * 2;
+template <int KIND> constexpr size_t pk_lds() {
+    return KIND == 6 ? ((size_t)P6_NBUF * P6_BUF > EPI_LDS * 2 ? (size_t)P6_NBUF * P6_BUF : EPI_LDS * 2) : (size_t)P5_NBUF * P5_BUF;
+}
+template <int KIND> constexpr int pk_rows() { return KIND == 6 ? 256 : 128; }
 
-template <bool TA, bool TB>
-int launch_p6(const GemmArgs& g, hipStream_t s) {
+template <bool TA, bool TB, int KIND>
+int launch_pk(const GemmArgs& g, hipStream_t s) {
     static bool attr_set = false;
     if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_p6_kernel<TA, TB>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)P6_LDS) != hipSuccess) return ASSL_ELAUNCH;
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_pk_kernel<TA, TB, KIND>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)pk_lds<KIND>()) != hipSuccess) return ASSL_ELAUNCH;
         attr_set = true;
     }
-    const int tiles = ceil_div(g.M, 256) * ceil_div(g.N, 128);
-    { static char nm[96]; g_assl_last_kernel = note_name(nm, "gemm_p6_kernel<%s, %s>", TF(TA), TF(TB)); }
-    hipLaunchKernelGGL((gemm_p6_kernel<TA, TB>), dim3(tiles, 1, g.ksplit), dim3(512), P6_LDS, s, g);
+    const int tiles = ceil_div(g.M, pk_rows<KIND>()) * ceil_div(g.N, 128);
+    { static char nm[96]; g_assl_last_kernel = note_name(nm, "gemm_pk_kernel<%s, %s, %d>", TF(TA), TF(TB), KIND); }
+    hipLaunchKernelGGL((gemm_pk_kernel<TA, TB, KIND>), dim3(tiles, 1, g.ksplit), dim3(512), pk_lds<KIND>(), s, g);
     ASSL_LAUNCH_CHECK();
 }
-template <bool TA, bool TB>
-int launch_p6_multi(const GemmMulti& gm_, int count, int ksplit, hipStream_t s) {
+template <bool TA, bool TB, int KIND>
+int launch_pk_multi(const GemmMulti& gm_, int count, int ksplit, hipStream_t s) {
     GemmMulti gm = gm_;
-    const int grid = multi_grid(gm, count, 256, 128);
+    const int grid = multi_grid(gm, count, pk_rows<KIND>(), 128);
     static bool attr_set = false;
     if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_p6_multi_kernel<TA, TB>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)P6_LDS) != hipSuccess) return ASSL_ELAUNCH;
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_pk_multi_kernel<TA, TB, KIND>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)pk_lds<KIND>()) != hipSuccess) return ASSL_ELAUNCH;
         attr_set = true;
     }
-    { static char nm[96]; g_assl_last_kernel = note_name(nm, "gemm_p6_multi_kernel<%s, %s>", TF(TA), TF(TB)); }
-    hipLaunchKernelGGL((gemm_p6_multi_kernel<TA, TB>), dim3(grid, 1, ksplit), dim3(512), P6_LDS, s, gm);
+    { static char nm[96]; g_assl_last_kernel = note_name(nm, "gemm_pk_multi_kernel<%s, %s, %d>", TF(TA), TF(TB), KIND); }
+    hipLaunchKernelGGL((gemm_pk_multi_kernel<TA, TB, KIND>), dim3(grid, 1, ksplit), dim3(512), pk_lds<KIND>(), s, gm);
     ASSL_LAUNCH_CHECK();
 }
-int dispatch_p6(const GemmArgs& g, int ta, int tb, hipStream_t s) {
-    if (!ta && !tb) return launch_p6<false, false>(g, s);
-    if (!ta && tb) return launch_p6<false, true>(g, s);
-    if (ta && tb) return launch_p6<true, true>(g, s);
-    return launch_p6<true, false>(g, s);
+template <int KIND>
+int dispatch_pk(const GemmArgs& g, int ta, int tb, hipStream_t s) {
+    if (!ta && !tb) return launch_pk<false, false, KIND>(g, s);
+    if (!ta && tb) return launch_pk<false, true, KIND>(g, s);
+    if (ta && tb) return launch_pk<true, true, KIND>(g, s);
+    return launch_pk<true, false, KIND>(g, s);
 }
-int dispatch_p6_multi(const GemmMulti& gm, int count, int ksplit, int ta, int tb, hipStream_t s) {
-    if (!ta && !tb) return launch_p6_multi<false, false>(gm, count, ksplit, s);
-    if (!ta && tb) return launch_p6_multi<false, true>(gm, count, ksplit, s);
-    if (ta && tb) return launch_p6_multi<true, true>(gm, count, ksplit, s);
-    return launch_p6_multi<true, false>(gm, count, ksplit, s);
+template <int KIND>
+int dispatch_pk_multi(const GemmMulti& gm, int count, int ksplit, int ta, int tb, hipStream_t s) {
+    if (!ta && !tb) return launch_pk_multi<false, false, KIND>(gm, count, ksplit, s);
+    if (!ta && tb) return launch_pk_multi<false, true, KIND>(gm, count, ksplit, s);
+    if (ta && tb) return launch_pk_multi<true, true, KIND>(gm, count, ksplit, s);
+    return launch_pk_multi<true, false, KIND>(gm, count, ksplit, s);
 }
 
 // BK = 32 with a register budget for THREE workgroups per CU (41 KB of LDS each; the epilogue runs on half-height tiles so
@@ -1350,20 +1435,25 @@ static int dispatch_multi(const GemmMulti& gm, int count, int M, int N, int kmin
     } while (0)
     static const int p8 = getenv("AUDIOSSL_GEMM_P8") ? atoi(getenv("AUDIOSSL_GEMM_P8")) : -1;
     static const int p6 = getenv("AUDIOSSL_GEMM_P6") ? atoi(getenv("AUDIOSSL_GEMM_P6")) : -1;
-    bool hs_ok = M >= 256 && N >= 128 && (!trans_a || M % 8 == 0);           // the hand-scheduled kernels: K % 64, whole 16-byte rows
-    long t6 = 0, t8 = 0;
+    bool hs_ok = M >= 128 && N >= 128 && (!trans_a || M % 8 == 0);           // the hand-scheduled kernels: K % 64, whole 16-byte rows
+    long t5 = 0, t6 = 0, t8 = 0;
     for (int i = 0; i < count; ++i) {
         hs_ok = hs_ok && K[i] % GBK == 0 && (!trans_b || Nv[i] % 8 == 0);
+        t5 += (long)ceil_div(M, 128) * ceil_div(Nv[i], 128);
         t6 += (long)ceil_div(M, 256) * ceil_div(Nv[i], 128);
         t8 += (long)ceil_div(M, 256) * ceil_div(Nv[i], 256);
     }
+    t5 *= ksplit; t6 *= ksplit; t8 *= ksplit;
     // the 256 x 128 kernel: problems whose 256 x 256 tiles would leave more than half of the CUs idle while the 256 x 128 tiles
-    // fit the chip in one round (the M = 1,024 layers and data gradients of the three heads: 192 workgroups)
-    if (p6 != 0 && hs_ok && (p6 == 1 || (t6 * ksplit >= 128 && t6 * ksplit <= 288 && t8 * ksplit < 128 && kmin >= 512)))
-        return dispatch_p6_multi(gm, count, ksplit, trans_a, trans_b, s);
+    // fit the chip in one round (the M = 1,024 layers and data gradients of the three heads: 192 workgroups); the 128 x 128 kernel
+    // where even those are too few (M = 512: 96 -> 192 workgroups)
+    if (p6 != 0 && hs_ok && M >= 256 && (p6 == 1 || (t6 >= 128 && t6 <= 288 && t8 < 128 && kmin >= 512)))
+        return dispatch_pk_multi<6>(gm, count, ksplit, trans_a, trans_b, s);
+    if (p6 != 0 && hs_ok && (p6 == 5 || (p6 != 1 && t5 >= 96 && t5 <= 288 && t6 < 128 && kmin >= 512)))
+        return dispatch_pk_multi<5>(gm, count, ksplit, trans_a, trans_b, s);
     // multi-problem launches: measured wins for the transposed-A weight gradients of the three heads (2048 x 2048 x 1024:
     // 50.9 -> 43.9 us, x 512: 31.3 -> 29.0 us)
-    if (p8 != 0 && p8 != 2 && hs_ok && N >= 256 && (p8 == 1 || (trans_a && t8 * ksplit >= 128 && kmin >= 512)))
+    if (p8 != 0 && p8 != 2 && hs_ok && M >= 256 && N >= 256 && (p8 == 1 || (trans_a && t8 >= 128 && kmin >= 512)))
         return dispatch_p8_multi(gm, count, ksplit, trans_a, trans_b, s);
     static const int w8 = getenv("AUDIOSSL_GEMM_W8") ? atoi(getenv("AUDIOSSL_GEMM_W8")) : 0;
     if (w8 && M >= 256) MULTI(64, 2, 8);
@@ -1457,9 +1547,15 @@ static int run_bf16(const GemmArgs& g, int trans_a, int trans_b, hipStream_t s) 
     // the hand-scheduled 256 x 128 kernel (written for the multi-problem launches of the projector heads, see dispatch_multi):
     // single problems whose 256 x 128 tiles fill the chip once while the 256 x 256 tiles would leave half of it idle
     static const int p6 = getenv("AUDIOSSL_GEMM_P6") ? atoi(getenv("AUDIOSSL_GEMM_P6")) : -1;
-    if (p6 != 0 && p8_ok && !g.lse_mode && M >= 256 && N >= 128) {
-        const long t6 = (long)ceil_div(M, 256) * ceil_div(N, 128), t8 = (long)ceil_div(M, 256) * ceil_div(N, 256);
-        if (p6 == 1 || (t6 * ksplit >= 128 && t6 * ksplit <= 288 && t8 * ksplit < 128 && K / ksplit >= 512)) return dispatch_p6(g, trans_a, trans_b, s);
+    if (p6 != 0 && p8_ok && !g.lse_mode && M >= 128 && N >= 128) {
+        const long t5 = (long)ceil_div(M, 128) * ceil_div(N, 128) * ksplit, t6 = (long)ceil_div(M, 256) * ceil_div(N, 128) * ksplit,
+                   t8 = (long)ceil_div(M, 256) * ceil_div(N, 256) * ksplit;
+        if (M >= 256 && (p6 == 1 || (t6 >= 128 && t6 <= 288 && t8 < 128 && K / ksplit >= 512))) return dispatch_pk<6>(g, trans_a, trans_b, s);
+        // measured (tools/gemm_shapes.py): NN 6144 x 512 x 2048 34.1 -> 25.8 us, TN 2048 x 512 x 6144 / 3 41.9 -> 32.2 us; with short K
+        // loops (2048 x 2048 x 512 TN: 19.3 vs 17.9 us) and for K-contiguous operands on <= 128 tiles (the ring kernel: 20.2 vs 21.7 us)
+        // the older kernels stay
+        if (p6 == 5 || (p6 != 1 && t5 >= 96 && t5 <= 288 && t6 < 128 && K / ksplit >= 1024 && (trans_a || trans_b || t5 > 128)))
+            return dispatch_pk<5>(g, trans_a, trans_b, s);
     }
     // grids of >= 2 workgroups per CU with a K-contiguous A operand: K-step 32 and THREE co-resident workgroups per CU (41 KB
     // of LDS each, 126 VGPRs) - 12 waves per CU hide the staged-load and barrier waits better than two workgroups at K-step
@@ -1506,6 +1602,7 @@ extern "C" int audiossl_gemm(int dtype, int trans_a, int trans_b, int M, int N, 
     ASSL_REQUIRE(atomic >= 0 && atomic <= 2);
     ASSL_REQUIRE(!atomic || out_f32 || dtype == 0);
     ASSL_REQUIRE(ksplit == 1 || atomic == 1);
+    ASSL_REQUIRE(ksplit == 1 || (!relu && !keep && !gate));             // non-linear epilogue terms need the whole sum (the bias is added by split 0)
     ASSL_REQUIRE(!resid || (ksplit == 1 && !atomic));
     // vector (8-element) dimension of each operand must be a multiple of 8 and its rows 16-byte aligned
     ASSL_REQUIRE((trans_a ? M : K) % 8 == 0 && (trans_b ? N : K) % 8 == 0);

@@ -16,28 +16,29 @@ constexpr int LN_MAX = 16;       // columns per lane: C <= 1024
 // one wave per row
 __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
                                                             const float* __restrict__ beta, bf16* __restrict__ y,
-                                                            float* __restrict__ mean, float* __restrict__ rstd, int M, int C,
-                                                            float eps) {
+                                                            float* __restrict__ y32, float* __restrict__ mean,
+                                                            float* __restrict__ rstd, int M, int C, float eps) {
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (row >= M) return;
     const float* xr = x + (long)row * C;
-    const int n = C / 64;
     float v[LN_MAX];
     float s = 0.f;
 #pragma unroll
     for (int i = 0; i < LN_MAX; ++i)
-        if (i < n) { v[i] = xr[lane + 64 * i]; s += v[i]; }
+        if (lane + 64 * i < C) { v[i] = xr[lane + 64 * i]; s += v[i]; }
     const float mu = wave_sum(s) / (float)C;
     float q = 0.f;
 #pragma unroll
     for (int i = 0; i < LN_MAX; ++i)
-        if (i < n) { const float d = v[i] - mu; q += d * d; }
+        if (lane + 64 * i < C) { const float d = v[i] - mu; q += d * d; }
     const float rs = rsqrtf(wave_sum(q) / (float)C + eps);
 #pragma unroll
     for (int i = 0; i < LN_MAX; ++i)
-        if (i < n) {
+        if (lane + 64 * i < C) {
             const int c = lane + 64 * i;
-            y[(long)row * C + c] = (bf16)((v[i] - mu) * rs * gamma[c] + beta[c]);
+            const float o = (v[i] - mu) * rs * gamma[c] + beta[c];
+            y[(long)row * C + c] = (bf16)o;
+            if (y32) y32[(long)row * C + c] = o;
         }
     if (lane == 0) { mean[row] = mu; rstd[row] = rs; }
 }
@@ -51,12 +52,11 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
                                                             float* __restrict__ dgamma, float* __restrict__ dbeta, int M, int C) {
     __shared__ float sg[1024], sb[1024];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int n = C / 64;
     for (int c = threadIdx.x; c < C; c += 256) { sg[c] = 0.f; sb[c] = 0.f; }
     __syncthreads();
     float pg[LN_MAX], pb[LN_MAX], gm[LN_MAX];
 #pragma unroll
-    for (int i = 0; i < LN_MAX; ++i) { pg[i] = 0.f; pb[i] = 0.f; gm[i] = i < n ? gamma[lane + 64 * i] : 0.f; }
+    for (int i = 0; i < LN_MAX; ++i) { pg[i] = 0.f; pb[i] = 0.f; gm[i] = lane + 64 * i < C ? gamma[lane + 64 * i] : 0.f; }
     for (int k = 0; k < LN_ROWS / 4; ++k) {
         const int row = blockIdx.x * LN_ROWS + wave * (LN_ROWS / 4) + k;
         if (row >= M) break;
@@ -65,7 +65,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
         for (int i = 0; i < LN_MAX; ++i)
-            if (i < n) {
+            if (lane + 64 * i < C) {
                 const long o = (long)row * C + lane + 64 * i;
                 const float d = dy[o];
                 xh[i] = (x[o] - mu) * rs;
@@ -79,14 +79,14 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
         s2 = wave_sum(s2) / (float)C;
 #pragma unroll
         for (int i = 0; i < LN_MAX; ++i)
-            if (i < n) {
+            if (lane + 64 * i < C) {
                 const long o = (long)row * C + lane + 64 * i;
                 dres[o] += rs * (g[i] - s1 - xh[i] * s2);
             }
     }
 #pragma unroll
     for (int i = 0; i < LN_MAX; ++i)
-        if (i < n) { atomicAdd(&sg[lane + 64 * i], pg[i]); atomicAdd(&sb[lane + 64 * i], pb[i]); }
+        if (lane + 64 * i < C) { atomicAdd(&sg[lane + 64 * i], pg[i]); atomicAdd(&sb[lane + 64 * i], pb[i]); }
     __syncthreads();
     for (int c = threadIdx.x; c < C; c += 256) { atomicAdd(dgamma + c, sg[c]); atomicAdd(dbeta + c, sb[c]); }
 }
@@ -186,17 +186,17 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const
 
 #define S_(stream) static_cast<hipStream_t>(stream)
 
-extern "C" int audiossl_layernorm_fwd(const float* x, const float* gamma, const float* beta, void* y, float* mean, float* rstd, int M,
-                                      int C, float eps, void* stream) {
-    ASSL_REQUIRE(x && gamma && beta && y && mean && rstd && M > 0 && C > 0 && (C % 64) == 0 && C <= 64 * LN_MAX);
+extern "C" int audiossl_layernorm_fwd(const float* x, const float* gamma, const float* beta, void* y, float* y32, float* mean, float* rstd,
+                                      int M, int C, float eps, void* stream) {
+    ASSL_REQUIRE(x && gamma && beta && y && mean && rstd && M > 0 && C > 0 && C <= 64 * LN_MAX);
     hipLaunchKernelGGL(layernorm_fwd_kernel, dim3(ceil_div(M, 4)), dim3(256), 0, S_(stream), x, gamma, beta, static_cast<bf16*>(y),
-                       mean, rstd, M, C, eps);
+                       y32, mean, rstd, M, C, eps);
     ASSL_LAUNCH_CHECK();
 }
 
 extern "C" int audiossl_layernorm_bwd(const float* dy, const float* x, const float* mean, const float* rstd, const float* gamma,
                                       float* dres, float* dgamma, float* dbeta, int M, int C, void* stream) {
-    ASSL_REQUIRE(dy && x && mean && rstd && gamma && dres && dgamma && dbeta && M > 0 && (C % 64) == 0 && C <= 64 * LN_MAX);
+    ASSL_REQUIRE(dy && x && mean && rstd && gamma && dres && dgamma && dbeta && M > 0 && C > 0 && C <= 64 * LN_MAX);
     hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(ceil_div(M, LN_ROWS)), dim3(256), 0, S_(stream), dy, x, mean, rstd, gamma, dres,
                        dgamma, dbeta, M, C);
     ASSL_LAUNCH_CHECK();

@@ -28,6 +28,44 @@ _BN_FUSED = _os.environ.get("AUDIOSSL_BN_FUSED", "1") != "0"
 ONE_STREAM = os.environ.get("AUDIOSSL_ONE_STREAM", "0") == "1"
 
 
+# ---- stream forks under hipGraph capture ------------------------------------------------------------------------------------
+# Capture rules (HIP = CUDA): a stream joins a capture by waiting on an event recorded in a capturing stream (a FORK); every
+# stream that joined must be ordered back into the capture's ORIGIN stream before hipStreamEndCapture (a JOIN); no wait on an
+# event recorded outside the capture.  Every fork of this package's steps starts at the origin stream (key encoder, loss heads,
+# preparation sweeps, weight gradients) and is joined back into it.  The one variant of round 2 that forked from an already forked
+# stream (the heads' weight-gradient launches sent to the WGRAD stream from inside the heads' stream, joined into the origin by
+# the encoder backward's WGRAD join - legal by the rules above, and fine when issued eagerly) died inside hipStreamEndCapture on
+# ROCm 7.2 with a segmentation fault instead of an error code.  Nothing in these sources can tell a runtime defect from a rule this
+# runtime enforces differently, so the product simply never builds that topology: while a capture scope is open, `fork` refuses a
+# parent stream that is not the scope's origin (AUDIOSSL_ALLOW_NESTED_FORK=1 lifts the check for experiments).
+_CAPTURE_ORIGIN = []
+
+
+class capture_scope:
+    """with capture_scope(): ... - entered INSIDE `torch.cuda.graph(...)` by the graph steps; the stream current at entry is the
+    capture's origin."""
+
+    def __enter__(self):
+        _CAPTURE_ORIGIN.append(torch.cuda.current_stream())
+        return self
+
+    def __exit__(self, *exc):
+        _CAPTURE_ORIGIN.pop()
+        return False
+
+
+def fork(side, parent=None, device=None):
+    """Order `side` after everything enqueued so far on `parent` (default: the current stream) - the only way this package
+    starts work on a side stream."""
+    parent = parent if parent is not None else torch.cuda.current_stream(device)
+    if _CAPTURE_ORIGIN and parent.cuda_stream != _CAPTURE_ORIGIN[-1].cuda_stream and side.cuda_stream != _CAPTURE_ORIGIN[-1].cuda_stream \
+            and os.environ.get("AUDIOSSL_ALLOW_NESTED_FORK", "0") != "1":
+        raise RuntimeError("nested stream fork inside a hipGraph capture: a side stream may only be forked from the capture's origin "
+                           "stream (a fork from an already forked stream crashed hipStreamEndCapture on ROCm 7.2 - engine.py, "
+                           "DESIGN.md section 7); restructure the step or set AUDIOSSL_ALLOW_NESTED_FORK=1 to experiment")
+    side.wait_stream(parent)
+
+
 class SideStream:
     """A second HIP stream for work that is off the critical dependency chain (weight-gradient GEMMs, the key
     encoder): `run(fn)` orders the side stream after everything enqueued so far on the current stream, `join()`
@@ -48,7 +86,7 @@ class SideStream:
         if ONE_STREAM:
             return fn()
         s = self.stream(device)
-        s.wait_stream(torch.cuda.current_stream(device))
+        fork(s, torch.cuda.current_stream(device))
         with torch.cuda.stream(s):
             return fn()
 
@@ -129,6 +167,13 @@ def gemm(dtype, ta, tb, M, Nn, K, A, lda, B, ldb, C, ldc, alpha=1.0, bias=None, 
 
 def linear_fwd(dtype, X, W, M, Nout, K, bias=None, relu=0, keep=None, keep_scale=1.0, out=None, out_f32=0):
     """X [M,K] @ W[Nout,K]^T (+bias) -> [M,Nout]"""
+    if out is None and dtype == N.BF16 and out_f32 and not relu and keep is None and M * Nout <= (1 << 16) and K >= 1024 and K % 512 == 0:
+        # tiny outputs with a long contraction (the 2048 -> 128 embedding layers of the MoCo heads): eight workgroups walking 32
+        # K-steps each took 17-22 us of pure latency on the critical path; K is split over the idle CUs instead - fp32 atomics
+        # into a zeroed output, the bias added by the first split
+        out = ARENA.zeros((M, Nout), torch.float32, like=X)
+        gemm(dtype, 0, 0, M, Nout, K, X, K, W, K, out, Nout, bias=bias, out_f32=1, atomic=1, ksplit=min(8, K // 256))
+        return out
     if out is None:
         out = _empty((M, Nout), torch.float32 if (out_f32 or dtype == 0) else torch.bfloat16, like=X)
     gemm(dtype, 0, 0, M, Nout, K, X, K, W, K, out, Nout, bias=bias, relu=relu, keep=keep, ldk=Nout, keep_scale=keep_scale,

@@ -127,7 +127,7 @@ class GraphPhases:
             g = torch.cuda.CUDAGraph()
             try:
                 # thread-local capture mode: RCCL's watchdog thread polls its events while we capture
-                with torch.cuda.graph(g, capture_error_mode="thread_local"):
+                with torch.cuda.graph(g, capture_error_mode="thread_local"), E.capture_scope():
                     self.results[name] = fn()
             except RuntimeError as e:          # nothing of the phase has executed yet: issue it eagerly from now on
                 import warnings
@@ -231,7 +231,7 @@ class GraphedStep:
             self.graphs, self.losses = [], []
             for _ in range(n):
                 g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g):
+                with torch.cuda.graph(g), E.capture_scope():
                     self.losses.append(self._eager(self.in_1, self.in_2))
                 self.graphs.append(g)
             self.graph, self.loss = self.graphs[0], self.losses[0]

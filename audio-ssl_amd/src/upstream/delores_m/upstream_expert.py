@@ -174,7 +174,7 @@ class Upstream_Expert(MocoQueueMixin, FusedExpertMixin, UpstreamModule):
         if self.high_precision or dt == N.F32 or not self.grouped_heads:
             for i, p in enumerate(heads):
                 if not E.ONE_STREAM:
-                    streams[i].wait_stream(main)
+                    E.fork(streams[i], main)
                 with torch.cuda.stream(streams[i]):
                     dys[i] = R.phase(f"head{i + 1}", lambda i=i, p=p: head_phase(i, p))
         else:
@@ -193,7 +193,7 @@ class Upstream_Expert(MocoQueueMixin, FusedExpertMixin, UpstreamModule):
                     dy_ready=(lambda: dy_event.record()) if dy_event is not None else None)
             hs = streams[0] if _HEADS_ASIDE else main
             if not E.ONE_STREAM and _HEADS_ASIDE:
-                streams[0].wait_stream(main)
+                E.fork(streams[0], main)
             # one rank: the encoder backward only waits for the heads' data gradients (an event recorded before their weight-
             # gradient launches); the head-segment SGD is issued on the heads' own stream, i.e. after those launches
             if need_grad and not ddp and not E.ONE_STREAM and _HEADS_ASIDE and _SGD_ASIDE and _DY_EVENT:
@@ -239,7 +239,7 @@ class Upstream_Expert(MocoQueueMixin, FusedExpertMixin, UpstreamModule):
                 # (nothing reads the fp32 head weights or their gradients again in this step)
                 early = streams[0] if _SGD_ASIDE else main
                 if not E.ONE_STREAM and _SGD_ASIDE and dy_event is None:
-                    early.wait_stream(main)
+                    E.fork(early, main)
                 with torch.cuda.stream(early):
                     if R.phase("sgd_heads", lambda: optimizer.step_tail(flat, self.head_offset())):
                         optimizer.mark_early(flat, self.head_offset())

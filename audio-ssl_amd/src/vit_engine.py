@@ -28,11 +28,11 @@ class ViTCtx:
     pass
 
 
-def _ln(x, g, b, M, C, eps):
+def _ln(x, g, b, M, C, eps, y32=None):
     y = torch.empty(M, C, dtype=torch.bfloat16, device=x.device)
     mean = torch.empty(M, dtype=torch.float32, device=x.device)
     rstd = torch.empty(M, dtype=torch.float32, device=x.device)
-    N.call("layernorm_fwd", x, g, b, y, mean, rstd, M, C, eps)
+    N.call("layernorm_fwd", x, g, b, y, y32, mean, rstd, M, C, eps)
     return y, mean, rstd
 
 

@@ -120,7 +120,7 @@ int audiossl_conv1_bwd(int dtype, int conv_dtype, const float* img, int N, int F
 
 /* ---- K7/K8 conv blocks 2,3: audiontt.py:52-60, 76-93 ----------------------------------------------------
  * colstats : per-column sum / sum of squares of x [G][M][C] (ld) in fp64 -> [G][C].  `groups` = independent batches that
- *            go through the same layer (the two views of the projector); C % 64 == 0.
+ *            go through the same layer (the two views of the projector); C % 8 == 0.
  * bn_finalize: train-mode BatchNorm statistics -> per-group scale/shift/mean/rstd [G][C]; running stats (momentum 0.1)
  *            are updated group after group, as the reference's successive module calls do.
  * bn_relu_pool_fwd: Y [N][Ti][Fi][64] -> P [N][Ti/2][Fi/2][64].   tmean_fwd: P -> xl [N][Fo*64] (x_1/x_2/x_3).
@@ -205,7 +205,8 @@ int audiossl_conv3x3_wgrad(const void* dY, const void* X, float* dWp, float* wor
  * Epilogue, in order: + bias[N]; ReLU; * keep[M][ldk] * keep_scale (dropout); zero where gate[M][ldg] <= 0;
  * + resid[M][ldr] (fp32, out-of-place residual connection of the transformer blocks; ksplit 1, not atomic);
  * store as dtype, or fp32 (out_f32), or accumulate into fp32 C: atomic = 1 by atomicAdd (required when ksplit > 1 or when
- * other launches may add to C concurrently), atomic = 2 by plain load-add-store (this launch owns C; ksplit 1). */
+ * other launches may add to C concurrently), atomic = 2 by plain load-add-store (this launch owns C; ksplit 1).
+ * ksplit > 1: the bias is added by the first split only; relu / keep / gate need the whole sum and are rejected. */
 int audiossl_gemm(int dtype, int trans_a, int trans_b, int M, int N, int K, float alpha, const void* A, long lda,
                   const void* B, long ldb, void* C, long ldc, const float* bias, int relu, const uint8_t* keep, long ldk,
                   float keep_scale, const void* gate, long ldg, int out_f32, int atomic, int ksplit, const float* resid,
@@ -367,7 +368,8 @@ int audiossl_softmax_rows_bwd(const float* y, const float* gy, float* gx, int M,
  *           tile per (clip, head); longer sequences (10 s clips: 1,212 tokens) walk 128-token blocks, B*H <= 65535.
  * attn_bwd: dout bf16 [B*S][H*64] -> dqkv bf16 [B*S][3*H*64].  `out` = what attn_fwd wrote (needed when S > 128: the
  *           multi-block backward takes D = rowsum(dout * out) from it; may be NULL for S <= 128).
- * layernorm_fwd: x fp32 [M][C] -> y bf16, mean / rstd fp32 [M] (C % 64 == 0, C <= 1024).
+ * layernorm_fwd: x fp32 [M][C] -> y bf16 (+ the same in fp32 into y32 when it is not NULL), mean / rstd fp32 [M] (C <= 1024;
+ *            the MViT widths are 96 * 2^k).
  * layernorm_bwd: dres fp32 [M][C] += dx (the residual-stream gradient accumulates in place); dgamma, dbeta += .
  * gelu_fwd / gelu_bwd: exact GELU on bf16, da = dh * gelu'(a).
  * patch_unfold: x fp32 [B][F][T] -> bf16 [B*nf*nt][256], 16x16 patches, strides (fstride, tstride), row = (b, pf, pt).
@@ -377,8 +379,8 @@ int audiossl_softmax_rows_bwd(const float* y, const float* gy, float* gx, int M,
 int audiossl_attn_fwd(const void* qkv, void* out, float* lse, int B, int S, int H, float scale, void* stream);
 int audiossl_attn_bwd(const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv, int B, int S, int H,
                       float scale, void* stream);
-int audiossl_layernorm_fwd(const float* x, const float* gamma, const float* beta, void* y, float* mean, float* rstd, int M,
-                           int C, float eps, void* stream);
+int audiossl_layernorm_fwd(const float* x, const float* gamma, const float* beta, void* y, float* y32, float* mean, float* rstd,
+                           int M, int C, float eps, void* stream);
 int audiossl_layernorm_bwd(const float* dy, const float* x, const float* mean, const float* rstd, const float* gamma,
                            float* dres, float* dgamma, float* dbeta, int M, int C, void* stream);
 int audiossl_gelu_fwd(const void* a, void* h, long n, void* stream);
@@ -387,6 +389,41 @@ int audiossl_patch_unfold(const float* x, void* out, int B, int F, int T, int fs
 int audiossl_tile_rows(const float* src, float* out, long rows, int period, int group, float scale, int C, void* stream);
 int audiossl_adamw(float* p, const float* g, float* m, float* v, long n, float lr, float beta1, float beta2, float eps,
                    float weight_decay, float grad_scale, const long long* step, void* stream);
+
+/* ---- MViTv2 pooling attention (the encoder SS-MAST instantiates: models_msn.py:147 -> ASTModel(model_size='mvit')):
+ * extras/mast_new/mast/mvit/models/attention.py:12-41 (attention_pool), :44-90 (cal_rel_pos_spatial), :93-302
+ * (MultiScaleAttention), :304-393 (MultiScaleBlock).  GEMMs are audiossl_gemm, LayerNorm over the width audiossl_layernorm_*.
+ * mvit_pool_fwd: one of q / k / v out of qkv bf16 [B*H*W][ldq] (column block starting at col0, head h at col0 + h*d) ->
+ *           out fp32 [B][heads][Ho*Wo][d] = LayerNorm_d(depthwise 3x3 conv, stride (sh, sw), pad 1, filters w [d][3][3] shared by
+ *           the heads); z / mean / rstd keep the conv output and its row statistics for the backward.  w == NULL: no pooling
+ *           on this path - the head split only (Ho = H, Wo = W, no LayerNorm).  d <= 128.
+ * mvit_pool_bwd: dout fp32 [B][heads][Ho*Wo][d] -> the tensor's column block of dqkv bf16 [B*H*W][ldq] (written, not
+ *           accumulated); dw [d][3][3], dgamma, dbeta accumulated; dz = scratch of dout's shape.
+ * mvit_attn_fwd: q [B][heads][qh*qw][d], k / v [B][heads][kh*kw][d] fp32 -> out bf16 [B*qh*qw][heads*d] =
+ *           softmax(scale q k^T + q . rh[ih[query row][key row]] + q . rw[iw[query col][key col]]) v (+ q when residual: the
+ *           residual pooling connection), lse fp32 [B][heads][qh*qw].  rh / rw fp32 [nrh | nrw][d] (both or neither), ih / iw
+ *           int32 [qh][kh], [qw][kw] row tables (device).  d in {64, 96, 128}.
+ * mvit_attn_bwd: dout bf16 [B*Lq][heads*d] -> dq fp32 (written), dk / dv fp32 and drh / drw (accumulated: zero them first).
+ * tokpool_max_fwd / _bwd: MaxPool2d((kh, kw), (sh, sw), padding (kh/2, kw/2)) over the token grid of x fp32 [B][H*W][C]
+ *           (the skip path of a block whose queries are pooled, attention.py:343-350); arg uint8 = tap of the maximum;
+ *           bwd writes dx (gathered per input token). */
+int audiossl_mvit_pool_fwd(const void* qkv, int ldq, int col0, const float* w, const float* gamma, const float* beta, float* out,
+                           float* z, float* mean, float* rstd, int B, int heads, int d, int H, int W, int Ho, int Wo, int sh, int sw,
+                           float eps, void* stream);
+int audiossl_mvit_pool_bwd(const void* qkv, int ldq, int col0, const float* w, const float* gamma, const float* dout, const float* z,
+                           const float* mean, const float* rstd, float* dz, float* dw, float* dgamma, float* dbeta, void* dqkv, int B,
+                           int heads, int d, int H, int W, int Ho, int Wo, int sh, int sw, void* stream);
+int audiossl_mvit_attn_fwd(const float* q, const float* k, const float* v, const float* rh, const float* rw, const int* ih,
+                           const int* iw, void* out, float* lse, int B, int heads, int d, int qh, int qw, int kh, int kw, int nrh,
+                           int nrw, int residual, float scale, void* stream);
+int audiossl_mvit_attn_bwd(const float* q, const float* k, const float* v, const float* rh, const float* rw, const int* ih,
+                           const int* iw, const void* dout, const float* lse, float* dq, float* dk, float* dv, float* drh, float* drw,
+                           int B, int heads, int d, int qh, int qw, int kh, int kw, int nrh, int nrw, int residual, float scale,
+                           void* stream);
+int audiossl_tokpool_max_fwd(const float* x, float* y, void* arg, int B, int H, int W, int C, int kh, int kw, int sh, int sw,
+                             void* stream);
+int audiossl_tokpool_max_bwd(const float* dy, const void* arg, float* dx, int B, int H, int W, int C, int kh, int kw, int sh, int sw,
+                             void* stream);
 
 /* ---- LARS: extras/delores-s/multi_proc.py:4-43, on the flat parameter buffer ---------------------------------------
  * seg: n_seg x {int64 offset, int64 numel, int32 flags (bit0 weight decay, bit1 trust ratio), int32 pad} (device);

@@ -141,3 +141,22 @@ def golden_case(cname):
     x = torch.from_numpy(fill.normalish((2, L, cfg["dim"]), 1500 + len(cname)))
     kw = {k: v for k, v in cfg.items() if k != "hw"}
     return P, x, kw, 1501 + len(cname)
+
+
+def mvit_encoder(P, x, blocks, fstride=10, tstride=10, final_norm=False, eps=1e-6):
+    """The encoder `ASTModel(model_size='mvit')` runs (`models/ast_work.py:101, 183-230`: 16 x 16 patch embedding with strides
+    (fstride, tstride), the MultiScaleBlocks, mean over the tokens; no position embedding, no final norm in the shipped forward)
+    plus the Linear the MoCo wrapper adds.  P: name -> tensor with the product's parameter names (`v.patch_embed.proj.*`,
+    `v.blocks.<i>.*`, `fc.*`); blocks: list of dicts with the keyword arguments of `multiscale_block` + `hw`.
+    x [B, 1, F, T] -> [B, out_dim].  UNPINNED as a whole (the reference builds this shell with timm, absent here): the blocks are
+    the pinned `multiscale_block`, the shell follows the call sites in ast_work.py / moco_model.py."""
+    t = F.conv2d(x, P["v.patch_embed.proj.weight"], P["v.patch_embed.proj.bias"], stride=(fstride, tstride))
+    hw = tuple(t.shape[-2:])
+    t = t.flatten(2).transpose(1, 2)
+    for i, b in enumerate(blocks):
+        kw = {k: v for k, v in b.items() if k != "hw"}
+        assert tuple(b["hw"]) == tuple(hw), (i, b["hw"], hw)
+        t, hw = multiscale_block(P, t, hw, prefix=f"v.blocks.{i}.", eps=eps, **kw)
+    if final_norm:
+        t = F.layer_norm(t, (t.shape[-1],), P["v.norm.weight"], P["v.norm.bias"], eps)
+    return F.linear(t.mean(1), P["fc.weight"], P["fc.bias"])

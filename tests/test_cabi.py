@@ -31,7 +31,7 @@ def test_argument_validation_happens_before_any_launch():
     assert lib.audiossl_gemm(1, 0, 0, 16, 16, 16, 1.0, 256, 16, 256, 16, 256, 16, None, 0, None, 0, 1.0, None, 0, 0, 0, 2, None, 0, None) == -1  # split-K needs atomic
     assert lib.audiossl_logmel_fwd(256, 256, 1, 16000, 101, 512, 160, 64, 45, 256, 256, 256, 256, 0.0, 0.0, 1, None) == -1   # n_fft != 1024
     assert lib.audiossl_logmel_fwd(256, 256, 1, 16000, 100, 1024, 160, 64, 45, 256, 256, 256, 256, 0.0, 0.0, 1, None) == -1  # T mismatch
-    assert lib.audiossl_colstats(1, 256, 1, 10, 60, 64, 1, 256, 256, None) == -1        # C % 64
+    assert lib.audiossl_colstats(1, 256, 1, 10, 60, 64, 1, 256, 256, None) == -1        # C % 8
     assert lib.audiossl_sgd_momentum(260, 256, 256, 8, 0.1, 0.9, 0.0, 1, 1.0, None, None, 0, None) == -3
 
 

@@ -109,11 +109,21 @@ def test_spherical_kmeans_vs_reference_cluster_memory(golden, case):
     out, cent = cluster_memory(mem, index, size_dataset, K, iters)
     out = out.cpu()
     assert torch.equal(out == -100, want_a == -100) and int((want_a == -100).sum()) == size_dataset - N
-    assert float((out == want_a).float().mean()) >= 0.999
     np.testing.assert_allclose(cent.cpu().numpy(), g[f"{case}.centroids"][-1], rtol=2e-5, atol=2e-6)
-    if case == "b":
-        seen = out[out >= 0]
-        empty = np.nonzero(np.bincount(seen.numpy(), minlength=K) == 0)[0]
+    if case == "a":
+        assert float((out == want_a).float().mean()) >= 0.999
+    else:
+        # case b is degenerate by construction (512 rows = copies of 20 directions, duplicate seeds): a point has the SAME dot
+        # product, to the last ulp or not, with the centroid of its copies and with every unused duplicate seed, so the label of
+        # the final arg-max is a coin toss between equal centroids.  What must hold: every point sits on a centroid that is
+        # optimal for it (dot within 2e-6 of the best), and the clusters the REFERENCE left empty still carry their seed.
+        ref_c = torch.from_numpy(g[f"{case}.centroids"][-1]).double()
+        dots = mem.cpu().double() @ ref_c.T
+        mine = out[index.cpu()]
+        got = dots[torch.arange(N), mine]
+        assert float((dots.max(1).values - got).max()) <= 2e-6
+        ref_seen = want_a[want_a >= 0]
+        empty = np.nonzero(np.bincount(ref_seen.numpy(), minlength=K) == 0)[0]
         assert len(empty) >= 12
         seeds = mem[torch.from_numpy(g[f"{case}.seed_idx"]).cuda()].cpu().numpy()
         np.testing.assert_allclose(cent.cpu().numpy()[empty], seeds[empty], rtol=1e-6, atol=1e-7)

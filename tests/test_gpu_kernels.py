@@ -76,6 +76,31 @@ def test_gemm_epilogue(N, dtype):
     assert rel_l2(out.float().cpu(), ref.cpu()) < (1e-5 if dtype == 0 else 4e-3)
 
 
+def test_linear_fwd_split_k_adds_the_bias_once(N):
+    """`engine.linear_fwd` on a tiny output with a long contraction (the 2048 -> 128 embedding layers: M = 512) splits K over
+    eight workgroups per tile with fp32 atomics; the bias comes from the first split only.  Also through the C ABI: relu with
+    ksplit > 1 is rejected."""
+    from src import engine as E
+    g = torch.Generator().manual_seed(29)
+    M, Nn, K = 512, 128, 2048
+    X = (torch.randn(M, K, generator=g) * 0.5).cuda().bfloat16()
+    W = (torch.randn(Nn, K, generator=g) * 0.05).cuda().bfloat16()
+    bias = torch.randn(Nn, generator=g).cuda()
+    N.PROFILE, N.PROFILE_ALL = {}, True
+    try:
+        out = E.linear_fwd(N.BF16, X, W, M, Nn, K, bias=bias, out_f32=1)
+        torch.cuda.synchronize()
+        args = N.PROFILE["audiossl_gemm"][0][2]
+    finally:
+        N.PROFILE, N.PROFILE_ALL = None, False
+    assert args[-2] == 8 and args[-3] == 1                       # (..., atomic, ksplit, ldr): ksplit 8, atomic accumulation
+    ref = X.double() @ W.double().T + bias.double()
+    assert out.dtype == torch.float32 and rel_l2(out.double().cpu(), ref.cpu()) < 1e-5
+    lib = N.lib()
+    assert lib.audiossl_gemm(1, 0, 0, M, Nn, K, 1.0, X.data_ptr(), K, W.data_ptr(), K, out.data_ptr(), Nn, bias.data_ptr(), 1, None, 0, 1.0,
+                             None, 0, 1, 1, 8, None, 0, None) == -1
+
+
 @pytest.mark.parametrize("shape", [(72, 200, 64, 200), (256, 128, 192, 128), (64, 104, 128, 105)])
 def test_gemm_exclusive_accumulate(N, shape):
     """atomic = 2: C += A^T B by plain load-add-store (the weight-gradient GEMMs without split-K); ldc = 105 breaks the
@@ -679,7 +704,10 @@ def test_gemm_multi_hand_scheduled_kernels(N):
              (0, 1, M, [2048, 1024, 512], [D] * 3, 1, 0),        # (full-batch form of the last data gradient)
              (1, 1, D, [D] * 3, [M] * 3, 1, 2),                  # weight gradients, exclusive accumulation
              (1, 1, D, [2048, 1024, 512], [M] * 3, 1, 0),        # first layer's weight gradient, store-only
-             (1, 1, D, [D] * 3, [512] * 3, 1, 0)]                # cross-correlation
+             (1, 1, D, [D] * 3, [512] * 3, 1, 0),                # cross-correlation
+             (0, 0, 512, [D] * 3, [D] * 3, 1, 0),                # dzn of view 1 (128 x 128 kernel)
+             (0, 1, 512, [D] * 3, [D] * 3, 1, 0),                # dzn of view 2
+             (0, 1, 512, [2048, 1024, 512], [D] * 3, 1, 0)]      # last data gradient (view 1 rows only)
     for ta, tb, m, Ns, Ks, f32, atomic in cases:
         As = [(torch.randn((k, m) if ta else (m, k), generator=g) * 0.5).cuda().bfloat16() for k in Ks]
         Bs = [(torch.randn((k, n) if tb else (n, k), generator=g) * 0.5).cuda().bfloat16() for n, k in zip(Ns, Ks)]
@@ -728,6 +756,11 @@ print("WORST", worst)
      [("NT", 1100, 392, 64), ("NT", 1100, 392, 128), ("NT", 700, 264, 192), ("NT", 520, 136, 256), ("NN", 1100, 392, 192),
       ("NN", 700, 264, 448), ("TN", 1096, 392, 192), ("TN", 696, 264, 448), ("NT", 1024, 2048, 2048), ("NN", 1024, 2048, 2048),
       ("TN", 2048, 1024, 1024)]),
+    # hand-scheduled 128 x 128 kernel (ring of five buffers): 1 ... 7 K-tiles, partial tiles, the heads' M = 512 shapes
+    ({"AUDIOSSL_GEMM_P6": "5", "AUDIOSSL_GEMM_P8": "0"},
+     [("NT", 600, 392, 64), ("NT", 600, 392, 128), ("NT", 300, 264, 192), ("NT", 520, 136, 256), ("NT", 130, 130, 320), ("NN", 600, 392, 384),
+      ("NN", 300, 264, 448), ("TN", 600, 392, 192), ("TN", 296, 264, 448), ("NT", 512, 2048, 2048), ("NN", 512, 2048, 2048),
+      ("NN", 6144, 512, 2048)]),
 ])
 def test_gemm_tile_variants_in_subprocess(env, shapes):
     """The tile variants that the default dispatch does not pick for these shapes (ring of every layout, 256x256 and 256x128

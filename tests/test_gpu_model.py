@@ -432,8 +432,11 @@ def test_delores_m_grouped_heads_match_per_head_path(cfg_m):
     (l0, g0), (l1, g1) = outs
     np.testing.assert_allclose(l1, l0, rtol=1e-4)
     assert set(g0) == set(g1)
+    # two separate runs: besides the grouping itself (different GEMM kernels), every fp32-atomic accumulation may land in another
+    # order (split-K weight gradients, statistics replicas, since round 3 the split-K embedding layers), and one flipped bf16
+    # rounding upstream moves the small BatchNorm-bias gradients of the first conv block by 1-2e-3
     for n in g0:
-        assert rel_l2(g1[n], g0[n]) < 2e-3, n
+        assert rel_l2(g1[n], g0[n]) < 3e-3, n
 
 
 def test_delores_m_eager_step_orders_main_stream_after_the_heads_weight_gradients(cfg_m):
@@ -462,6 +465,27 @@ def test_delores_m_eager_step_orders_main_stream_after_the_heads_weight_gradient
         final = em.flat.grad[ho:]
         assert float(final.abs().max()) > 0
         assert torch.equal(snap, final), f"repetition {rep}: the main stream read the head gradients before they were complete"
+
+
+def test_nested_stream_fork_is_refused_inside_a_capture_scope():
+    """Every side stream of a captured step is forked from the capture's origin stream and joined back into it.  A fork from an
+    already forked stream (round 2's experiment with the heads' weight gradients) ended in a segmentation fault inside
+    hipStreamEndCapture on ROCm 7.2; `engine.fork` refuses that topology while a capture scope is open, eagerly anything goes.
+    (The scope is opened without a capture here: the guard is host logic, the crash is not provoked.)"""
+    from src import engine as E
+    a, b = torch.cuda.Stream(), torch.cuda.Stream()
+    E.fork(a)
+    E.fork(b, a)                                                   # eager issue: allowed
+    torch.cuda.current_stream().wait_stream(b)
+    with E.capture_scope():
+        E.fork(a)                                                  # from the origin
+        with pytest.raises(RuntimeError, match="nested stream fork"):
+            E.fork(b, a)                                           # from a forked stream
+        with pytest.raises(RuntimeError, match="nested stream fork"):
+            with torch.cuda.stream(a):
+                E.SideStream().run(torch.device("cuda", torch.cuda.current_device()), lambda: None)
+        torch.cuda.current_stream().wait_stream(a)                 # joins are not forks
+    torch.cuda.synchronize()
 
 
 # ------------------------------------------------------------------------------------------------ hipGraph replay
