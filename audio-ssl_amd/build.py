@@ -30,13 +30,21 @@ def _stale(target, deps):
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def _compile(src, obj):
-    cmd = [HIPCC] + FLAGS + ["-c", src, "-o", obj]
+def _compile(src, obj, extra=()):
+    cmd = [HIPCC] + FLAGS + list(extra) + ["-c", src, "-o", obj]
     r = subprocess.run(cmd, capture_output=True, text=True)
     return src, r.returncode, r.stdout + r.stderr
 
 
-def build(force=False, jobs=None, verbose=True):
+def build(force=False, jobs=None, verbose=True, ablate=False):
+    """ablate: the diagnostics build - -DAUDIOSSL_ABLATE compiles in the ablation variants of the hand-scheduled kernels (no
+    MFMA / no DMA / no fragment reads ...: WRONG results by design, selected by AUDIOSSL_*_DBG) into lib/libaudiossl_hip_ablate.so;
+    tools load it through AUDIOSSL_LIB_PATH.  The product library never contains them."""
+    global OBJ, LIB
+    flags_extra = []
+    if ablate:
+        OBJ, LIB = os.path.join(HERE, "build_ablate"), os.path.join(LIBDIR, "libaudiossl_hip_ablate.so")
+        flags_extra = ["-DAUDIOSSL_ABLATE"]
     os.makedirs(OBJ, exist_ok=True)
     os.makedirs(LIBDIR, exist_ok=True)
     srcs = sorted(glob.glob(os.path.join(CSRC, "*.hip")))
@@ -50,7 +58,7 @@ def build(force=False, jobs=None, verbose=True):
     jobs = jobs or min(8, os.cpu_count() or 1)
     if todo:
         with cf.ThreadPoolExecutor(max_workers=jobs) as ex:
-            for src, rc, out in ex.map(lambda a: _compile(*a), todo):
+            for src, rc, out in ex.map(lambda a: _compile(*a, extra=flags_extra), todo):
                 if verbose or rc:
                     print(f"[hipcc] {os.path.basename(src)} rc={rc}")
                 if out.strip() and (rc or verbose):
@@ -72,6 +80,7 @@ if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--force", action="store_true")
     ap.add_argument("--jobs", type=int, default=None)
+    ap.add_argument("--ablate", action="store_true", help="diagnostics library with the ablation kernel variants (wrong results by design)")
     a = ap.parse_args()
-    build(a.force, a.jobs)
+    build(a.force, a.jobs, ablate=a.ablate)
     sys.exit(0)

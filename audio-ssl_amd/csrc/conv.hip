@@ -676,7 +676,13 @@ extern "C" int audiossl_conv3x3_fwd(const void* X, const void* W, const float* b
     if (!ASSL_ALIGNED16(X) || !ASSL_ALIGNED16(W) || !ASSL_ALIGNED16(Y)) return ASSL_EALIGN;
     hipStream_t s = static_cast<hipStream_t>(stream);
     // AUDIOSSL_CONV_DBG (diagnostics, tools/conv_fwd_ablate.py / conv_ts.py): 1 no epilogue, 2 no halo DMA, 4 no k-loop, 16 cycle stamps
+    // - honoured only by -DAUDIOSSL_ABLATE builds (python audio-ssl_amd/build.py --ablate): the shipped library cannot be switched
+    //   into a mode that produces wrong results
+#ifdef AUDIOSSL_ABLATE
     static const int conv_dbg = getenv("AUDIOSSL_CONV_DBG") ? atoi(getenv("AUDIOSSL_CONV_DBG")) : 0;
+#else
+    constexpr int conv_dbg = 0;
+#endif
     if (sum && !(conv_dbg & 16)) {
         if (sumsq == sum + 64) {
             ASSL_ZERO(sum, sizeof(double) * 128 * stat_replicas, s);
@@ -732,7 +738,11 @@ extern "C" int audiossl_conv3x3_wgrad(const void* dY, const void* X, float* dWp,
     const int grid = tiles < 256 ? tiles : 256;
     // workspace (optional): 2 * 256 * 64 * 576 floats cover every launch shape; without it the results go through atomics
     const bool two_stage = workspace != nullptr && workspace_floats >= (long)grid * CH * KTOT;
+#ifdef AUDIOSSL_ABLATE
     static const int wg_dbg = getenv("AUDIOSSL_CONV_DBG") ? atoi(getenv("AUDIOSSL_CONV_DBG")) : 0;
+#else
+    constexpr int wg_dbg = 0;
+#endif
     WgradArgs a{static_cast<const bf16*>(dY), static_cast<const bf16*>(X), dWp, Ti, rows, tiles, two_stage ? workspace : nullptr, wg_dbg};
     // measured in isolation (tools/conv_bench.py, B = 512): two-stage with the pixel split 122 / 46 us (32- / 16-wide layer),
     // without it 140 / 51 us; atomics 147 / 67 us without the split and 155 / 91 us with it (twice the atomics)

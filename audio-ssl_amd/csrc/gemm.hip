@@ -95,12 +95,10 @@ template <> struct Mma<float> {
 constexpr int EPI_PITCH = 65;                                    // floats; odd pitch: conflict-free row reads
 constexpr size_t EPI_LDS = sizeof(float) * 4 * 64 * EPI_PITCH;   // 66,560 B for four waves (8-wave workgroups: twice that)
 
-// MI = 32-row MFMA blocks per wave in M (wave tile = 32*MI x 64)
-template <typename T, int MI>
-__device__ __forceinline__ void epilogue_lds(const GemmArgs& g, f32x16 (&acc)[MI][2], char* smem, int row0, int col0, int lane,
-                                             int wave) {
-    __syncthreads();                                             // every wave is done with the staging buffers
-    float* ct = reinterpret_cast<float*>(smem) + wave * (32 * MI) * EPI_PITCH;
+// Accumulators -> the wave's fp32 tile [32 * MI][64] in LDS.  32x32 MFMA: C/D map col = lane & 31, row = (r & 3) + 8 * (r >> 2) +
+// 4 * (lane >> 5); 16x16 MFMA: col = lane & 15, row = 4 * (lane >> 4) + r.
+template <int MI>
+__device__ __forceinline__ void park(const f32x16 (&acc)[MI][2], float* ct, int lane) {
     const int half = lane >> 5, l31 = lane & 31;
 #pragma unroll
     for (int i = 0; i < MI; ++i)
@@ -108,7 +106,26 @@ __device__ __forceinline__ void epilogue_lds(const GemmArgs& g, f32x16 (&acc)[MI
         for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r)
-                ct[(i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half) * EPI_PITCH + j * 32 + l31] = acc[i][j][r];
+                ct[(i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half) * 65 + j * 32 + l31] = acc[i][j][r];
+}
+template <int MB>
+__device__ __forceinline__ void park(const f32x4 (&acc)[MB][4], float* ct, int lane) {
+    const int q = lane >> 4, c = lane & 15;
+#pragma unroll
+    for (int i = 0; i < MB; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) ct[(i * 16 + 4 * q + r) * 65 + j * 16 + c] = acc[i][j][r];
+}
+
+// MI = 32-row MFMA blocks per wave in M (wave tile = 32*MI x 64)
+template <typename T, int MI, typename ACC>
+__device__ __forceinline__ void epilogue_lds(const GemmArgs& g, ACC& acc, char* smem, int row0, int col0, int lane,
+                                             int wave) {
+    __syncthreads();                                             // every wave is done with the staging buffers
+    float* ct = reinterpret_cast<float*>(smem) + wave * (32 * MI) * EPI_PITCH;
+    park(acc, ct, lane);
     const int col = col0 + lane;
     if (col >= g.N) return;
     const float bias = (g.bias && blockIdx.z == 0) ? g.bias[col] : 0.f;      // split-K: the first split adds the bias
@@ -146,19 +163,12 @@ __device__ __forceinline__ void epilogue_lds(const GemmArgs& g, f32x16 (&acc)[MI
 // fp32), 8-byte keep-mask loads, 16-byte gate / residual loads.  The one-column-per-lane form above issues a 128-byte
 // store per row and wave - on the 6144 x 2048 Linear layers of the encoder the epilogue then took longer than the k-loop
 // (70 us at K = 512 against 113 us at K = 2048).  bf16 operands, non-atomic results, N % 8 == 0 and aligned operands only.
-template <int MI>
-__device__ __forceinline__ void epilogue_vec(const GemmArgs& g, f32x16 (&acc)[MI][2], char* smem, int row0, int col0, int lane,
+template <int MI, typename ACC>
+__device__ __forceinline__ void epilogue_vec(const GemmArgs& g, ACC& acc, char* smem, int row0, int col0, int lane,
                                              int wave) {
     __syncthreads();
     float* ct = reinterpret_cast<float*>(smem) + wave * (32 * MI) * EPI_PITCH;
-    const int half = lane >> 5, l31 = lane & 31;
-#pragma unroll
-    for (int i = 0; i < MI; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r)
-                ct[(i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half) * EPI_PITCH + j * 32 + l31] = acc[i][j][r];
+    park(acc, ct, lane);
     const int c8 = (lane & 7) * 8, rr = lane >> 3;
     const int col = col0 + c8;
     if (col >= g.N) return;
@@ -230,19 +240,12 @@ __device__ __forceinline__ void epilogue_vec(const GemmArgs& g, f32x16 (&acc)[MI
 
 // Row-softmax epilogues (MoCo InfoNCE, `delores_m/upstream_expert.py:250-264`): logits = alpha * acc are reduced / transformed
 // in the tile and never stored.  Same parking of the accumulators as above; a lane owns 8 consecutive columns of one of 8 rows.
-template <int MI>
-__device__ __forceinline__ void epilogue_softmax(const GemmArgs& g, f32x16 (&acc)[MI][2], char* smem, int row0, int col0, int lane,
+template <int MI, typename ACC>
+__device__ __forceinline__ void epilogue_softmax(const GemmArgs& g, ACC& acc, char* smem, int row0, int col0, int lane,
                                                  int wave) {
     __syncthreads();
     float* ct = reinterpret_cast<float*>(smem) + wave * (32 * MI) * EPI_PITCH;
-    const int half = lane >> 5, l31 = lane & 31;
-#pragma unroll
-    for (int i = 0; i < MI; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r)
-                ct[(i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half) * EPI_PITCH + j * 32 + l31] = acc[i][j][r];
+    park(acc, ct, lane);
     const int c8 = (lane & 7) * 8, rr = lane >> 3;
     const int col = col0 + c8;
     if (col0 >= g.N) return;                                   // the whole wave tile is outside (wave-uniform)
@@ -281,8 +284,9 @@ __device__ __forceinline__ void epilogue_softmax(const GemmArgs& g, f32x16 (&acc
     }
 }
 
-template <typename T, int MI>
-__device__ __forceinline__ void epilogue(const GemmArgs& g, f32x16 (&acc)[MI][2], char* smem, int row0, int col0, int lane, int wave) {
+// MI = 32-row blocks of the wave tile; ACC = f32x16 [MI][2] (32x32 MFMA) or f32x4 [2 * MI][4] (16x16 MFMA)
+template <typename T, int MI, typename ACC>
+__device__ __forceinline__ void epilogue(const GemmArgs& g, ACC& acc, char* smem, int row0, int col0, int lane, int wave) {
     if constexpr (sizeof(T) == 2) {
         if (g.lse_mode) { epilogue_softmax<MI>(g, acc, smem, row0, col0, lane, wave); return; }
         if (g.vec_epi) { epilogue_vec<MI>(g, acc, smem, row0, col0, lane, wave); return; }
@@ -1103,7 +1107,11 @@ int dispatch_p8_multi(const GemmMulti& gm, int count, int ksplit, int ta, int tb
 }
 
 int dispatch_p8(const GemmArgs& g, int ta, int tb, hipStream_t s) {
+#ifdef AUDIOSSL_ABLATE
     static const int dbg = getenv("AUDIOSSL_GEMM_P8_DBG") ? atoi(getenv("AUDIOSSL_GEMM_P8_DBG")) : 0;   // ablation (wrong results)
+#else
+    constexpr int dbg = 0;            // the ablation instantiations exist only in -DAUDIOSSL_ABLATE builds (python audio-ssl_amd/build.py --ablate)
+#endif
     if (!ta && !tb && dbg) {
         switch (dbg) {
             case 1: return launch_p8<false, false, 1>(g, s);      // no MFMA
@@ -1136,7 +1144,7 @@ int dispatch_p8(const GemmArgs& g, int ta, int tb, hipStream_t s) {
 //   * K-tiles past the end are staged from an offset beyond the buffer (zeros, no traffic): the counts stay uniform.
 constexpr int P6_PART = 16384, P6_BUF = 3 * P6_PART, P6_NBUF = 3;      // slot order inside a buffer: A(r0) B A(r1)
 
-template <bool TA, bool TB>
+template <bool TA, bool TB, int SCHED, int DBG = 0>
 __device__ __forceinline__ void p6_body(const GemmArgs& g, char* smem, int wg) {
     const int tiles_n = (g.N + 127) / 128;
     const int bm = (wg / tiles_n) * 256, bn = (wg % tiles_n) * 128;
@@ -1163,21 +1171,28 @@ __device__ __forceinline__ void p6_body(const GemmArgs& g, char* smem, int wg) {
 
     auto issue = [&](int slot, int t, int boff) {            // slot: 0 A(r0), 1 B, 2 A(r1)
         char* d = wdst + boff + slot * P6_PART;
-        const bool live = t < nk;
+        const bool live = t < nk && !((DBG & 2) && t >= 2);
         if (slot == 1) ob.issue(0, t, d, live); else oa.issue(slot >> 1, t, d, live);
     };
     Vec8<bf16> fa[4], fb[2][4];
+    if (DBG & 4) {
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) { fa[kk] = Vec8<bf16>::zero(); fb[0][kk] = Vec8<bf16>::zero(); fb[1][kk] = Vec8<bf16>::zero(); }
+    }
     auto loadA = [&](const char* img) {
+        if ((DBG & 4) && nk > 0) return;
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) fa[kk] = oa.frag(img, 0, kk, half);
     };
     auto loadB = [&](const char* img) {
+        if ((DBG & 4) && nk > 0) return;
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int kk = 0; kk < 4; ++kk) fb[j][kk] = ob.frag(img, j, kk, half);
     };
     auto mfma_half = [&](int X) {
+        if (DBG & 1) return;
         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk)
@@ -1228,6 +1243,115 @@ __device__ __forceinline__ void p6_body(const GemmArgs& g, char* smem, int wg) {
     epilogue<bf16, 2>(g, acc, smem, bm + wr * 64, bn + wc * 64, lane, wave);
 }
 
+// The 256 x 128 kernel with BALANCED load sections.  Ablations of p6_body on the three-head launch (M = 1,024, K = 2,048; -DAUDIOSSL_ABLATE
+// build, tools/heads_gemm_bench.py): 34.9 us in full; 26.7 without the fragment reads, 31.1 without the DMA, 25.6 without the MFMAs,
+// 24.5 with MFMAs and barriers alone, 18.7 with the barriers alone - i.e. ~9 us of launch / prologue / epilogue, an MFMA-paced loop
+// of 16.4 us, and ~10 us that the LOAD sections add because they are uneven: phase 1 reads 12 fragments and issues two parts (~380
+// cycles) beside the other wave group's 8 MFMAs (~276), phase 2 reads 4 and issues one (~140).  Here the B fragments of K-tile t + 1
+// are read in phase 2 of K-tile t (a second register set, the loop is unrolled over two K-tiles): phase 1 = 4 reads + two parts,
+// phase 2 = 12 reads + one part.  B(t + 1) must then have landed at the end of phase 1's LOAD section: all but the three youngest
+// parts (vmcnt(6)); phase 2's wait (all but the five youngest, vmcnt(10)) is already met.
+template <bool TA, bool TB>
+__device__ __forceinline__ void p6b_body(const GemmArgs& g, char* smem, int wg) {
+    const int tiles_n = (g.N + 127) / 128;
+    const int bm = (wg / tiles_n) * 256, bn = (wg % tiles_n) * 128;
+    const int ksteps = g.K / GBK;
+    const int per = (ksteps + g.ksplit - 1) / g.ksplit;
+    const int ks0 = blockIdx.z * per, ks1 = min(ksteps, ks0 + per);
+    if (ks0 >= ks1) return;
+    const int nk = ks1 - ks0;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, half = lane >> 5;
+    const int wr = wave >> 1, wc = wave & 1;
+
+    PartOp<TA, 32, 64> oa; PartOp<TB, 64, 64> ob;
+    oa.init(g.A, g.a_bytes, g.lda, bm, ks0 * GBK, wave, lane, wr);
+    ob.init(g.B, g.b_bytes, g.ldb, bn, ks0 * GBK, wave, lane, wc);
+    char* const wdst = smem + wave * 2048;
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    auto issue = [&](int slot, int t, int boff) {            // slot: 0 A(r0), 1 B, 2 A(r1)
+        char* d = wdst + boff + slot * P6_PART;
+        const bool live = t < nk;
+        if (slot == 1) ob.issue(0, t, d, live); else oa.issue(slot >> 1, t, d, live);
+    };
+    Vec8<bf16> fa[4], fb0[2][4], fb1[2][4];
+    auto loadA = [&](const char* img) {
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) fa[kk] = oa.frag(img, 0, kk, half);
+    };
+    auto loadB = [&](const char* img, Vec8<bf16> (&fb)[2][4]) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) fb[j][kk] = ob.frag(img, j, kk, half);
+    };
+    auto mfma_half = [&](int X, const Vec8<bf16> (&fb)[2][4]) {
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) Mma<bf16>::run(acc[X][j], fa[kk], fb[j][kk]);
+        __builtin_amdgcn_s_setprio(0);
+    };
+    auto load_end = [&]() {
+        __builtin_amdgcn_s_barrier();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    auto sync = [&]() {
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    int cb = 0, nb = P6_BUF, ib = 2 * P6_BUF;                // buffers of K-tiles t, t + 1, t + 2 (byte offsets)
+    auto advance = [&]() {
+        cb = nb; nb = ib;
+        ib = ib + P6_BUF == P6_NBUF * P6_BUF ? 0 : ib + P6_BUF;
+    };
+    // one K-tile: fbc = the B fragments of this K-tile (already in registers), fbn receives those of the next one
+    auto ktile = [&](int t, Vec8<bf16> (&fbc)[2][4], Vec8<bf16> (&fbn)[2][4]) {
+        loadA(smem + cb);
+        issue(0, t + 2, ib); issue(1, t + 2, ib);
+        wait_vm<6>();                                        // A(r1) of t and B of t + 1 have landed
+        load_end();
+        mfma_half(0, fbc);
+        sync();
+        loadA(smem + cb + 2 * P6_PART);
+        loadB(smem + nb + P6_PART, fbn);
+        issue(2, t + 2, ib);
+        wait_vm<10>();
+        load_end();
+        mfma_half(1, fbc);
+        sync();
+        advance();
+    };
+
+    issue(0, 0, 0); issue(1, 0, 0); issue(2, 0, 0);
+    issue(0, 1, P6_BUF); issue(1, 1, P6_BUF); issue(2, 1, P6_BUF);
+    wait_vm<8>();                                            // A(r0) and B of K-tile 0
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    loadB(smem + P6_PART, fb0);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    if (wave >= 4) { __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); }
+    for (int t = 0; t < nk; t += 2) {
+        ktile(t, fb0, fb1);
+        if (t + 1 < nk) ktile(t + 1, fb1, fb0);
+    }
+    if (wave < 4) { __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); }
+    wait_vm<0>();
+    epilogue<bf16, 2>(g, acc, smem, bm + wr * 64, bn + wc * 64, lane, wave);
+}
+
 // 128 x 128 output tile, 8 waves (4 x 2, wave tile 32 x 64): the same loop for the M = 512 problems (the heads' dzn / last data
 // gradient launches: 96 tiles of 256 x 128, 192 of 128 x 128) and single problems with a narrow output.  A K-tile is TWO 16 KB parts
 // (A: every wave's 32 rows, B: every wave's 64 columns) and ONE phase (8 MFMA 32x32x16 per wave); K-tile t + 3 is staged in
@@ -1236,7 +1360,7 @@ __device__ __forceinline__ void p6_body(const GemmArgs& g, char* smem, int wg) {
 // youngest K-tiles = vmcnt(8).  More LDS read bytes per MFMA than the 256-row kernels (12 fragment reads per 8 MFMAs).
 constexpr int P5_PART = 16384, P5_BUF = 2 * P5_PART, P5_NBUF = 5, P5_AHEAD = 3;
 
-template <bool TA, bool TB>
+template <bool TA, bool TB, int SCHED>
 __device__ __forceinline__ void p5_body(const GemmArgs& g, char* smem, int wg) {
     const int tiles_n = (g.N + 127) / 128;
     const int bm = (wg / tiles_n) * 128, bn = (wg % tiles_n) * 128;
@@ -1279,16 +1403,19 @@ __device__ __forceinline__ void p5_body(const GemmArgs& g, char* smem, int wg) {
         for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int kk = 0; kk < 4; ++kk) fb[j][kk] = ob.frag(img + P5_PART, j, kk, half);
-        issue(t + P5_AHEAD, ib);
-        wait_vm<8>();
+        if (SCHED == 0) { issue(t + P5_AHEAD, ib); wait_vm<8>(); }
+        else wait_vm<4>();                                   // K-tile t + 3 is issued inside the MFMA section below
         __builtin_amdgcn_s_barrier();
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-        for (int kk = 0; kk < 4; ++kk)
+        for (int kk = 0; kk < 4; ++kk) {
 #pragma unroll
             for (int j = 0; j < 2; ++j) Mma<bf16>::run(acc[0][j], fa[kk], fb[j][kk]);
+            if (SCHED == 1 && kk == 0) oa.issue(0, t + P5_AHEAD, wdst + ib, t + P5_AHEAD < nk);
+            if (SCHED == 1 && kk == 2) ob.issue(0, t + P5_AHEAD, wdst + ib + P5_PART, t + P5_AHEAD < nk);
+        }
         __builtin_amdgcn_s_setprio(0);
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_barrier();
@@ -1302,10 +1429,16 @@ __device__ __forceinline__ void p5_body(const GemmArgs& g, char* smem, int wg) {
     epilogue<bf16, 1>(g, acc, smem, bm + wr * 32, bn + wc * 64, lane, wave);
 }
 
-// KIND: 6 = 256 x 128 tiles (p6_body), 5 = 128 x 128 tiles (p5_body)
+// KIND: 6 = 256 x 128 tiles (p6_body / p6b_body), 5 = 128 x 128 tiles (p5_body, DMA issued inside the MFMA section: 25.1 -> 22.4 us on
+// the M = 512 launches; the same move changed nothing on the 256 x 128 kernel), 60 + bits = ablation builds of the 256 x 128 kernel
 template <bool TA, bool TB, int KIND>
 __device__ __forceinline__ void pk_body(const GemmArgs& g, char* smem, int wg) {
-    if constexpr (KIND == 6) p6_body<TA, TB>(g, smem, wg); else p5_body<TA, TB>(g, smem, wg);
+    if constexpr (KIND >= 60) p6_body<TA, TB, 0, KIND - 60>(g, smem, wg);              // ablation builds
+    else if constexpr (KIND == 6) {
+        // measured (three-head launches, tools/heads_gemm_bench.py): with a transposed B operand (two transposing reads per
+        // fragment) the balanced form is 5 % faster (39.6 -> 37.3 us), for K-contiguous operands the two are equal (35.3 us)
+        if constexpr (TB) p6b_body<TA, TB>(g, smem, wg); else p6_body<TA, TB, 0>(g, smem, wg);
+    } else p5_body<TA, TB, 1>(g, smem, wg);
 }
 
 template <bool TA, bool TB, int KIND>
@@ -1322,9 +1455,9 @@ __global__ __launch_bounds__(512) void gemm_pk_multi_kernel(GemmMulti gm) {
     pk_body<TA, TB, KIND>(gm.p[p], smem, wg);
 }
 template <int KIND> constexpr size_t pk_lds() {
-    return KIND == 6 ? ((size_t)P6_NBUF * P6_BUF > EPI_LDS * 2 ? (size_t)P6_NBUF * P6_BUF : EPI_LDS * 2) : (size_t)P5_NBUF * P5_BUF;
+    return KIND != 5 ? ((size_t)P6_NBUF * P6_BUF > EPI_LDS * 2 ? (size_t)P6_NBUF * P6_BUF : EPI_LDS * 2) : (size_t)P5_NBUF * P5_BUF;
 }
-template <int KIND> constexpr int pk_rows() { return KIND == 6 ? 256 : 128; }
+template <int KIND> constexpr int pk_rows() { return KIND != 5 ? 256 : 128; }
 
 template <bool TA, bool TB, int KIND>
 int launch_pk(const GemmArgs& g, hipStream_t s) {
@@ -1448,7 +1581,17 @@ static int dispatch_multi(const GemmMulti& gm, int count, int M, int N, int kmin
     // fit the chip in one round (the M = 1,024 layers and data gradients of the three heads: 192 workgroups); the 128 x 128 kernel
     // where even those are too few (M = 512: 96 -> 192 workgroups)
     if (p6 != 0 && hs_ok && M >= 256 && (p6 == 1 || (t6 >= 128 && t6 <= 288 && t8 < 128 && kmin >= 512)))
+    {
+#ifdef AUDIOSSL_ABLATE
+        static const int dbg = getenv("AUDIOSSL_GEMM_P6_DBG") ? atoi(getenv("AUDIOSSL_GEMM_P6_DBG")) : 0;     // ablation builds: WRONG results
+        if (dbg == 1) return launch_pk_multi<false, false, 61>(gm, count, ksplit, s);       // no MFMA
+        if (dbg == 2) return launch_pk_multi<false, false, 62>(gm, count, ksplit, s);       // no DMA after two K-tiles
+        if (dbg == 4) return launch_pk_multi<false, false, 64>(gm, count, ksplit, s);       // no fragment reads
+        if (dbg == 6) return launch_pk_multi<false, false, 66>(gm, count, ksplit, s);       // MFMA + barriers only
+        if (dbg == 7) return launch_pk_multi<false, false, 67>(gm, count, ksplit, s);       // barriers only
+#endif
         return dispatch_pk_multi<6>(gm, count, ksplit, trans_a, trans_b, s);
+    }
     if (p6 != 0 && hs_ok && (p6 == 5 || (p6 != 1 && t5 >= 96 && t5 <= 288 && t6 < 128 && kmin >= 512)))
         return dispatch_pk_multi<5>(gm, count, ksplit, trans_a, trans_b, s);
     // multi-problem launches: measured wins for the transposed-A weight gradients of the three heads (2048 x 2048 x 1024:
@@ -1550,7 +1693,8 @@ static int run_bf16(const GemmArgs& g, int trans_a, int trans_b, hipStream_t s) 
     if (p6 != 0 && p8_ok && !g.lse_mode && M >= 128 && N >= 128) {
         const long t5 = (long)ceil_div(M, 128) * ceil_div(N, 128) * ksplit, t6 = (long)ceil_div(M, 256) * ceil_div(N, 128) * ksplit,
                    t8 = (long)ceil_div(M, 256) * ceil_div(N, 256) * ksplit;
-        if (M >= 256 && (p6 == 1 || (t6 >= 128 && t6 <= 288 && t8 < 128 && K / ksplit >= 512))) return dispatch_pk<6>(g, trans_a, trans_b, s);
+        if (M >= 256 && (p6 == 1 || (t6 >= 128 && t6 <= 288 && t8 < 128 && K / ksplit >= 512)))
+            return dispatch_pk<6>(g, trans_a, trans_b, s);
         // measured (tools/gemm_shapes.py): NN 6144 x 512 x 2048 34.1 -> 25.8 us, TN 2048 x 512 x 6144 / 3 41.9 -> 32.2 us; with short K
         // loops (2048 x 2048 x 512 TN: 19.3 vs 17.9 us) and for K-contiguous operands on <= 128 tiles (the ring kernel: 20.2 vs 21.7 us)
         // the older kernels stay

@@ -12,7 +12,8 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _PKG = os.path.dirname(_HERE)
-LIB_PATH = os.path.join(_PKG, "lib", "libaudiossl_hip.so")
+# AUDIOSSL_LIB_PATH: diagnostics only (tools/ load the -DAUDIOSSL_ABLATE build through it)
+LIB_PATH = os.environ.get("AUDIOSSL_LIB_PATH") or os.path.join(_PKG, "lib", "libaudiossl_hip.so")
 HEADER_PATH = os.path.join(os.path.dirname(_PKG), "include", "audiossl_hip.h")
 
 F32, BF16 = 0, 1

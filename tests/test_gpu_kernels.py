@@ -754,8 +754,8 @@ print("WORST", worst)
     # hand-scheduled 256 x 128 kernel (three buffers): 1, 2, 3, 4 and 7 K-tiles, partial tiles in M and N, the heads' shapes
     ({"AUDIOSSL_GEMM_P6": "1", "AUDIOSSL_GEMM_P8": "0"},
      [("NT", 1100, 392, 64), ("NT", 1100, 392, 128), ("NT", 700, 264, 192), ("NT", 520, 136, 256), ("NN", 1100, 392, 192),
-      ("NN", 700, 264, 448), ("TN", 1096, 392, 192), ("TN", 696, 264, 448), ("NT", 1024, 2048, 2048), ("NN", 1024, 2048, 2048),
-      ("TN", 2048, 1024, 1024)]),
+      ("NN", 700, 264, 448), ("NN", 300, 200, 320), ("TN", 1096, 392, 192), ("TN", 696, 264, 448), ("TN", 296, 136, 128), ("NT", 1024, 2048, 2048),
+      ("NN", 1024, 2048, 2048), ("TN", 2048, 1024, 1024)]),
     # hand-scheduled 128 x 128 kernel (ring of five buffers): 1 ... 7 K-tiles, partial tiles, the heads' M = 512 shapes
     ({"AUDIOSSL_GEMM_P6": "5", "AUDIOSSL_GEMM_P8": "0"},
      [("NT", 600, 392, 64), ("NT", 600, 392, 128), ("NT", 300, 264, 192), ("NT", 520, 136, 256), ("NT", 130, 130, 320), ("NN", 600, 392, 384),
