@@ -9,6 +9,11 @@ def SSMAST(config, emb_dim=256):
     inp = pre["input"]
     be = pre["base_encoder"]
     t_dim = 1 + int(inp["length_wave"] * inp["sampling_rate"]) // 160
+    if be.get("model_size", "base224") == "mvit":
+        # what the reference's SS-MAST really instantiates (`extras/mast_new/mast/models_msn.py:147`): the MViTv2 encoder;
+        # `base_encoder.mvit` = overrides of `mvit_engine.stage_layout` (default: configs/MVITv2_B.yaml)
+        return ASTModel(label_dim=emb_dim, fstride=be.get("fstride", 10), tstride=be.get("tstride", 10), input_fdim=inp["n_mels"],
+                        input_tdim=t_dim, model_size="mvit", mvit=be.get("mvit"))
     return ASTModel(label_dim=emb_dim, fstride=be.get("fstride", 10), tstride=be.get("tstride", 10), input_fdim=inp["n_mels"],
                     input_tdim=t_dim, embed_dim=be.get("output_dim", 768), depth=be.get("depth", 12),
                     num_heads=be.get("num_heads", 12))

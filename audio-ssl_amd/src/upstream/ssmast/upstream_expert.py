@@ -17,7 +17,6 @@ import torch.nn as nn
 
 from src import _native as N
 from src import engine as E
-from src import vit_engine as VE
 from src.module_base import UpstreamModule
 from src.upstream.common import EAGER, FusedExpertMixin, FusedStepFn, MocoQueueMixin, _world
 from src.upstream.ssmast.upstream_encoder import SSMAST
@@ -65,41 +64,70 @@ class Upstream_Expert(MocoQueueMixin, FusedExpertMixin, UpstreamModule):
 
     # ---- fused step ----------------------------------------------------------------------------------------------------
     def fused_loss(self, img_1, img_2, need_grad=True, runner=None):
+        """Both directions of `Moco_v2.training_step` (`extras/mast_new/mast/moco_model.py:253-340`).  The work is written as
+        collective-free phases handed to `runner` (query forward, key EMA + forward, InfoNCE, enqueue per direction, then the two
+        backwards): eager issue runs them in place, the data-parallel graph step captures each into its own hipGraph
+        (`common.GraphPhases`) with the collectives - batch shuffle / unshuffle, key gather, gradient all-reduce - in between."""
+        R = runner or EAGER
         flat = self.ensure_flat()
         ddp = _world() > 1
-        if need_grad:
-            flat.zero_grad()
         eq, ek = self.encoder_q, self.encoder_k
-        flat.refresh_shadow(N.BF16)               # one cast launch: bf16 copies of every query-encoder weight
-        Pq, Wq = eq.param_dict(), flat.shadow_dict("encoder_q.")
-        G = flat.grad_dict("encoder_q.")
         T = float(self.hparams.softmax_temperature)
-        loss = torch.zeros(2, dtype=torch.float32, device=img_1.device)
+        dev = img_1.device
         img_1, img_2 = img_1.float().contiguous(), img_2.float().contiguous()
+        Pq = eq.param_dict()
+        G = flat.grad_dict("encoder_q.")
+
+        def prep_phase():
+            if need_grad:
+                flat.zero_grad()
+            flat.refresh_shadow(N.BF16)               # one cast launch: bf16 copies of every query-encoder weight
+            return torch.zeros(2, dtype=torch.float32, device=dev)
+        loss = R.phase("prep", prep_phase)
+        Wq = flat.shadow_dict("encoder_q.")
+        shadow = self.queue_shadow(N.BF16)            # bf16 copy of the queue, kept current by `enqueue` (no per-pass cast of 65,536 keys)
         ctxs, dqs = [], []
         for d, (xq, xk) in enumerate(((img_1, img_2), (img_2, img_1))):
-            q, c = VE.vit_forward(Pq, Wq, xq, eq.cfg, need_ctx=need_grad)
-            self._momentum_update_key_encoder()
+            q, c = R.phase(f"query{d}", lambda xq=xq: eq.engine_forward(Pq, Wq, xq, eq.cfg, need_ctx=need_grad))
             idx_unshuffle = None
             if ddp:
                 xk, idx_unshuffle = self._batch_shuffle_ddp(xk)
-            self.flat_k.refresh_shadow(N.BF16)    # the key weights just moved
-            k, _ = VE.vit_forward(ek.param_dict(), self.flat_k.shadow_dict(), xk, ek.cfg, need_ctx=False)
+                xk = R.static(f"key_in{d}", xk.contiguous())
+
+            def key_phase(xk=xk):
+                self._momentum_update_key_encoder()
+                self.flat_k.refresh_shadow(N.BF16)    # the key weights just moved
+                return ek.engine_forward(ek.param_dict(), self.flat_k.shadow_dict(), xk, ek.cfg, need_ctx=False)[0]
+            k = R.phase(f"key{d}", key_phase)
             if ddp:
-                k = self._batch_unshuffle_ddp(k.contiguous(), idx_unshuffle)
-            shadow = E.cast(N.BF16, self.queue)
-            dq, kn32 = E.moco_forward_backward(N.BF16, q, k, self.queue, shadow, T, loss[d:d + 1], backward=need_grad)
-            self._dequeue_and_enqueue(kn32, None)
+                k = R.static(f"key_out{d}", self._batch_unshuffle_ddp(k.contiguous(), idx_unshuffle))
+            dq, kn32 = R.phase(f"moco{d}", lambda q=q, k=k, d=d: E.moco_forward_backward(
+                N.BF16, q, k, self.queue, shadow, T, loss[d:d + 1], backward=need_grad))
+            if ddp:
+                from src.utils import concat_all_gather
+                kn32 = R.static(f"keys{d}", concat_all_gather(kn32))
+            R.phase(f"enqueue{d}", lambda kn32=kn32: self._enqueue_local(kn32, shadow))
             ctxs.append(c)
             dqs.append(dq)
         if need_grad:
-            for c, dq in zip(ctxs, dqs):
-                VE.vit_backward(c, Pq, Wq, G, dq.float())
+            def backward_phase():
+                for c, dq in zip(ctxs, dqs):
+                    eq.engine_backward(c, Pq, Wq, G, dq.float())
+                return loss.sum()
+            total = R.phase("backward", backward_phase)
             self.reduce_begin("enc")
+            return total
         return loss.sum()
 
+    @torch.no_grad()
+    def _enqueue_local(self, keys32, shadow):
+        """`_dequeue_and_enqueue` (`moco_model.py:187-204`) after the key gather: keys32 holds the keys of EVERY rank."""
+        K = self.hparams.num_negatives
+        assert K % keys32.shape[0] == 0  # for simplicity
+        N.call("enqueue", self.precision, keys32, keys32.shape[0], keys32.shape[1], K, 0, self.queue_ptr, self.queue, shadow)
+
     def graph_phases_supported(self):
-        return False                              # the step is not cut into collective-free phases yet: eager on >1 ranks
+        return True
 
     def forward(self, img_q=None, img_k=None, epoch=None):
         raise NotImplementedError("the HIP expert fuses forward and loss; call training_step((img_1, img_2), i)")

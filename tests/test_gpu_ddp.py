@@ -28,7 +28,19 @@ def _worker(rank, world, port, which, steps, graph, ret):
         from helpers import closed_queue, views
         from src.encoder import AudioNTT2020Task6
         B, T, K = 16, 96, 256
-        if which == "delores_m":
+        mk = views
+        if which.startswith("ssmast"):
+            from src.upstream.ssmast.upstream_expert import Upstream_Expert
+            B, T, K = 8, 101, 64
+            be = {"type": "MAST", "output_dim": 768, "depth": 2, "num_heads": 12, "fstride": 10, "tstride": 10, "return_all_layers": False}
+            if which == "ssmast_mvit":                      # the MViTv2 encoder, three blocks with one stage transition
+                be.update(model_size="mvit", mvit=dict(depth=3, dim_mul=((1, 2.0),), head_mul=((1, 2.0),), q_strides=((1, 2, 2),)))
+            cfg = {"run": {"batch_size": 8, "precision": "bf16"},
+                   "pretrain": {"base_encoder": be, "normalization": "mean_var",
+                                "input": {"type": "raw_wav", "sampling_rate": 16000, "length_wave": 1.0, "n_mels": 128}}}
+            m = Upstream_Expert(cfg, num_negatives=K)
+            mk = lambda b, t, salt: torch.cat([views(b, t, salt), views(b, t, salt + 5000)], dim=2).contiguous()
+        elif which == "delores_m":
             from src.upstream.delores_m.upstream_expert import Upstream_Expert
             cfg = copy.deepcopy(CFG_M)
             cfg["run"]["precision"] = "bf16"
@@ -39,17 +51,17 @@ def _worker(rank, world, port, which, steps, graph, ret):
             cfg["run"]["precision"] = "bf16"
             m = Upstream_Expert(cfg, base_encoder=AudioNTT2020Task6)
         fill.fill_state_dict_(m, seed=33)                      # identical weights on both ranks
-        if which == "delores_m":
+        if which == "delores_m" or which.startswith("ssmast"):
             for pq, pk in zip(m.encoder_q.parameters(), m.encoder_k.parameters()):
                 pk.data.copy_(pq.data)
-            m.queue.copy_(closed_queue(128, K))
+            m.queue.copy_(closed_queue(m.queue.shape[0], K))
         m = m.cuda().train()
         opt = m.configure_optimizers()
         step = m.graphed_step(opt, eager_steps=1) if graph else None
         losses = []
         for s in range(steps):
-            a = views(B, T, 9300 + 10 * s + rank).cuda()       # different clips per rank
-            b = views(B, T, 9350 + 10 * s + rank).cuda()
+            a = mk(B, T, 9300 + 10 * s + rank).cuda()          # different clips per rank
+            b = mk(B, T, 9350 + 10 * s + rank).cuda()
             if step is not None:
                 loss = step(a, b)
             else:
@@ -62,9 +74,11 @@ def _worker(rank, world, port, which, steps, graph, ret):
         torch.cuda.synchronize()
         out = {"losses": losses, "w": {n: p.detach().float().cpu().numpy() for n, p in m.named_parameters()},
                "graphs": None if step is None else (sorted(step.phases.graphs), step.phases.broken)}
-        if which == "delores_m":
+        if which == "delores_m" or which.startswith("ssmast"):
             out["queue"] = m.queue.cpu().numpy()
             out["ptr"] = int(m.queue_ptr[0])
+        if which.startswith("ssmast"):
+            out["shadow_ok"] = bool(torch.equal(m.queue_shadow(1).float(), m.queue.bfloat16().float()))
         ret[rank] = out
     finally:
         dist.destroy_process_group()
@@ -243,3 +257,111 @@ def test_two_rank_sync_batchnorm_equals_one_rank_on_the_whole_batch():
     for k in ("rm1", "rv3", "rmp", "rvp"):
         np.testing.assert_allclose(r0[k], one[k], rtol=2e-4, atol=1e-6, err_msg=k)
         np.testing.assert_array_equal(r0[k], r1[k], err_msg=k)
+
+
+@pytest.mark.parametrize("which", ["ssmast", "ssmast_mvit"])
+def test_two_rank_ssmast_eager_and_graph_phases(which):
+    """BASELINE config 4 is an 8-GPU configuration: the SS-MAST step (`extras/mast_new/mast/moco_model.py:253-340`: both directions,
+    batch shuffle / unshuffle around the key encoder, key gather before each enqueue, one all-reduce of the flat gradient, AdamW)
+    on two ranks sharing the GPU over gloo - with the AST-base blocks and with the MViTv2 pooling-attention blocks.  Replicas stay
+    bit-identical, the queue advances by twice the GLOBAL batch per step and its bf16 shadow follows it; the graph-phase step
+    (one hipGraph per collective-free phase) reproduces the eagerly issued one."""
+    from helpers import rel_l2
+    steps = 3
+    e0, e1 = _run(which, steps=steps, graph=False)
+    assert all(np.isfinite(e0["losses"])) and e0["losses"] != e1["losses"]
+    for n in e0["w"]:
+        np.testing.assert_array_equal(e0["w"][n], e1["w"][n], err_msg=n)
+    assert e0["ptr"] == e1["ptr"] == (steps * 2 * 2 * 8) % 64
+    np.testing.assert_array_equal(e0["queue"], e1["queue"])
+    assert e0["shadow_ok"] and e1["shadow_ok"]
+    assert not np.array_equal(e0["w"]["encoder_q.fc.weight"], e0["w"]["encoder_k.fc.weight"])
+    g0, g1 = _run(which, steps=steps, graph=True)
+    names, broken = g0["graphs"]
+    assert broken is None and g1["graphs"][1] is None
+    assert set(names) == {"prep", "query0", "key0", "moco0", "enqueue0", "query1", "key1", "moco1", "enqueue1", "backward"}
+    for n in g0["w"]:
+        np.testing.assert_array_equal(g0["w"][n], g1["w"][n], err_msg=n)
+    np.testing.assert_allclose(g0["losses"], e0["losses"], rtol=2e-3)
+    assert g0["ptr"] == e0["ptr"] and g0["shadow_ok"]
+    for n in g0["w"]:
+        assert rel_l2(torch.from_numpy(g0["w"][n]), torch.from_numpy(e0["w"][n])) < 2e-2, n
+
+
+def _downstream_steps(world, rank):
+    """Two optimisation steps of the frozen-encoder linear probe on this rank's slice of fixed 16-clip batches (train() mode:
+    BatchNorm on batch statistics), after `train_downstream.sync_replicas` -> final weights, losses, a running statistic."""
+    import importlib.util
+    from oracle import fill
+    from helpers import drop_mask, views
+    from src import _native as N
+    from src import engine as E
+    from src.downstream import DownstreamEncoder
+    from src.encoder import AudioNTT2020Task6
+    from src.utils import freeze_encoder
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("train_downstream_hip", os.path.join(root, "audio-ssl_amd", "train_downstream.py"))
+    td = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(td)
+    dcfg = {"downstream": {"finetune_layer": -1, "base_encoder": {"return_all_layers": False, "output_dim": 2048}, "input": {"n_mels": 64}}}
+    B, T, C = 16, 96, 7
+    torch.manual_seed(1000 + 17 * rank)                         # every rank draws ANOTHER random head, as separate processes do
+    model = DownstreamEncoder(dcfg, None, AudioNTT2020Task6, C)
+    sd = model.state_dict()
+    enc = {k: v for k, v in sd.items() if k.startswith("encoder.")}
+    fill.fill_state_dict_(model.encoder, seed=23)               # the (pre-trained) encoder is the same file on every rank
+    model = model.cuda()
+    model.encoder.precision = N.F32
+    freeze_encoder(model)
+    head_before = model.final.weight.detach().cpu().clone()
+    td.sync_replicas(model, world)
+    try:
+        tr = td.ProbeTrainer(model, lr=1e-2)
+        model.train()
+        lo, hi = rank * (B // world), (rank + 1) * (B // world)
+        losses = []
+        for s in range(2):
+            x = views(B, T, 9850 + s)[lo:hi]
+            y = torch.from_numpy((fill.uniform01((B,), 9860 + s) * C).astype(np.int64))[lo:hi]
+            model.encoder.dropout_masks.queue = [drop_mask((B, T // 8, 2048), 9870 + s)[lo:hi]]
+            losses.append(float(tr.step(x.cuda(), y.cuda())))
+        torch.cuda.synchronize()
+    finally:
+        E.set_sync_bn(None)
+    return {"head0": head_before.numpy(), "w": model.final.weight.detach().cpu().numpy(), "b": model.final.bias.detach().cpu().numpy(),
+            "losses": losses, "rm": model.encoder.features_1[1].running_mean.cpu().numpy()}
+
+
+def _worker_downstream(rank, world, port, ret):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        ret[rank] = _downstream_steps(world, rank)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_downstream_probe_is_one_model():
+    """`train_downstream.py:80-85` of the reference wraps the model in SyncBatchNorm + DistributedDataParallel: rank 0's parameters
+    everywhere, BatchNorm on the global batch.  Here: two ranks that drew DIFFERENT random heads end up, after `sync_replicas`
+    and two all-reduced Adam steps on 8 clips each, bit-identical to each other and equal to ONE rank training rank 0's head on
+    all 16 clips (fp32 path: 2e-4 on the losses, 2e-3 on the head)."""
+    from helpers import rel_l2
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker_downstream, args=(2, port, ret), nprocs=2, join=True)
+    r0, r1 = ret[0], ret[1]
+    assert not np.array_equal(r0["head0"], r1["head0"])             # they really started apart
+    np.testing.assert_array_equal(r0["w"], r1["w"])
+    np.testing.assert_array_equal(r0["b"], r1["b"])
+    np.testing.assert_array_equal(r0["rm"], r1["rm"])
+    one = _downstream_steps(1, 0)                                   # same seed as rank 0: the head rank 0 broadcast
+    np.testing.assert_array_equal(one["head0"], r0["head0"])
+    for s in range(2):
+        assert abs(0.5 * (r0["losses"][s] + r1["losses"][s]) - one["losses"][s]) <= 2e-4 * abs(one["losses"][s])
+    assert rel_l2(torch.from_numpy(r0["w"]), torch.from_numpy(one["w"])) < 2e-3
+    np.testing.assert_allclose(r0["rm"], one["rm"], rtol=2e-4, atol=1e-6)

@@ -319,7 +319,20 @@ def test_delores_m_full_config_b512_k65536_bf16_vs_fp32_path(cfg_m):
     ref.training_loss(a.cpu(), b.cpu(), mq, mk, rparts).backward()
     rn, rnorm, _ = grad_digest(ref)
     want4 = np.array([float(rparts[k]) for k in ("ce", "b1", "b2", "b3")])
+    rgrads = {n: p.grad.clone() for n, p in ref.named_parameters() if p.grad is not None}
     del ref
+    # the bf16 bar at FULL size: the oracle's own modules under torch.autocast(bfloat16) (PyTorch's AMP recipe), same inputs
+    amp = OM.DeloresMExpert(copy.deepcopy(cfg_m), num_negatives=K)
+    fill.fill_state_dict_(amp, seed=13)
+    for pq, pk in zip(amp.encoder_q.parameters(), amp.encoder_k.parameters()):
+        pk.data.copy_(pq.data)
+    amp.queue.copy_(closed_queue(128, K))
+    amp.train()
+    with torch.autocast("cpu", dtype=torch.bfloat16):
+        la = amp.training_loss(a.cpu(), b.cpu(), mq, mk)
+    la.backward()
+    e_amp = {n: rel_l2(p.grad, rgrads[n]) for n, p in amp.named_parameters() if p.grad is not None}
+    del amp
     for prec in ("fp32", "bf16"):
         em = Upstream_Expert(_cfg(cfg_m, prec), base_encoder=AudioNTT2020Task6, num_negatives=K)
         fill.fill_state_dict_(em, seed=13)
@@ -336,9 +349,7 @@ def test_delores_m_full_config_b512_k65536_bf16_vs_fp32_path(cfg_m):
         names, norms, _ = grad_digest(em)
         outs[prec] = dict(loss=float(loss), parts=parts["losses"].cpu().numpy(), names=names, norms=norms,
                           ptr=int(em.queue_ptr[0]), keys=em.queue[:, :B].float().cpu(), tail=em.queue[:, B:B + 64].float().cpu(),
-                          grads={n: p.grad.float().cpu() for n, p in em.named_parameters() if p.grad is not None
-                                 and n in ("encoder_q.fc.weight", "encoder_q.encoder.fc.3.weight", "p1.projector.6.weight",
-                                           "encoder_q.encoder.features_3.0.weight", "encoder_q.encoder.features_2.0.weight")})
+                          grads={n: p.grad.float().cpu() for n, p in em.named_parameters() if p.grad is not None})
         assert all(bool(torch.isfinite(p.grad).all()) for p in em.parameters() if p.grad is not None)
         del em
         torch.cuda.empty_cache()
@@ -354,8 +365,23 @@ def test_delores_m_full_config_b512_k65536_bf16_vs_fp32_path(cfg_m):
     assert torch.equal(f["tail"], closed_queue(128, K)[:, B:B + 64])        # columns past the pointer untouched
     assert h["names"] == f["names"]
     _check_grad_norms(h["names"], h["norms"], f["norms"], "bf16")
-    for n in f["grads"]:
-        assert rel_l2(h["grads"][n], f["grads"][n]) < 0.25, n
+    # EVERY gradient tensor at full size, against the CPU oracle: the fp32 path within 5e-3; the bf16 path at least as close to
+    # the fp32 oracle as the oracle's own autocast(bfloat16) run (10 % slack), which is the bar of the B = 32 test taken to
+    # batch 512 / queue 65,536.  (Conv biases in front of a train-mode BatchNorm have zero gradient: rounding residue, skipped.)
+    worse, worst = [], (None, 0.0, 0.0)
+    for n, gr in rgrads.items():
+        if n.endswith(".0.bias") and "features" in n:
+            continue
+        # two fp32 implementations with different summation orders: 2e-3 at B = 32; at B = 512 the first projector layers (three
+        # train-mode BatchNorm backwards behind them, |column mean| ~ 10 sigma inputs) reach 2.8e-3
+        assert rel_l2(f["grads"][n], gr) < 5e-3, (n, rel_l2(f["grads"][n], gr))
+        e_hip = rel_l2(h["grads"][n], gr)
+        if e_hip > worst[1]:
+            worst = (n, e_hip, e_amp[n])
+        if e_hip > 1.1 * e_amp[n] + 5e-3:
+            worse.append((n, round(e_hip, 4), round(e_amp[n], 4)))
+    print("largest bf16 gradient deviation at B = 512 (tensor, HIP, autocast oracle):", worst)
+    assert not worse, worse
 
 
 @pytest.mark.parametrize("prec", ["fp32", "bf16"])
