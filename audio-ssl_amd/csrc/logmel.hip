@@ -191,10 +191,12 @@ __device__ __forceinline__ void wave_fence() { asm volatile("" ::: "memory"); } 
 constexpr int EXW = 576;                // float2 exchange buffer of a wave (512 + 512 / 8 padding)
 constexpr int PWW = 576;                // floats: 513 power bins + zero tail up to the last aligned mel chunk
 // Output staging: a wave collects up to OTF consecutive frames of its run in an LDS tile [mel row][frame] and writes them out as
-// row segments of OTF * 4 = 64 contiguous bytes (16 lanes per mel row, 4 rows per store instruction).  Storing each frame on its
+// row segments of up to OTF * 4 = 128 contiguous bytes (32 lanes per mel row, 2 rows per store instruction).  Storing each frame on its
 // own - one float per lane, lane = mel row, 4 * T bytes apart - made every store instruction 64 partial-line writes: 140 MB left
 // the L2 per launch for 13.2 MB of output (PMC WRITE_SIZE, round 2).
-constexpr int OTF = 16, OTP = OTF + 1;  // frames per tile; row pitch in floats (odd: the per-frame column writes are conflict-free)
+constexpr int OTF = 32, OTP = OTF + 1;  // frames per tile; row pitch in floats (odd: the per-frame column writes are conflict-free)
+// (OTF = 16: 64-byte segments at the 404-byte row pitch of T = 101 straddle three 32-byte sectors - 23.1 MB left the L2 for 13.2 MB
+// of output; at B = 512 a wave's run is 25-26 frames of one clip, so 32 columns give ONE flush of ~100-byte segments per run)
 
 template <int MPL, int NCH>
 __global__ __launch_bounds__(256) void logmel2_kernel(LogmelArgs a, int total_frames) {
@@ -315,13 +317,14 @@ __global__ __launch_bounds__(256) void logmel2_kernel(LogmelArgs a, int total_fr
         }
         wave_fence();
         // ---- flush the tile when it is full, at the end of a clip (the next frame belongs to another clip's rows) and at the
-        //      end of the run: frames t - tl .. t of clip b, 16 lanes per mel row
+        //      end of the run: frames t - tl .. t of clip b, OTF lanes per mel row
         if (tl == OTF - 1 || t == a.T - 1 || f == f1 - 1) {
-            const int col = lane & 15, t0 = t - tl;
+            const int col = lane & (OTF - 1), t0 = t - tl;
             float* const dst = a.out + (long)b * a.n_mels * a.T + t0 + col;
+            constexpr int RPI = 64 / OTF;                    // mel rows per store instruction
 #pragma unroll 4
-            for (int i = 0; i < 16 * MPL; ++i) {
-                const int row = 4 * i + (lane >> 4);
+            for (int i = 0; i < 64 * MPL / RPI; ++i) {
+                const int row = RPI * i + lane / OTF;
                 const float v = ot[row * OTP + col];
                 if (col <= tl && row < a.n_mels) dst[(long)row * a.T] = v;
             }

@@ -236,8 +236,8 @@ class GraphedStep:
                 self.graphs.append(g)
             self.graph, self.loss = self.graphs[0], self.losses[0]
             self.key = key
-        self.in_1.copy_(img_1)
-        self.in_2.copy_(img_2)
+        E.fast_copy(self.in_1, img_1)
+        E.fast_copy(self.in_2, img_2)
         i = self.replays % len(self.graphs)
         self.graphs[i].replay()
         self.replays += 1

@@ -13,6 +13,8 @@ steps = int(sys.argv[2]) if len(sys.argv) > 2 else 10
 graph = (sys.argv[3] != "eager") if len(sys.argv) > 3 else True
 T = int(sys.argv[4]) if len(sys.argv) > 4 else 101          # frames: 101 = 1 s (108 patches), 1001 = 10 s (1,188 patches: block-walking attention)
 CFG["pretrain"]["input"]["length_wave"] = (T - 1) / 100.0
+if len(sys.argv) > 5 and sys.argv[5] == "mvit":            # the MViTv2-B encoder SS-MAST instantiates (pooling attention, 24 blocks)
+    CFG["pretrain"]["base_encoder"]["model_size"] = "mvit"
 torch.manual_seed(0)
 ex = Upstream_Expert(copy.deepcopy(CFG), num_negatives=65536).cuda().train()
 opt = ex.configure_optimizers()
