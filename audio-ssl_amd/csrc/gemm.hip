@@ -1129,229 +1129,6 @@ int dispatch_p8(const GemmArgs& g, int ta, int tb, hipStream_t s) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-// 256 x 128 output tile, 8 waves (4 x 2, wave tile 64 x 64): the hand-scheduled loop for the M = 1,024 problems of the projector
-// heads.  There the 256 x 256 kernel has 96 tiles for 256 CUs (three heads, 32 tiles each) and the 128 x 128 kernels need as many
-// L2 -> LDS staging cycles per K-tile as MFMA cycles; this tile gives 192 workgroups and 0.75 staging cycles per MFMA cycle.
-//   * a K-tile (64 deep) is THREE 16 KB parts - A(r0), B, A(r1): the 32-row halves of every wave's 64 rows and the wave's 64
-//     columns - staged by direct-to-LDS DMA (two 1 KB instructions per wave and part), three buffers = 144 KB of LDS;
-//   * a phase = one 32-row half of every wave's tile over the K-tile (8 MFMA 32x32x16): phase 1 reads the fragments of A(r0) and
-//     B (which stay in registers for phase 2), phase 2 those of A(r1); LOAD and MFMA sections closed by raw s_barriers, the two
-//     waves of a SIMD (waves 0-3 / 4-7) one section apart, as in the 256 x 256 kernel;
-//   * phase 1 of K-tile t stages A(r0) and B of K-tile t + 2, phase 2 stages A(r1) of t + 2: every part is re-staged two phases
-//     after its last fragment read (WAR: the barrier behind the later wave group's completed reads lies in between) and is read
-//     four phases after its issue, one phase after the counted wait that retired it in every wave (RAW) - all but the five
-//     youngest parts at the end of a phase-1 LOAD section (vmcnt(10)), all but the four youngest at the end of phase 2 (vmcnt(8));
-//   * K-tiles past the end are staged from an offset beyond the buffer (zeros, no traffic): the counts stay uniform.
-constexpr int P6_PART = 16384, P6_BUF = 3 * P6_PART, P6_NBUF = 3;      // slot order inside a buffer: A(r0) B A(r1)
-
-template <bool TA, bool TB, int SCHED, int DBG = 0>
-__device__ __forceinline__ void p6_body(const GemmArgs& g, char* smem, int wg) {
-    const int tiles_n = (g.N + 127) / 128;
-    const int bm = (wg / tiles_n) * 256, bn = (wg % tiles_n) * 128;
-    const int ksteps = g.K / GBK;
-    const int per = (ksteps + g.ksplit - 1) / g.ksplit;
-    const int ks0 = blockIdx.z * per, ks1 = min(ksteps, ks0 + per);
-    if (ks0 >= ks1) return;
-    const int nk = ks1 - ks0;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, half = lane >> 5;
-    const int wr = wave >> 1, wc = wave & 1;
-
-    PartOp<TA, 32, 64> oa; PartOp<TB, 64, 64> ob;
-    oa.init(g.A, g.a_bytes, g.lda, bm, ks0 * GBK, wave, lane, wr);
-    ob.init(g.B, g.b_bytes, g.ldb, bn, ks0 * GBK, wave, lane, wc);
-    char* const wdst = smem + wave * 2048;                   // this wave's 2 KB slice of every part image
-
-    f32x16 acc[2][2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-    auto issue = [&](int slot, int t, int boff) {            // slot: 0 A(r0), 1 B, 2 A(r1)
-        char* d = wdst + boff + slot * P6_PART;
-        const bool live = t < nk && !((DBG & 2) && t >= 2);
-        if (slot == 1) ob.issue(0, t, d, live); else oa.issue(slot >> 1, t, d, live);
-    };
-    Vec8<bf16> fa[4], fb[2][4];
-    if (DBG & 4) {
-#pragma unroll
-        for (int kk = 0; kk < 4; ++kk) { fa[kk] = Vec8<bf16>::zero(); fb[0][kk] = Vec8<bf16>::zero(); fb[1][kk] = Vec8<bf16>::zero(); }
-    }
-    auto loadA = [&](const char* img) {
-        if ((DBG & 4) && nk > 0) return;
-#pragma unroll
-        for (int kk = 0; kk < 4; ++kk) fa[kk] = oa.frag(img, 0, kk, half);
-    };
-    auto loadB = [&](const char* img) {
-        if ((DBG & 4) && nk > 0) return;
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int kk = 0; kk < 4; ++kk) fb[j][kk] = ob.frag(img, j, kk, half);
-    };
-    auto mfma_half = [&](int X) {
-        if (DBG & 1) return;
-        __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-        for (int kk = 0; kk < 4; ++kk)
-#pragma unroll
-            for (int j = 0; j < 2; ++j) Mma<bf16>::run(acc[X][j], fa[kk], fb[j][kk]);
-        __builtin_amdgcn_s_setprio(0);
-    };
-    auto sync = [&]() {                                      // end of an MFMA section
-        __builtin_amdgcn_sched_barrier(0);
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-        __builtin_amdgcn_sched_barrier(0);
-    };
-
-    // prologue: K-tiles 0 and 1 whole; A(r0) and B of K-tile 0 have landed when all but the four youngest parts have
-    issue(0, 0, 0); issue(1, 0, 0); issue(2, 0, 0);
-    issue(0, 1, P6_BUF); issue(1, 1, P6_BUF); issue(2, 1, P6_BUF);
-    wait_vm<8>();
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-    if (wave >= 4) { __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); }   // the second wave of every SIMD: one section behind
-    int cb = 0, ib = 2 * P6_BUF;                             // buffer of K-tile t / of K-tile t + 2 (byte offsets)
-    for (int t = 0; t < nk; ++t) {
-        const char* const img = smem + cb;
-        // ---- phase 1: rows r0
-        loadA(img); loadB(img + P6_PART);
-        issue(0, t + 2, ib); issue(1, t + 2, ib);
-        wait_vm<10>();
-        __builtin_amdgcn_s_barrier();
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_sched_barrier(0);
-        mfma_half(0);
-        sync();
-        // ---- phase 2: rows r1
-        loadA(img + 2 * P6_PART);
-        issue(2, t + 2, ib);
-        wait_vm<8>();
-        __builtin_amdgcn_s_barrier();
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_sched_barrier(0);
-        mfma_half(1);
-        sync();
-        cb = cb + P6_BUF == P6_NBUF * P6_BUF ? 0 : cb + P6_BUF;
-        ib = ib + P6_BUF == P6_NBUF * P6_BUF ? 0 : ib + P6_BUF;
-    }
-    if (wave < 4) { __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); }
-    wait_vm<0>();
-    epilogue<bf16, 2>(g, acc, smem, bm + wr * 64, bn + wc * 64, lane, wave);
-}
-
-// The 256 x 128 kernel with BALANCED load sections.  Ablations of p6_body on the three-head launch (M = 1,024, K = 2,048; -DAUDIOSSL_ABLATE
-// build, tools/heads_gemm_bench.py): 34.9 us in full; 26.7 without the fragment reads, 31.1 without the DMA, 25.6 without the MFMAs,
-// 24.5 with MFMAs and barriers alone, 18.7 with the barriers alone - i.e. ~9 us of launch / prologue / epilogue, an MFMA-paced loop
-// of 16.4 us, and ~10 us that the LOAD sections add because they are uneven: phase 1 reads 12 fragments and issues two parts (~380
-// cycles) beside the other wave group's 8 MFMAs (~276), phase 2 reads 4 and issues one (~140).  Here the B fragments of K-tile t + 1
-// are read in phase 2 of K-tile t (a second register set, the loop is unrolled over two K-tiles): phase 1 = 4 reads + two parts,
-// phase 2 = 12 reads + one part.  B(t + 1) must then have landed at the end of phase 1's LOAD section: all but the three youngest
-// parts (vmcnt(6)); phase 2's wait (all but the five youngest, vmcnt(10)) is already met.
-template <bool TA, bool TB>
-__device__ __forceinline__ void p6b_body(const GemmArgs& g, char* smem, int wg) {
-    const int tiles_n = (g.N + 127) / 128;
-    const int bm = (wg / tiles_n) * 256, bn = (wg % tiles_n) * 128;
-    const int ksteps = g.K / GBK;
-    const int per = (ksteps + g.ksplit - 1) / g.ksplit;
-    const int ks0 = blockIdx.z * per, ks1 = min(ksteps, ks0 + per);
-    if (ks0 >= ks1) return;
-    const int nk = ks1 - ks0;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, half = lane >> 5;
-    const int wr = wave >> 1, wc = wave & 1;
-
-    PartOp<TA, 32, 64> oa; PartOp<TB, 64, 64> ob;
-    oa.init(g.A, g.a_bytes, g.lda, bm, ks0 * GBK, wave, lane, wr);
-    ob.init(g.B, g.b_bytes, g.ldb, bn, ks0 * GBK, wave, lane, wc);
-    char* const wdst = smem + wave * 2048;
-
-    f32x16 acc[2][2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-    auto issue = [&](int slot, int t, int boff) {            // slot: 0 A(r0), 1 B, 2 A(r1)
-        char* d = wdst + boff + slot * P6_PART;
-        const bool live = t < nk;
-        if (slot == 1) ob.issue(0, t, d, live); else oa.issue(slot >> 1, t, d, live);
-    };
-    Vec8<bf16> fa[4], fb0[2][4], fb1[2][4];
-    auto loadA = [&](const char* img) {
-#pragma unroll
-        for (int kk = 0; kk < 4; ++kk) fa[kk] = oa.frag(img, 0, kk, half);
-    };
-    auto loadB = [&](const char* img, Vec8<bf16> (&fb)[2][4]) {
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int kk = 0; kk < 4; ++kk) fb[j][kk] = ob.frag(img, j, kk, half);
-    };
-    auto mfma_half = [&](int X, const Vec8<bf16> (&fb)[2][4]) {
-        __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-        for (int kk = 0; kk < 4; ++kk)
-#pragma unroll
-            for (int j = 0; j < 2; ++j) Mma<bf16>::run(acc[X][j], fa[kk], fb[j][kk]);
-        __builtin_amdgcn_s_setprio(0);
-    };
-    auto load_end = [&]() {
-        __builtin_amdgcn_s_barrier();
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_sched_barrier(0);
-    };
-    auto sync = [&]() {
-        __builtin_amdgcn_sched_barrier(0);
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-        __builtin_amdgcn_sched_barrier(0);
-    };
-    int cb = 0, nb = P6_BUF, ib = 2 * P6_BUF;                // buffers of K-tiles t, t + 1, t + 2 (byte offsets)
-    auto advance = [&]() {
-        cb = nb; nb = ib;
-        ib = ib + P6_BUF == P6_NBUF * P6_BUF ? 0 : ib + P6_BUF;
-    };
-    // one K-tile: fbc = the B fragments of this K-tile (already in registers), fbn receives those of the next one
-    auto ktile = [&](int t, Vec8<bf16> (&fbc)[2][4], Vec8<bf16> (&fbn)[2][4]) {
-        loadA(smem + cb);
-        issue(0, t + 2, ib); issue(1, t + 2, ib);
-        wait_vm<6>();                                        // A(r1) of t and B of t + 1 have landed
-        load_end();
-        mfma_half(0, fbc);
-        sync();
-        loadA(smem + cb + 2 * P6_PART);
-        loadB(smem + nb + P6_PART, fbn);
-        issue(2, t + 2, ib);
-        wait_vm<10>();
-        load_end();
-        mfma_half(1, fbc);
-        sync();
-        advance();
-    };
-
-    issue(0, 0, 0); issue(1, 0, 0); issue(2, 0, 0);
-    issue(0, 1, P6_BUF); issue(1, 1, P6_BUF); issue(2, 1, P6_BUF);
-    wait_vm<8>();                                            // A(r0) and B of K-tile 0
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-    loadB(smem + P6_PART, fb0);
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_sched_barrier(0);
-    if (wave >= 4) { __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); }
-    for (int t = 0; t < nk; t += 2) {
-        ktile(t, fb0, fb1);
-        if (t + 1 < nk) ktile(t + 1, fb1, fb0);
-    }
-    if (wave < 4) { __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); }
-    wait_vm<0>();
-    epilogue<bf16, 2>(g, acc, smem, bm + wr * 64, bn + wc * 64, lane, wave);
-}
-
 // 128 x 128 output tile, 8 waves (4 x 2, wave tile 32 x 64): the same loop for the M = 512 problems (the heads' dzn / last data
 // gradient launches: 96 tiles of 256 x 128, 192 of 128 x 128) and single problems with a narrow output.  A K-tile is TWO 16 KB parts
 // (A: every wave's 32 rows, B: every wave's 64 columns) and ONE phase (8 MFMA 32x32x16 per wave); K-tile t + 3 is staged in
@@ -1429,16 +1206,12 @@ __device__ __forceinline__ void p5_body(const GemmArgs& g, char* smem, int wg) {
     epilogue<bf16, 1>(g, acc, smem, bm + wr * 32, bn + wc * 64, lane, wave);
 }
 
-// KIND: 6 = 256 x 128 tiles (p6_body / p6b_body), 5 = 128 x 128 tiles (p5_body, DMA issued inside the MFMA section: 25.1 -> 22.4 us on
-// the M = 512 launches; the same move changed nothing on the 256 x 128 kernel), 60 + bits = ablation builds of the 256 x 128 kernel
+// KIND 5 = the 128 x 128 tiles of p5_body (DMA issued inside the MFMA section: 25.1 -> 22.4 us on the M = 512 launches).  The
+// 256 x 128 tiles that used to be KIND 6 run in the software-pipelined form below (SpBody, shape 6).
 template <bool TA, bool TB, int KIND>
 __device__ __forceinline__ void pk_body(const GemmArgs& g, char* smem, int wg) {
-    if constexpr (KIND >= 60) p6_body<TA, TB, 0, KIND - 60>(g, smem, wg);              // ablation builds
-    else if constexpr (KIND == 6) {
-        // measured (three-head launches, tools/heads_gemm_bench.py): with a transposed B operand (two transposing reads per
-        // fragment) the balanced form is 5 % faster (39.6 -> 37.3 us), for K-contiguous operands the two are equal (35.3 us)
-        if constexpr (TB) p6b_body<TA, TB>(g, smem, wg); else p6_body<TA, TB, 0>(g, smem, wg);
-    } else p5_body<TA, TB, 1>(g, smem, wg);
+    static_assert(KIND == 5, "the sectioned loop remains for the 128 x 128 tiles only");
+    p5_body<TA, TB, 1>(g, smem, wg);
 }
 
 template <bool TA, bool TB, int KIND>
@@ -1455,9 +1228,9 @@ __global__ __launch_bounds__(512) void gemm_pk_multi_kernel(GemmMulti gm) {
     pk_body<TA, TB, KIND>(gm.p[p], smem, wg);
 }
 template <int KIND> constexpr size_t pk_lds() {
-    return KIND != 5 ? ((size_t)P6_NBUF * P6_BUF > EPI_LDS * 2 ? (size_t)P6_NBUF * P6_BUF : EPI_LDS * 2) : (size_t)P5_NBUF * P5_BUF;
+    return (size_t)P5_NBUF * P5_BUF;
 }
-template <int KIND> constexpr int pk_rows() { return KIND != 5 ? 256 : 128; }
+template <int KIND> constexpr int pk_rows() { return 128; }
 
 template <bool TA, bool TB, int KIND>
 int launch_pk(const GemmArgs& g, hipStream_t s) {
@@ -1499,6 +1272,288 @@ int dispatch_pk_multi(const GemmMulti& gm, int count, int ksplit, int ta, int tb
     if (!ta && tb) return launch_pk_multi<false, true, KIND>(gm, count, ksplit, s);
     if (ta && tb) return launch_pk_multi<true, true, KIND>(gm, count, ksplit, s);
     return launch_pk_multi<true, false, KIND>(gm, count, ksplit, s);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// The SOFTWARE-PIPELINED family: the hand-scheduled tiles above without LOAD / MFMA sections and without the wave-group stagger.
+// A step = one 16-deep slice of the contraction: the wave's 2 MI MFMAs (MI x 2 blocks of 32 x 32) on one register set of MI + 2
+// fragments, while the fragments of the NEXT step are read into the other set - two reads in each gap between MFMAs, where the LDS
+// array serves them at no cost to the MFMA pipe - and the DMA instructions that stage a later slice follow in the remaining gaps.
+// A stage = BK / 16 steps = one [rows][BK] slice of both operands, kept as 128-row sub-images in a ring of NB stages.  ONE
+// s_barrier per stage, at the top of its last step, behind the wait that retired that step's own fragments (the wave's last reads
+// of the stage):
+//   * after it every wave is done reading stage h -> its ring slot takes stage h + NB (WAR), issued in this step and the following
+//     BK / 16 - 1 steps;
+//   * before it every wave waited for all of its DMA but the NB - 2 youngest stages -> stage h + 1, which the reads issued from
+//     here on address, has landed in every wave's slice of the sub-images (RAW).
+// Measured on the three-head launches (M = 1,024, K = 2,048, 256 x 128 tiles): 35.1 -> 31.8 us against the sectioned loop.
+// Sub-image layouts: K-contiguous operand: [128 rows][BK] with the 16-byte chunk c of row r stored at c ^ swz(r), swz = (r >> 2) & 3
+// for BK = 32 (64-byte rows) and (r >> 1) & 7 for BK = 64: the 16 lanes the LDS serves together (ds_read_b128) hit all 64 banks
+// once; row-contiguous operand: [BK k][128 rows], 64-byte group ^= k & 3, read with ds_read_b64_tr_b16 (as PartOp above).
+template <bool TRANS, int BK>
+struct SliceOp {
+    static constexpr int NI = BK / 32;                       // DMA instructions per wave and sub-image (1 KB each)
+    static constexpr int SUBB = 128 * BK * 2;                // bytes of a sub-image
+    static constexpr int CH = BK / 8;                        // 16-byte chunks per row (K-contiguous form)
+    __amdgpu_buffer_rsrc_t rsrc;
+    int voff[NI];
+    int kstride, sub_delta, base_off;                        // bytes; wave-uniform
+    __device__ __forceinline__ static int swz(int r) { return BK == 32 ? (r >> 2) & 3 : (r >> 1) & 7; }
+    __device__ __forceinline__ void init(const void* base_, unsigned bytes, long ld, int r0, int k0, int wave, int lane) {
+        rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base_), 0, bytes, 0x00020000);
+        if (!TRANS) {
+#pragma unroll
+            for (int i = 0; i < NI; ++i) {
+                const int p = wave * 16 + i * (64 / CH) + lane / CH;          // row of the sub-image this lane fills
+                const int sc = (lane % CH) ^ swz(p);                          // the logical chunk stored at position lane % CH
+                voff[i] = (int)(((long)p * ld + sc * 8) * 2);
+            }
+            kstride = BK * 2;
+            sub_delta = (int)(128 * ld * 2);
+            base_off = (int)(((long)r0 * ld + k0) * 2);
+        } else {
+#pragma unroll
+            for (int i = 0; i < NI; ++i) {
+                const int kl = wave * (BK / 8) + i * 4 + (lane >> 4), pc = lane & 15;
+                const int roff = ((((pc >> 2) ^ (kl & 3)) << 2) + (pc & 3)) * 8;
+                voff[i] = (int)(((long)kl * ld + roff) * 2);
+            }
+            kstride = (int)(BK * ld * 2);
+            sub_delta = 256;
+            base_off = (int)(((long)k0 * ld + r0) * 2);
+        }
+    }
+    // DMA instruction i of sub-image `sub` of stage st; dst = this wave's slice (wave * 1024 * NI) of that sub-image
+    __device__ __forceinline__ void issue(int sub, int i, int st, char* dst, bool live) const {
+        typedef __attribute__((address_space(3))) void* lptr_t;
+        const int so = live ? base_off + st * kstride + sub * sub_delta : 0x7FFFFF00;          // past the buffer: zeros, no traffic
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lptr_t)(dst + i * 1024), 16, voff[i], so, 0, 0);
+    }
+    // byte offset (inside a stage's run of this operand's sub-images) of the step-0 fragment of the 32-row block at tile row row0
+    __device__ __forceinline__ static int frag_off(int row0, int lane) {
+        if (!TRANS) {
+            const int local = (row0 & 127) + (lane & 31), half = lane >> 5;
+            return (row0 >> 7) * SUBB + local * (BK * 2) + ((half ^ swz(local)) << 4);
+        }
+        const int gb = row0 >> 5, q = (lane & 15) >> 2, pp = lane & 3, h4 = (lane >> 4) & 1, half = lane >> 5;
+        return (gb >> 2) * SUBB + (8 * half + q) * 256 + (((gb & 3) ^ q) << 6) + 32 * h4 + 8 * pp;
+    }
+    __device__ __forceinline__ static Vec8<bf16> frag(const char* stage, int off, int kk) {
+        if (!TRANS) return Vec8<bf16>::load(reinterpret_cast<const bf16*>(stage + (off ^ (kk << 5))));
+        typedef __attribute__((address_space(3))) const char* lds_t;                            // inline asm: see PartOp::frag
+        const unsigned a = (unsigned)(size_t)(lds_t)(stage + off + kk * 4096);
+        bf16x4 lo, hi;
+        asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(lo) : "v"(a) : "memory");
+        asm volatile("ds_read_b64_tr_b16 %0, %1 offset:1024" : "=v"(hi) : "v"(a) : "memory");
+        Vec8<bf16> f;
+        f.v = bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        return f;
+    }
+};
+
+// SHAPE 8: 256 x 256 (waves 2 x 4, wave tile 128 x 64), BK 32, ring of 5 x 32 KB; SHAPE 6: 256 x 128 (4 x 2, 64 x 64), BK 64, ring of
+// 3 x 48 KB; SHAPE 5: 128 x 128 (4 x 2, 32 x 64), BK 64, ring of 5 x 32 KB
+template <int SHAPE> struct SpCfg;
+template <> struct SpCfg<8> { static constexpr int WR = 2, WC = 4, MI = 4, BK = 32, NB = 5; };
+template <> struct SpCfg<6> { static constexpr int WR = 4, WC = 2, MI = 2, BK = 64, NB = 3; };
+template <> struct SpCfg<5> { static constexpr int WR = 4, WC = 2, MI = 1, BK = 64, NB = 5; };
+template <int SHAPE> struct SpDim {
+    using C = SpCfg<SHAPE>;
+    static constexpr int RA = C::WR * C::MI * 32, RB = C::WC * 64;
+    static constexpr int SA = RA / 128, SBN = RB / 128, NSUB = SA + SBN;
+    static constexpr int SUBB = 128 * C::BK * 2, STG = NSUB * SUBB;
+    static constexpr int PER = NSUB * (C::BK / 32);          // DMA instructions per wave and stage
+    static constexpr int KS = C::BK / 16;                    // steps per stage
+    static constexpr int DPS = (PER + KS - 1) / KS;          // DMA instructions per step
+    static constexpr size_t LDS = (size_t)C::NB * STG > EPI_LDS * 2 ? (size_t)C::NB * STG : EPI_LDS * 2;
+};
+
+// (a class with a static member: as a function template the host pass of hipcc rejected every instantiation after the first)
+template <bool TA, bool TB, int SHAPE>
+struct SpBody {
+__device__ __forceinline__ static void run(const GemmArgs& g, char* smem, int wg) {
+    using C = SpCfg<SHAPE>; using D = SpDim<SHAPE>;
+    constexpr int MI = C::MI, BK = C::BK, NB = C::NB, KS = D::KS, NI = BK / 32, NM = 2 * MI, NR = MI + 2;
+    static_assert(C::WR * C::WC == 8 && D::RA % 128 == 0 && D::RB % 128 == 0 && KS % 2 == 0, "shape");
+    constexpr int first_dma_gap = NM - 1 > (NR + 1) / 2 ? (NR + 1) / 2 : NM - 2;     // the gap after the last pair of fragment reads
+    const int tiles_n = (g.N + D::RB - 1) / D::RB;
+    const int bm = (wg / tiles_n) * D::RA, bn = (wg % tiles_n) * D::RB;
+    const int k64 = g.K / GBK;
+    const int per = (k64 + g.ksplit - 1) / g.ksplit;
+    const int ks0 = blockIdx.z * per, ks1 = min(k64, ks0 + per);
+    if (ks0 >= ks1) return;
+    const int nk = (ks1 - ks0) * (GBK / BK);                 // stages
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wr = wave / C::WC, wc = wave % C::WC;
+
+    SliceOp<TA, BK> oa; SliceOp<TB, BK> ob;
+    oa.init(g.A, g.a_bytes, g.lda, bm, ks0 * GBK, wave, lane);
+    ob.init(g.B, g.b_bytes, g.ldb, bn, ks0 * GBK, wave, lane);
+    char* const wdst = smem + wave * (1024 * NI);            // this wave's slice of every sub-image
+
+    int foff[NR];                                            // step-0 fragment offsets inside a stage: MI row blocks, 2 column blocks
+#pragma unroll
+    for (int i = 0; i < MI; ++i) foff[i] = oa.frag_off(wr * MI * 32 + i * 32, lane);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) foff[MI + j] = D::SA * D::SUBB + ob.frag_off(wc * 64 + j * 32, lane);
+
+    f32x16 acc[MI][2];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    // DMA instruction n (0 .. PER - 1) of stage st into the ring slot at byte offset sbase
+    auto dma = [&](int n, int st, int sbase) {
+        const int sub = n / NI, i = n % NI;
+        const bool live = st < nk;
+        if (sub < D::SA) oa.issue(sub, i, st, wdst + sbase + sub * D::SUBB, live);
+        else ob.issue(sub - D::SA, i, st, wdst + sbase + sub * D::SUBB, live);
+    };
+    Vec8<bf16> fr[2][NR];                                    // [register set][fragment]
+    auto read = [&](int set, int n, const char* stage, int kk) {
+        if (n < MI) fr[set][n] = oa.frag(stage, foff[n], kk);
+        else fr[set][n] = ob.frag(stage, foff[n], kk);
+    };
+
+    // prologue: stages 0 .. NB - 2 whole and the first step's share of stage NB - 1
+#pragma unroll
+    for (int h = 0; h < NB - 1; ++h)
+#pragma unroll
+        for (int n = 0; n < D::PER; ++n) dma(n, h, h * D::STG);
+#pragma unroll
+    for (int n = 0; n < D::DPS && n < D::PER; ++n) dma(n, NB - 1, (NB - 1) * D::STG);
+    wait_vm<(NB - 2) * D::PER + (D::DPS < D::PER ? D::DPS : D::PER)>();       // stage 0
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+#pragma unroll
+    for (int n = 0; n < NR; ++n) read(0, n, smem, 0);
+
+    int cb = 0, pb = (NB - 1) * D::STG;                      // ring slots of stage h and of stage h - 1
+    for (int h = 0; h < nk; ++h) {
+        const int nb = cb + D::STG == NB * D::STG ? 0 : cb + D::STG;
+#pragma unroll
+        for (int kk = 0; kk < KS; ++kk) {
+            const int cur = kk & 1, nxt = cur ^ 1;
+            const bool last = kk == KS - 1;
+            const char* const src = smem + (last ? nb : cb);
+            const int kn = last ? 0 : kk + 1;
+            // DMA share of this step: the slot freed by the most recent barrier takes stage (that stage) + NB
+            const int c = last ? 0 : kk + 1, dst_stage = last ? h + NB : h - 1 + NB, dst_slot = last ? cb : pb;
+            // the transposing reads are inline asm the compiler does not track; the K-contiguous ones get its own counted waits
+            if (TA || TB || last) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if (last) {
+                wait_vm<(NB - 2) * D::PER>();
+                __builtin_amdgcn_s_barrier();
+                asm volatile("" ::: "memory");
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int m = 0; m < NM; ++m) {
+                Mma<bf16>::run(acc[m >> 1][m & 1], fr[cur][m >> 1], fr[cur][MI + (m & 1)]);
+                __builtin_amdgcn_sched_barrier(0);
+                if (m < NM - 1) {
+                    // gap m: two fragment reads, then (behind the reads) the step's DMA instructions, all of them by the last gap
+#pragma unroll
+                    for (int n = 2 * m; n < 2 * m + 2 && n < NR; ++n) read(nxt, n, src, kn);
+#pragma unroll
+                    for (int d = 0; d < D::DPS; ++d) {
+                        constexpr int gaps = NM - 1 - first_dma_gap, per_gap = (D::DPS + gaps - 1) / gaps;
+                        const int gap = first_dma_gap + d / per_gap;
+                        if (gap == m && c * D::DPS + d < D::PER) dma(c * D::DPS + d, dst_stage, dst_slot);
+                    }
+                    if (NM == 2) {                           // one gap only: the third fragment too
+#pragma unroll
+                        for (int n = 2; n < NR; ++n) read(nxt, n, src, kn);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+        }
+        pb = cb; cb = nb;
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    wait_vm<0>();
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    if constexpr (MI == 4) {
+        epilogue<bf16, 2>(g, *reinterpret_cast<f32x16 (*)[2][2]>(&acc[0]), smem, bm + wr * 128, bn + wc * 64, lane, wave);
+        epilogue<bf16, 2>(g, *reinterpret_cast<f32x16 (*)[2][2]>(&acc[2]), smem, bm + wr * 128 + 64, bn + wc * 64, lane, wave);
+    } else epilogue<bf16, MI>(g, acc, smem, bm + wr * MI * 32, bn + wc * 64, lane, wave);
+}
+};
+
+template <bool TA, bool TB, int SHAPE>
+__global__ __launch_bounds__(512) void gemm_sp_kernel(GemmArgs g) {
+    extern __shared__ __attribute__((aligned(1024))) char smem[];
+    SpBody<TA, TB, SHAPE>::run(g, smem, xcd_contiguous(blockIdx.x, gridDim.x));
+}
+template <bool TA, bool TB, int SHAPE>
+__global__ __launch_bounds__(512) void gemm_sp_multi_kernel(GemmMulti gm) {
+    extern __shared__ __attribute__((aligned(1024))) char smem[];
+    int wg;
+    const int p = multi_locate(gm, wg);
+    if (p < 0) return;
+    SpBody<TA, TB, SHAPE>::run(gm.p[p], smem, wg);
+}
+template <bool TA, bool TB, int SHAPE>
+int launch_sp(const GemmArgs& g, hipStream_t s) {
+    using D = SpDim<SHAPE>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_sp_kernel<TA, TB, SHAPE>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)D::LDS) != hipSuccess) return ASSL_ELAUNCH;
+        attr_set = true;
+    }
+    const int tiles = ceil_div(g.M, D::RA) * ceil_div(g.N, D::RB);
+    { static char nm[96]; g_assl_last_kernel = note_name(nm, "gemm_sp_kernel<%s, %s, %d>", TF(TA), TF(TB), SHAPE); }
+    hipLaunchKernelGGL((gemm_sp_kernel<TA, TB, SHAPE>), dim3(tiles, 1, g.ksplit), dim3(512), D::LDS, s, g);
+    ASSL_LAUNCH_CHECK();
+}
+template <bool TA, bool TB, int SHAPE>
+int launch_sp_multi(const GemmMulti& gm_, int count, int ksplit, hipStream_t s) {
+    using D = SpDim<SHAPE>;
+    GemmMulti gm = gm_;
+    const int grid = multi_grid(gm, count, D::RA, D::RB);
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_sp_multi_kernel<TA, TB, SHAPE>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)D::LDS) != hipSuccess) return ASSL_ELAUNCH;
+        attr_set = true;
+    }
+    { static char nm[96]; g_assl_last_kernel = note_name(nm, "gemm_sp_multi_kernel<%s, %s, %d>", TF(TA), TF(TB), SHAPE); }
+    hipLaunchKernelGGL((gemm_sp_multi_kernel<TA, TB, SHAPE>), dim3(grid, 1, ksplit), dim3(512), D::LDS, s, gm);
+    ASSL_LAUNCH_CHECK();
+}
+template <int SHAPE>
+int dispatch_sp(const GemmArgs& g, int ta, int tb, hipStream_t s) {
+    if (!ta && !tb) return launch_sp<false, false, SHAPE>(g, s);
+    if (!ta && tb) return launch_sp<false, true, SHAPE>(g, s);
+    if (ta && tb) return launch_sp<true, true, SHAPE>(g, s);
+    return launch_sp<true, false, SHAPE>(g, s);
+}
+template <int SHAPE>
+int dispatch_sp_multi(const GemmMulti& gm, int count, int ksplit, int ta, int tb, hipStream_t s) {
+    if (!ta && !tb) return launch_sp_multi<false, false, SHAPE>(gm, count, ksplit, s);
+    if (!ta && tb) return launch_sp_multi<false, true, SHAPE>(gm, count, ksplit, s);
+    if (ta && tb) return launch_sp_multi<true, true, SHAPE>(gm, count, ksplit, s);
+    return launch_sp_multi<true, false, SHAPE>(gm, count, ksplit, s);
+}
+// Shape 6 always runs in this form.  AUDIOSSL_GEMM_SP: bit mask that ALSO moves the 256 x 256 (bit 8) / 128 x 128 (bit 2) tiles to it.
+// Measured (tools/heads_gemm_bench.py, tools/gemm_shapes.py; us, sectioned -> pipelined):
+//   256 x 128: three-head M = 1,024 launches NT 35.1 -> 31.3 (822 TF/s), first layer 33.4 -> 30.0, NN 36.5 -> 35.3; single TN
+//              2048 x 2048 x 1024 26.2 -> 23.6, x 512 19.4 -> 17.7                                              -> default
+//   256 x 256: 6144 x 2048 x 2048 NT 63.0 -> 65.2, NN 64.2 -> 64.4, three-head TN 39.1 -> 38.4 (BK 32, ring of five; BK 64 with two
+//              buffers and the whole stage issued in the last step: 64.7 / 65.1 / 41.2): the same within the box-to-box spread - the
+//              sectioned kernel stays, these tiles are MFMA-paced either way
+//   128 x 128: M = 512 launches 21.9 -> 22.6, 23.3 -> 24.2, 20.4 -> 21.4: two MFMAs per step leave one gap for three reads and a DMA
+//              instruction - the sectioned kernel stays
+//   BK 32 stages for the 256 x 128 / 128 x 128 tiles (rings of 6 / 10): 38.3 vs 31.5 and 25.4 vs 22.5 - twice the barriers
+int sp_mask() {
+    static const int m = getenv("AUDIOSSL_GEMM_SP") ? atoi(getenv("AUDIOSSL_GEMM_SP")) : 0;
+    return m;
 }
 
 // BK = 32 with a register budget for THREE workgroups per CU (41 KB of LDS each; the epilogue runs on half-height tiles so
@@ -1582,22 +1637,20 @@ static int dispatch_multi(const GemmMulti& gm, int count, int M, int N, int kmin
     // where even those are too few (M = 512: 96 -> 192 workgroups)
     if (p6 != 0 && hs_ok && M >= 256 && (p6 == 1 || (t6 >= 128 && t6 <= 288 && t8 < 128 && kmin >= 512)))
     {
-#ifdef AUDIOSSL_ABLATE
-        static const int dbg = getenv("AUDIOSSL_GEMM_P6_DBG") ? atoi(getenv("AUDIOSSL_GEMM_P6_DBG")) : 0;     // ablation builds: WRONG results
-        if (dbg == 1) return launch_pk_multi<false, false, 61>(gm, count, ksplit, s);       // no MFMA
-        if (dbg == 2) return launch_pk_multi<false, false, 62>(gm, count, ksplit, s);       // no DMA after two K-tiles
-        if (dbg == 4) return launch_pk_multi<false, false, 64>(gm, count, ksplit, s);       // no fragment reads
-        if (dbg == 6) return launch_pk_multi<false, false, 66>(gm, count, ksplit, s);       // MFMA + barriers only
-        if (dbg == 7) return launch_pk_multi<false, false, 67>(gm, count, ksplit, s);       // barriers only
-#endif
-        return dispatch_pk_multi<6>(gm, count, ksplit, trans_a, trans_b, s);
+        return dispatch_sp_multi<6>(gm, count, ksplit, trans_a, trans_b, s);
     }
     if (p6 != 0 && hs_ok && (p6 == 5 || (p6 != 1 && t5 >= 96 && t5 <= 288 && t6 < 128 && kmin >= 512)))
+    {
+        if (sp_mask() & 2) return dispatch_sp_multi<5>(gm, count, ksplit, trans_a, trans_b, s);
         return dispatch_pk_multi<5>(gm, count, ksplit, trans_a, trans_b, s);
+    }
     // multi-problem launches: measured wins for the transposed-A weight gradients of the three heads (2048 x 2048 x 1024:
     // 50.9 -> 43.9 us, x 512: 31.3 -> 29.0 us)
     if (p8 != 0 && p8 != 2 && hs_ok && M >= 256 && N >= 256 && (p8 == 1 || (trans_a && t8 >= 128 && kmin >= 512)))
+    {
+        if (sp_mask() & 8) return dispatch_sp_multi<8>(gm, count, ksplit, trans_a, trans_b, s);
         return dispatch_p8_multi(gm, count, ksplit, trans_a, trans_b, s);
+    }
     static const int w8 = getenv("AUDIOSSL_GEMM_W8") ? atoi(getenv("AUDIOSSL_GEMM_W8")) : 0;
     if (w8 && M >= 256) MULTI(64, 2, 8);
     if (small) MULTI(64, 1, 4);
@@ -1685,7 +1738,8 @@ static int run_bf16(const GemmArgs& g, int trans_a, int trans_b, hipStream_t s) 
             ga.ksplit = ks;
         }
         const bool layout_ok = p8 != 2 || (!trans_a && !trans_b);            // AUDIOSSL_GEMM_P8=2: K-contiguous operands only
-        if (p8 == 1 || (layout_ok && t256 * ga.ksplit >= 128 && K / ga.ksplit >= 1024)) return dispatch_p8(ga, trans_a, trans_b, s);
+        if (p8 == 1 || (layout_ok && t256 * ga.ksplit >= 128 && K / ga.ksplit >= 1024))
+            return sp_mask() & 8 ? dispatch_sp<8>(ga, trans_a, trans_b, s) : dispatch_p8(ga, trans_a, trans_b, s);
     }
     // the hand-scheduled 256 x 128 kernel (written for the multi-problem launches of the projector heads, see dispatch_multi):
     // single problems whose 256 x 128 tiles fill the chip once while the 256 x 256 tiles would leave half of it idle
@@ -1694,12 +1748,12 @@ static int run_bf16(const GemmArgs& g, int trans_a, int trans_b, hipStream_t s) 
         const long t5 = (long)ceil_div(M, 128) * ceil_div(N, 128) * ksplit, t6 = (long)ceil_div(M, 256) * ceil_div(N, 128) * ksplit,
                    t8 = (long)ceil_div(M, 256) * ceil_div(N, 256) * ksplit;
         if (M >= 256 && (p6 == 1 || (t6 >= 128 && t6 <= 288 && t8 < 128 && K / ksplit >= 512)))
-            return dispatch_pk<6>(g, trans_a, trans_b, s);
+            return dispatch_sp<6>(g, trans_a, trans_b, s);
         // measured (tools/gemm_shapes.py): NN 6144 x 512 x 2048 34.1 -> 25.8 us, TN 2048 x 512 x 6144 / 3 41.9 -> 32.2 us; with short K
         // loops (2048 x 2048 x 512 TN: 19.3 vs 17.9 us) and for K-contiguous operands on <= 128 tiles (the ring kernel: 20.2 vs 21.7 us)
         // the older kernels stay
         if (p6 == 5 || (p6 != 1 && t5 >= 96 && t5 <= 288 && t6 < 128 && K / ksplit >= 1024 && (trans_a || trans_b || t5 > 128)))
-            return dispatch_pk<5>(g, trans_a, trans_b, s);
+            return sp_mask() & 2 ? dispatch_sp<5>(g, trans_a, trans_b, s) : dispatch_pk<5>(g, trans_a, trans_b, s);
     }
     // grids of >= 2 workgroups per CU with a K-contiguous A operand: K-step 32 and THREE co-resident workgroups per CU (41 KB
     // of LDS each, 126 VGPRs) - 12 waves per CU hide the staged-load and barrier waits better than two workgroups at K-step

@@ -751,7 +751,7 @@ print("WORST", worst)
     ({"AUDIOSSL_GEMM_P8": "1"}, [("NT", 1100, 520, 64), ("NT", 1100, 520, 192), ("NT", 700, 264, 512), ("NN", 1100, 520, 192),
                                  ("NN", 700, 264, 512), ("TN", 1096, 520, 192), ("TN", 696, 264, 512), ("NT", 6144, 2048, 2048),
                                  ("NN", 1024, 2048, 1024), ("TN", 2048, 520, 1024)]),
-    # hand-scheduled 256 x 128 kernel (three buffers): 1, 2, 3, 4 and 7 K-tiles, partial tiles in M and N, the heads' shapes
+    # software-pipelined 256 x 128 kernel (ring of three 48 KB stages): 1, 2, 3, 4 and 7 K-tiles, partial tiles in M and N, the heads' shapes
     ({"AUDIOSSL_GEMM_P6": "1", "AUDIOSSL_GEMM_P8": "0"},
      [("NT", 1100, 392, 64), ("NT", 1100, 392, 128), ("NT", 700, 264, 192), ("NT", 520, 136, 256), ("NN", 1100, 392, 192),
       ("NN", 700, 264, 448), ("NN", 300, 200, 320), ("TN", 1096, 392, 192), ("TN", 696, 264, 448), ("TN", 296, 136, 128), ("NT", 1024, 2048, 2048),
@@ -761,6 +761,14 @@ print("WORST", worst)
      [("NT", 600, 392, 64), ("NT", 600, 392, 128), ("NT", 300, 264, 192), ("NT", 520, 136, 256), ("NT", 130, 130, 320), ("NN", 600, 392, 384),
       ("NN", 300, 264, 448), ("TN", 600, 392, 192), ("TN", 296, 264, 448), ("NT", 512, 2048, 2048), ("NN", 512, 2048, 2048),
       ("NN", 6144, 512, 2048)]),
+    # the software-pipelined form of the 256 x 256 tile (BK 32, ring of five) and of the 128 x 128 tile (BK 64, ring of five): not the
+    # default for these tiles (gemm.hip, sp_mask), kept selectable - every layout, 1 ... 7 K-tiles, partial tiles
+    ({"AUDIOSSL_GEMM_SP": "8", "AUDIOSSL_GEMM_P8": "1"},
+     [("NT", 1100, 520, 64), ("NT", 1100, 520, 192), ("NT", 700, 264, 512), ("NN", 1100, 520, 192), ("NN", 700, 264, 512),
+      ("TN", 1096, 520, 192), ("TN", 696, 264, 512), ("NT", 6144, 2048, 2048), ("TN", 2048, 520, 1024)]),
+    ({"AUDIOSSL_GEMM_SP": "2", "AUDIOSSL_GEMM_P6": "5", "AUDIOSSL_GEMM_P8": "0"},
+     [("NT", 600, 392, 64), ("NT", 600, 392, 128), ("NT", 300, 264, 192), ("NT", 130, 130, 320), ("NN", 600, 392, 384),
+      ("NN", 300, 264, 448), ("TN", 600, 392, 192), ("TN", 296, 264, 448), ("NT", 512, 2048, 2048)]),
 ])
 def test_gemm_tile_variants_in_subprocess(env, shapes):
     """The tile variants that the default dispatch does not pick for these shapes (ring of every layout, 256x256 and 256x128
