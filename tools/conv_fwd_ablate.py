@@ -16,4 +16,6 @@ for Nimg, Ti, Fi in ((512, 50, 32), (512, 25, 16)):
     gf = 2.0 * Nimg * Ti * Fi * 64 * 576 / 1e6
     t = timeit(lambda: N.call("conv3x3_fwd", x, Wf, b, Y, 0, sq[0], sq[1], 1, Nimg, Ti, Fi))
     t2 = timeit(lambda: N.call("conv3x3_fwd", x, Wd, None, dx, 1, None, None, 1, Nimg, Ti, Fi))
-    print(f"dbg={os.environ.get('AUDIOSSL_CONV_DBG', '0')} {(Nimg, Ti, Fi)} fwd+stats {t:7.1f} us {gf / t:6.1f} TF/s | dgrad f32 {t2:7.1f} us", flush=True)
+    t3 = timeit(lambda: N.call("conv3x3_fwd", x, Wf, b, Y, 0, None, None, 1, Nimg, Ti, Fi))
+    print(f"dbg={os.environ.get('AUDIOSSL_CONV_DBG', '0')} ws={os.environ.get('AUDIOSSL_CONV_WS', '-')} {(Nimg, Ti, Fi)} fwd+stats {t:7.1f} us {gf / t:6.1f} TF/s | "
+          f"dgrad f32 {t2:7.1f} us | fwd {t3:7.1f} us", flush=True)
