@@ -631,6 +631,13 @@ __global__ __launch_bounds__(256) void sgd_kernel(float* __restrict__ p, float* 
     }
 }
 
+// g[off_s .. off_s + n_s) = 0 for a table of segments (blockIdx.y = segment): the small tensors of a flat gradient whose big ones are
+// overwritten (not accumulated into) by their only writer and therefore need no clearing
+__global__ __launch_bounds__(256) void zero_segments_kernel(float* __restrict__ g, const long* __restrict__ segs) {
+    const long off = segs[2 * blockIdx.y], n = segs[2 * blockIdx.y + 1];
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) g[off + i] = 0.f;
+}
+
 // pk = pk*m + pq*(1-m)
 // shadow (optional): bf16 copy of the updated pk, written in the same pass (the key encoder's MFMA operands)
 __global__ __launch_bounds__(256) void ema_kernel(float* __restrict__ pk, const float* __restrict__ pq, long n, float m,
@@ -1013,6 +1020,13 @@ extern "C" int audiossl_sgd_momentum(float* p, float* g, float* buf, long n, flo
     const int grid = (int)min((long)2048, (n + 1023) / 1024);
     hipLaunchKernelGGL(sgd_kernel, dim3(grid), dim3(256), 0, S_(stream), p, g, buf, n, lr, momentum, weight_decay, first, grad_scale,
                        grad_scale_dev, static_cast<bf16*>(shadow_bf16), zero_grad);
+    ASSL_LAUNCH_CHECK();
+}
+
+extern "C" int audiossl_zero_segments(float* g, const long* segs, int nseg, long max_n, void* stream) {
+    ASSL_REQUIRE(g && segs && nseg > 0 && nseg <= 65535 && max_n > 0);
+    const int gx = (int)min((long)64, (max_n + 255) / 256);
+    hipLaunchKernelGGL(zero_segments_kernel, dim3(gx, nseg), dim3(256), 0, S_(stream), g, segs);
     ASSL_LAUNCH_CHECK();
 }
 

@@ -742,6 +742,17 @@ def gemm_multi(ta, tb, M, Nn, Ks, As, ldas, Bs, ldbs, Cs, ldc, alpha=1.0, out_f3
            out_f32, atomic, ksplit)
 
 
+def _heads_wgrad_split(D, kmax, M, nh):
+    return _ksplit(D, kmax, M, max(256 // nh, 1))
+
+
+def heads_wgrads_store(D, kins, M, grads_zero=True):
+    """True when every weight-gradient launch of `barlow_heads_forward_backward(..., grads_zero=True)` STORES its result (one
+    unsplit writer per dW): the caller may then leave those gradients uncleared between steps (HipSGD.step_tail(stored=...))."""
+    nh = len(kins)
+    return bool(grads_zero) and all(_heads_wgrad_split(D, k, M, nh) == 1 for k in (D, max(kins)))
+
+
 def barlow_heads_forward_backward(PPs, Gs, Ys, dtype, lambds, scale_losses, loss_outs, update_running=True, backward=True,
                                   Wcs=None, grads_zero=False, dy_ready=None):
     """`barlow_forward_backward` for several heads in lock-step: every step of the chain - GEMM, train-mode BatchNorm, loss -
@@ -829,7 +840,7 @@ def barlow_heads_forward_backward(PPs, Gs, Ys, dtype, lambds, scale_losses, loss
         return out
 
     def wgrad(dys, xs, name, ks):                        # dW_h [D, k_h] += dy_h^T x_h; one writer per dW, so no atomics unless split
-        split = _ksplit(D, max(ks), M, max(256 // nh, 1))
+        split = _heads_wgrad_split(D, max(ks), M, nh)
         # grads_zero: the caller guarantees the gradient buffers are zero and written once in this step, so the single writer
         # stores its result instead of reading 50 MB of zeros per launch to add to them
         gemm_multi(1, 1, D, ks, [M] * nh, dys, [D] * nh, xs, ks, [Gs[h][name] for h in H], ks, out_f32=1,

@@ -114,14 +114,18 @@ class FlatGroup:
     def param_dict(self, prefix=""):
         return {n[len(prefix):]: p.data for n, p in zip(self.names, self.params) if n.startswith(prefix)}
 
-    def zero_grad(self):
-        if self._fresh_grad:                   # cleared by the SGD pass of the previous step
-            self._fresh_grad = False
+    def zero_grad(self, stores_ok=False):
+        """stores_ok: the caller's large gradients are STORED by their single writer this step (not accumulated into), so a
+        gradient the previous step's SGD pass cleared only partially (`mark_fresh(partial=True)`: everything but those tensors)
+        is good enough; any other caller gets a full clear."""
+        fresh, self._fresh_grad = self._fresh_grad, False
+        if fresh is True or (fresh == "partial" and stores_ok):   # cleared by the SGD pass of the previous step
             return
         self.grad.zero_()
 
-    def mark_fresh(self):
-        self._fresh_shadow = self._fresh_grad = True
+    def mark_fresh(self, partial=False):
+        self._fresh_shadow = True
+        self._fresh_grad = "partial" if partial else True
 
     def attach_grads(self, scale=None):
         """Expose the flat gradient through p.grad (alias when p.grad is None, else accumulate)."""

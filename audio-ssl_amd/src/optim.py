@@ -51,6 +51,7 @@ class HipSGD(FlatState, torch.optim.Optimizer):
         self.grad_scale_tensor = None      # optional device scalar multiplied in (loss.backward(g))
         self.steps = 0
         self._early = {}                   # id(flat group) -> first element already stepped by step_tail() this step
+        self._zero_tables = {}
         # fused_refresh (set by GraphedStep): the SGD pass also writes the bf16 shadow of the updated weights and clears the
         # gradient, and tells the flat group so - its next refresh_shadow() / zero_grad() are then no-ops.  Off by default:
         # with it, gradients read back as zero after step().
@@ -77,23 +78,55 @@ class HipSGD(FlatState, torch.optim.Optimizer):
                        float(g0["momentum"]), float(g0["weight_decay"]), int(first), float(self.grad_scale), self.grad_scale_tensor,
                        shadow, zero)
             if zero and (done is None or fg._early_fused):
-                fg.mark_fresh()                       # the whole buffer has been stepped with the fused tail
+                fg.mark_fresh(partial=fg._early_fused == "partial")   # the whole buffer has been stepped with the fused tail
             fg._early_fused = False
         self.steps += 1
 
     @torch.no_grad()
-    def step_tail(self, fg, start):
+    def step_tail(self, fg, start, stored=()):
         """Step the slice [start, numel) of one flat group now, on the current stream; the next step() covers the rest.
         Used by the fused experts to update the loss-head parameters (83 % of delores_m's buffer) as soon as their
-        gradients are final, underneath the encoder backward, instead of in the serial tail of the step."""
+        gradients are final, underneath the encoder backward, instead of in the serial tail of the step.
+        stored: names of parameters in the slice whose gradient is STORED by its only writer every step (the heads' weight
+        gradients): the fused tail then clears only the other tensors of the slice (one small launch over a segment table)
+        instead of writing zeros over 126 MB that the next step overwrites anyway; the flat group is told (`partial`)."""
         if fg.momentum is None or start >= fg.numel or start % 64:
             return False
         g0 = self.param_groups[0]
         shadow, zero = self._tail(fg, start, fg.numel)
+        segs = self._zero_table(fg, start, stored) if (zero and stored) else None
         N.call("sgd_momentum", fg.data[start:], fg.grad[start:], fg.momentum[start:], fg.numel - start, float(g0["lr"]),
-               float(g0["momentum"]), float(g0["weight_decay"]), 0, float(self.grad_scale), self.grad_scale_tensor, shadow, zero)
-        fg._early_fused = bool(zero)
+               float(g0["momentum"]), float(g0["weight_decay"]), 0, float(self.grad_scale), self.grad_scale_tensor, shadow,
+               0 if segs is not None else zero)
+        if segs is not None:
+            N.call("zero_segments", fg.grad, segs[0], segs[1], segs[2])
+        fg._early_fused = ("partial" if segs is not None else True) if zero else False
         return True
+
+    def _zero_table(self, fg, start, stored):
+        """Device table of the (offset, length) runs of [start, numel) that are NOT gradients of `stored` parameters; None when
+        there is nothing to skip."""
+        key = (id(fg), start, tuple(stored))
+        hit = self._zero_tables.get(key)
+        if hit is None:
+            skip = set(stored)
+            runs = []
+            for n, p, o in zip(fg.names, fg.params, fg.offsets):
+                if o + p.numel() <= start or n in skip:
+                    continue
+                lo = max(o, start)
+                if runs and runs[-1][0] + runs[-1][1] == lo:
+                    runs[-1][1] += o + p.numel() - lo
+                else:
+                    runs.append([lo, o + p.numel() - lo])
+            covered = sum(r[1] for r in runs)
+            if not runs or covered == fg.numel - start:
+                hit = (None,)
+            else:
+                table = torch.tensor([v for r in runs for v in r], dtype=torch.int64, device=fg.data.device)
+                hit = ((table, len(runs), max(r[1] for r in runs)),)
+            self._zero_tables[key] = hit
+        return hit[0]
 
     def mark_early(self, fg, start):
         """Host-side bookkeeping for step_tail (kept separate: a replayed graph re-issues the launch, not this)."""

@@ -25,6 +25,7 @@ from src.utils import concat_all_gather
 
 _PREP_ASIDE = os.environ.get("AUDIOSSL_PREP_ASIDE", "1") != "0"
 _HEADS_ASIDE = os.environ.get("AUDIOSSL_HEADS_ASIDE", "1") != "0"        # 0: the grouped Barlow heads are issued on the main stream
+_SKIP_ZERO = os.environ.get("AUDIOSSL_SKIP_ZERO", "1") != "0"            # 0: the head-segment SGD clears the whole gradient slice again
 _GRADS_ZERO = os.environ.get("AUDIOSSL_GRADS_ZERO", "1") != "0"          # 0: weight-gradient GEMMs of the heads add to the (zero) buffers
 _DY_EVENT = os.environ.get("AUDIOSSL_DY_EVENT", "1") != "0"              # 0: the main stream waits for the whole heads stream
 _LATE_JOIN = os.environ.get("AUDIOSSL_LATE_JOIN", "1") != "0"            # 0: join the heads before the whole encoder backward
@@ -127,6 +128,14 @@ class Upstream_Expert(MocoQueueMixin, FusedExpertMixin, UpstreamModule):
             return kk
         k = self._key_stream.run(dev, key_branch)
 
+        # the grouped heads STORE their nine weight gradients (single unsplit writer each): those need no clearing between steps
+        heads = (self.p1, self.p2, self.p3)
+        grouped = not (self.high_precision or dt == N.F32 or not self.grouped_heads)
+        D_ = self.p1.param_dict()["projector.3.weight"].shape[0]
+        kins_ = [p.param_dict()["projector.0.weight"].shape[1] for p in heads]
+        stored_grads = tuple(f"p{i + 1}.projector.{j}.weight" for i in range(3) for j in (0, 3, 6)) \
+            if (need_grad and grouped and _GRADS_ZERO and _SKIP_ZERO and E.heads_wgrads_store(D_, kins_, 2 * B)) else ()
+
         # ---- query encoder (main stream)
         def query_phase():
             # clearing the flat gradient and refreshing the bf16 weight shadow are two HBM-bound sweeps (152 MB written,
@@ -134,7 +143,7 @@ class Upstream_Expert(MocoQueueMixin, FusedExpertMixin, UpstreamModule):
             # the convolutions (which read the fp32 parameters) and are joined right before the first shadow weight is used
             def prep():
                 if need_grad:
-                    flat.zero_grad()
+                    flat.zero_grad(stores_ok=bool(stored_grads))
                 flat.refresh_shadow(dt)
             if _PREP_ASIDE:
                 self._prep_stream.run(dev, prep)
@@ -170,8 +179,7 @@ class Upstream_Expert(MocoQueueMixin, FusedExpertMixin, UpstreamModule):
                                              loss[i + 1:i + 2], need_dy1=True, need_dy2=False,
                                              update_running=self.training, backward=need_grad,
                                              Wc=tuple(Wp[f"projector.{j}.weight"] for j in (0, 3, 6)))
-        heads = (self.p1, self.p2, self.p3)
-        if self.high_precision or dt == N.F32 or not self.grouped_heads:
+        if not grouped:
             for i, p in enumerate(heads):
                 if not E.ONE_STREAM:
                     E.fork(streams[i], main)
@@ -241,7 +249,7 @@ class Upstream_Expert(MocoQueueMixin, FusedExpertMixin, UpstreamModule):
                 if not E.ONE_STREAM and _SGD_ASIDE and dy_event is None:
                     E.fork(early, main)
                 with torch.cuda.stream(early):
-                    if R.phase("sgd_heads", lambda: optimizer.step_tail(flat, self.head_offset())):
+                    if R.phase("sgd_heads", lambda: optimizer.step_tail(flat, self.head_offset(), stored=stored_grads)):
                         optimizer.mark_early(flat, self.head_offset())
                         early_box[0] = early
             return dys

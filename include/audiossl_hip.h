@@ -306,6 +306,10 @@ int audiossl_last_kernel(char* name, int capacity);
 int audiossl_sgd_momentum(float* p, float* g, float* buf, long n, float lr, float momentum, float weight_decay,
                           int first, float grad_scale, const float* grad_scale_dev, void* shadow_bf16, int zero_grad,
                           void* stream);
+/* g[segs[2s] .. + segs[2s+1]) = 0 for nseg segments (segs: DEVICE table of (offset, length) pairs in elements, max_n = the longest):
+ * clears the small tensors of a flat gradient whose large ones are stored, not accumulated, by their single writer
+ * (src/optim.py: HipSGD.step_tail(keep_stale=...)); no reference counterpart - the reference's optimizer.zero_grad() clears all. */
+int audiossl_zero_segments(float* g, const long* segs, int nseg, long max_n, void* stream);
 int audiossl_cast(int dtype, const float* src, void* dst, long n, void* stream);
 int audiossl_cast_back(int dtype, const void* src, float* dst, long n, void* stream);
 /* keep[i] = splitmix64(seed', i) >= p; seed' = (seed + *counter) mod 2^48 when `counter` (device int64) is given, so that

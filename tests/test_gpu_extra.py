@@ -373,3 +373,41 @@ def test_offline_pseudolabeler_vs_oracle(tmp_path):
     labels = CL.write_pseudolabel_csv([f"clip{i}.wav" for i in range(n)], km, str(tmp_path / "labels.csv"))
     lines = open(tmp_path / "labels.csv").read().split()
     assert len(lines) == n and lines[5] == f"clip5.wav,{int(labels[5])}" and labels[km.images_lists[3][0]] == 3
+
+
+def test_sgd_step_tail_clears_only_what_is_not_stored():
+    """`HipSGD.step_tail(stored=...)` (fused tail on): parameters, momentum and bf16 shadow equal the plain fused tail bit for
+    bit; afterwards the gradients of the stored tensors are untouched and every other gradient of the slice is zero."""
+    from src import _native as N
+    from src.flat import FlatGroup
+    from src.optim import HipSGD
+    shapes = ((64, 9), (256, 128), (256,), (256,), (256, 256), (256,), (256,), (128, 256))
+    names = ["enc.w", "h.0.weight", "h.1.weight", "h.1.bias", "h.3.weight", "h.4.weight", "h.4.bias", "h.6.weight"]
+    stored = ("h.0.weight", "h.3.weight", "h.6.weight")
+    outs = []
+    for use_stored in (False, True):
+        g = torch.Generator().manual_seed(3)
+        ps = [torch.nn.Parameter(torch.randn(*sh, generator=g).cuda()) for sh in shapes]
+        fg = FlatGroup(list(zip(names, ps)))
+        opt = HipSGD([fg], ps, 0.05, momentum=0.9, weight_decay=1e-3)
+        opt.fused_refresh = True
+        fg.refresh_shadow(N.BF16)
+        fg.momentum = torch.randn(fg.numel, generator=g).cuda()
+        fg.grad.copy_(torch.randn(fg.numel, generator=g).cuda())
+        g_before = fg.grad.clone()
+        start = fg.offsets[1]
+        assert opt.step_tail(fg, start, stored=stored if use_stored else ())
+        opt.mark_early(fg, start)
+        opt.step()
+        torch.cuda.synchronize()
+        assert fg._fresh_grad == ("partial" if use_stored else True)
+        outs.append((fg.data.clone(), fg.momentum.clone(), fg._shadow.clone()))
+        for n, p, o in zip(fg.names, fg.params, fg.offsets):
+            got = fg.grad[o:o + p.numel()]
+            if use_stored and n in stored:
+                assert torch.equal(got, g_before[o:o + p.numel()]), n
+            else:
+                assert float(got.abs().max()) == 0.0, n
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)
+

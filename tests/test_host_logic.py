@@ -164,3 +164,33 @@ def test_flat_optimiser_state_schema_round_trip_and_foreign_checkpoints():
             other = dict(sd, kind="SomethingElse")
             assert opt3.load_state_dict(other) is False
         assert len(w) == 2 and all(getattr(fg3, b, None) is None for b in bufs)
+
+
+def test_partial_gradient_clear_table_and_flags():
+    """HipSGD.step_tail(stored=...): the clear table lists exactly the runs of the stepped slice that are NOT gradients of the
+    stored tensors (adjacent tensors merge, padding between tensors is left alone), and a partially cleared flat gradient is
+    only accepted by a caller that stores into the stale tensors (`zero_grad(stores_ok=True)`): anyone else gets a full clear."""
+    from src.flat import FlatGroup
+    from src.optim import HipSGD
+    ps = [torch.nn.Parameter(torch.randn(*sh)) for sh in ((64, 3), (128, 64), (128,), (128,), (128, 128), (100,))]
+    names = ["enc.w", "h.0.weight", "h.1.weight", "h.1.bias", "h.3.weight", "h.4.bias"]
+    fg = FlatGroup(list(zip(names, ps)))
+    opt = HipSGD([fg], ps, 0.1)
+    start = fg.offsets[1]
+    table, nseg, longest = opt._zero_table(fg, start, ("h.0.weight", "h.3.weight"))
+    runs = table.view(-1, 2).tolist()
+    assert nseg == len(runs) == 2 and longest == 256
+    assert runs[0] == [fg.offsets[2], 256]                          # h.1.weight + h.1.bias: adjacent, merged
+    assert runs[1] == [fg.offsets[5], 100]
+    fg.grad.fill_(1.0)
+    fg.mark_fresh(partial=True)
+    fg.zero_grad(stores_ok=True)
+    assert float(fg.grad.min()) == 1.0                              # accepted: the stale tensors will be overwritten
+    fg.mark_fresh(partial=True)
+    fg.zero_grad()
+    assert float(fg.grad.abs().max()) == 0.0                        # any other caller: full clear
+    fg.grad.fill_(1.0)
+    fg.mark_fresh()
+    fg.zero_grad()
+    assert float(fg.grad.min()) == 1.0 and fg._fresh_grad is False  # a full fused clear buys one skipped sweep, as before
+
