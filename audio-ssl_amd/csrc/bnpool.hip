@@ -338,6 +338,64 @@ __global__ __launch_bounds__(256) void bn_relu_pool_bwd_kernel(const TY* __restr
     }
 }
 
+// Backward, pass 1 from the POOLED forward output: the routed gradient is non-zero only at the window's arg-max and only where the
+// pooled activation P = relu(max a) is positive, and there a = P, so xhat = ((P - shift) / scale - mean) * rstd needs no look at Y:
+// 26 + 26 MB read instead of 105 + 26 (block 2, B = 512).  P carries one bf16 rounding of a, as Y carries one of y: the sums move
+// by rounding noise only (tests/test_gpu_kernels.py compares the two).  A zero scale (gamma == 0: xhat is not recoverable) adds 0.
+template <typename TP, typename TG>
+__global__ __launch_bounds__(256) void bn_pool_bwd_stats_p_kernel(const TP* __restrict__ P, const TG* __restrict__ dP,
+                                                                  const TG* __restrict__ dxl, float inv_To,
+                                                                  const float* __restrict__ scale, const float* __restrict__ shift,
+                                                                  const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                                  float* __restrict__ stat, int N, int To, int Fo) {
+    __shared__ float red[256][16];
+    const long total = (long)N * To * Fo * 8;
+    float db[8], dg[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { db[i] = 0.f; dg[i] = 0.f; }
+    // the stride is a multiple of 8: a thread keeps its channel chunk over the trips; xhat = a * k1 + k0 per channel
+    const int c8 = threadIdx.x & 7;
+    float k1[8], k0[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int c = c8 * 8 + i;
+        const float sc = scale[c], inv = sc != 0.f ? 1.f / sc : 0.f;
+        k1[i] = inv * rstd[c];
+        k0[i] = sc != 0.f ? -(shift[c] * inv + mean[c]) * rstd[c] : 0.f;
+    }
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+        const long pos = idx >> 3;                                   // (n, to, fo)
+        const Vec8<TP> pv = Vec8<TP>::load(P + pos * 64 + c8 * 8);
+        const Vec8<TG> gp = Vec8<TG>::load(dP + pos * 64 + c8 * 8);
+        float g[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) g[i] = gp.get(i);
+        if (dxl) {
+            const long n = pos / ((long)To * Fo);
+            const int fo = (int)(pos % Fo);
+            const Vec8<TG> gx = Vec8<TG>::load(dxl + (n * Fo + fo) * 64 + c8 * 8);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) g[i] += gx.get(i) * inv_To;
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const float a = pv.get(i);
+            const float da = a > 0.f ? g[i] : 0.f;
+            db[i] += da;
+            dg[i] += da * (a * k1[i] + k0[i]);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { red[threadIdx.x][i] = db[i]; red[threadIdx.x][8 + i] = dg[i]; }
+    __syncthreads();
+    if (threadIdx.x < 128) {
+        const int kind = threadIdx.x >> 6, c = threadIdx.x & 63;
+        float t = 0.f;
+        for (int r = (c >> 3); r < 256; r += 8) t += red[r][kind * 8 + (c & 7)];
+        atomicAdd(&stat[128 + (blockIdx.x & 31) * 128 + kind * 64 + c], t);
+    }
+}
+
 // stat[0..127] = sum over the 32 replicas stat[128 + r*128 + ...]
 __global__ void stat_reduce_kernel(float* stat) {
     const int i = threadIdx.x;
@@ -507,7 +565,7 @@ __global__ void add_stat_kernel(const float* __restrict__ stat, float* dgamma, f
 // phase: 0 = everything (statistics, fold, apply, parameter gradients); 1 = statistics + fold only (stat[0..127] = this rank's
 // sum g / sum g xhat); 2 = apply with the sums in `gstat` over `count` elements (the all-reduced sums of SyncBatchNorm) and add
 // this rank's own sums (stat) to dgamma / dbeta
-static int bn_relu_pool_bwd_run(int phase, int dtype, int ydtype, int gdtype, const void* Y, const void* dP, const void* dxl,
+static int bn_relu_pool_bwd_run(int phase, int dtype, int ydtype, int gdtype, const void* Y, const void* P, const void* dP, const void* dxl,
                                 const float* scale, const float* shift, const float* mean, const float* rstd, float* stat,
                                 const float* gstat, double count, void* dY, float* dgamma, float* dbeta, int N, int Ti, int Fi,
                                 void* stream) {
@@ -525,14 +583,20 @@ static int bn_relu_pool_bwd_run(int phase, int dtype, int ydtype, int gdtype, co
 #define BW(TY, AP, TG, TO, ST) hipLaunchKernelGGL((bn_relu_pool_bwd_kernel<TY, AP, TG, TO>), dim3(grid), dim3(256), 0, s,              \
         static_cast<const TY*>(Y), static_cast<const TG*>(dP), static_cast<const TG*>(dxl), inv_To, scale, shift, mean, rstd, ST, \
         inv_count, static_cast<TO*>(dY), N, Ti, Fi)
-#define BW2(TY, TG, TO) do { if (phase != 2) { BW(TY, false, TG, TO, stat); hipLaunchKernelGGL(stat_reduce_kernel, dim3(1), dim3(128), 0, s, stat); } \
+#define BWP(TG, TO) hipLaunchKernelGGL((bn_pool_bwd_stats_p_kernel<TO, TG>), dim3(pgrid), dim3(256), 0, s, static_cast<const TO*>(P),          \
+        static_cast<const TG*>(dP), static_cast<const TG*>(dxl), inv_To, scale, shift, mean, rstd, stat, N, Ti / 2, Fi / 2)
+#define BW2(TY, TG, TO) do { if (phase != 2) { if (P) BWP(TG, TO); else BW(TY, false, TG, TO, stat);                                       \
+                                               hipLaunchKernelGGL(stat_reduce_kernel, dim3(1), dim3(128), 0, s, stat); }                     \
                              if (phase != 1) BW(TY, true, TG, TO, apply_stat); } while (0)
+    const long ptotal = (long)N * (Ti / 2) * (Fi / 2) * 8;
+    const int pgrid = (int)min((long)2048, (ptotal + 255) / 256);         // 2,048 x 256 threads: a multiple of 8, see the kernel
     if (dtype == 0) BW2(float, float, float);
     else if (ydtype == 0 && gdtype == 0) BW2(float, float, bf16);
     else if (ydtype == 0) BW2(float, bf16, bf16);
     else if (gdtype == 0) BW2(bf16, float, bf16);
     else BW2(bf16, bf16, bf16);
 #undef BW2
+#undef BWP
 #undef BW
     if (phase != 1) hipLaunchKernelGGL(add_stat_kernel, dim3(1), dim3(64), 0, s, stat, dgamma, dbeta);
     ASSL_LAUNCH_CHECK();
@@ -541,13 +605,20 @@ static int bn_relu_pool_bwd_run(int phase, int dtype, int ydtype, int gdtype, co
 extern "C" int audiossl_bn_relu_pool_bwd(int dtype, int ydtype, int gdtype, const void* Y, const void* dP, const void* dxl, const float* scale,
                                          const float* shift, const float* mean, const float* rstd, float* stat, void* dY,
                                          float* dgamma, float* dbeta, int N, int Ti, int Fi, void* stream) {
-    return bn_relu_pool_bwd_run(0, dtype, ydtype, gdtype, Y, dP, dxl, scale, shift, mean, rstd, stat, nullptr, 0.0, dY, dgamma, dbeta, N,
+    return bn_relu_pool_bwd_run(0, dtype, ydtype, gdtype, Y, nullptr, dP, dxl, scale, shift, mean, rstd, stat, nullptr, 0.0, dY, dgamma, dbeta, N,
+                                Ti, Fi, stream);
+}
+extern "C" int audiossl_bn_relu_pool_bwd_p(int dtype, int ydtype, int gdtype, const void* Y, const void* P, const void* dP, const void* dxl,
+                                           const float* scale, const float* shift, const float* mean, const float* rstd, float* stat,
+                                           void* dY, float* dgamma, float* dbeta, int N, int Ti, int Fi, void* stream) {
+    ASSL_REQUIRE(P);
+    return bn_relu_pool_bwd_run(0, dtype, ydtype, gdtype, Y, P, dP, dxl, scale, shift, mean, rstd, stat, nullptr, 0.0, dY, dgamma, dbeta, N,
                                 Ti, Fi, stream);
 }
 extern "C" int audiossl_bn_relu_pool_bwd_stats(int dtype, int ydtype, int gdtype, const void* Y, const void* dP, const void* dxl,
                                                const float* scale, const float* shift, const float* mean, const float* rstd,
                                                float* stat, int N, int Ti, int Fi, void* stream) {
-    return bn_relu_pool_bwd_run(1, dtype, ydtype, gdtype, Y, dP, dxl, scale, shift, mean, rstd, stat, nullptr, 0.0, nullptr, nullptr,
+    return bn_relu_pool_bwd_run(1, dtype, ydtype, gdtype, Y, nullptr, dP, dxl, scale, shift, mean, rstd, stat, nullptr, 0.0, nullptr, nullptr,
                                 nullptr, N, Ti, Fi, stream);
 }
 extern "C" int audiossl_bn_relu_pool_bwd_apply(int dtype, int ydtype, int gdtype, const void* Y, const void* dP, const void* dxl,
@@ -555,7 +626,7 @@ extern "C" int audiossl_bn_relu_pool_bwd_apply(int dtype, int ydtype, int gdtype
                                                float* stat, const float* gstat, double count_global, void* dY, float* dgamma,
                                                float* dbeta, int N, int Ti, int Fi, void* stream) {
     ASSL_REQUIRE(gstat && count_global > 1.0);
-    return bn_relu_pool_bwd_run(2, dtype, ydtype, gdtype, Y, dP, dxl, scale, shift, mean, rstd, stat, gstat, count_global, dY, dgamma,
+    return bn_relu_pool_bwd_run(2, dtype, ydtype, gdtype, Y, nullptr, dP, dxl, scale, shift, mean, rstd, stat, gstat, count_global, dY, dgamma,
                                 dbeta, N, Ti, Fi, stream);
 }
 

@@ -339,6 +339,7 @@ def _wgrad_workspace(device):
 
 STAT_REPLICAS = 8
 LOSS_REPLICAS = 32          # replicas of a Barlow loss term accumulated by the correlation GEMM's epilogue (gemm_multi_barlow)
+_BN_STATS_P = os.environ.get("AUDIOSSL_BN_STATS_P", "1") != "0"  # 0: BatchNorm-backward sums from a first sweep over the conv output
 _DP1_BF16 = os.environ.get("AUDIOSSL_DP1_BF16", "1") != "0"      # 0: the gradient into the stem backward stays fp32
 
 
@@ -472,7 +473,7 @@ def encoder_forward(P, x, dtype, keep=None, p_drop=0.3, train=True, update_runni
     return x1, x2, x3, c.H2.view(Nimg, T3, d), c
 
 
-def _conv_block_bwd(dtype, Y, dP, dxl, st, Nimg, Ti, Fi, Pin, Wd, G_w, G_gamma, G_beta, need_dx, col, keep, dx_bf16=False):
+def _conv_block_bwd(dtype, Y, dP, dxl, st, Nimg, Ti, Fi, Pin, Wd, G_w, G_gamma, G_beta, need_dx, col, keep, dx_bf16=False, Pout=None):
     """BN/ReLU/pool backward + conv wgrad (+ dgrad).  Returns dPin or None.  `keep`: list that holds the tensors the
     side-stream weight gradient still reads until the caller joins the streams."""
     td = N.torch_dtype(dtype)
@@ -481,7 +482,10 @@ def _conv_block_bwd(dtype, Y, dP, dxl, st, Nimg, Ti, Fi, Pin, Wd, G_w, G_gamma, 
     dY = torch.empty((M, 64), dtype=td, device=Y.device)
     stat = ARENA.scratch((33 * 128,), torch.float32, Y)
     yd = N.F32 if Y.dtype == torch.float32 else dtype
-    if SYNC_BN is None:
+    if SYNC_BN is None and Pout is not None and _BN_STATS_P and Pout.dtype == td:
+        # dbeta / dgamma from the block's pooled output (26 MB) instead of a first sweep over Y (105 MB at B = 512, block 2)
+        N.call("bn_relu_pool_bwd_p", dtype, yd, GD, Y, Pout, dP, dxl, scale, shift, mean, rstd, stat, dY, G_gamma, G_beta, Nimg, Ti, Fi)
+    elif SYNC_BN is None:
         N.call("bn_relu_pool_bwd", dtype, yd, GD, Y, dP, dxl, scale, shift, mean, rstd, stat, dY, G_gamma, G_beta, Nimg, Ti, Fi)
     else:
         N.call("bn_relu_pool_bwd_stats", dtype, yd, GD, Y, dP, dxl, scale, shift, mean, rstd, stat, Nimg, Ti, Fi)
@@ -551,9 +555,10 @@ def encoder_backward(c, G, dA2=None, dH2=None, dx1=None, dx2=None, dx3=None, dx_
     col = _col_buffer(dtype, Nimg, T1, F1, c.H2)
     keep = []
     dP2 = _conv_block_bwd(dtype, c.Y3, dP3, dx3, c.st3, Nimg, T2, F2, c.P2, c.W3d, G["features_3.0.weight"],
-                          G["features_3.1.weight"], G["features_3.1.bias"], True, col, keep)
+                          G["features_3.1.weight"], G["features_3.1.bias"], True, col, keep, Pout=c.P3)
     dP1 = _conv_block_bwd(dtype, c.Y2, dP2, dx2, c.st2, Nimg, T1, F1, c.P1, c.W2d, G["features_2.0.weight"],
-                          G["features_2.1.weight"], G["features_2.1.bias"], True, col, keep, dx_bf16=bool(c.stem_mfma) and _DP1_BF16)
+                          G["features_2.1.weight"], G["features_2.1.bias"], True, col, keep, dx_bf16=bool(c.stem_mfma) and _DP1_BF16,
+                          Pout=c.P2)
     gd1 = N.BF16 if dP1.dtype == torch.bfloat16 else GD
     acc = ARENA.scratch((32 * 64 * 11,), torch.float32, c.H2)
     P = c.P

@@ -147,6 +147,11 @@ int audiossl_tmean3_fwd(int dtype, int out_f32, const void* P1, void* x1, const 
 int audiossl_bn_relu_pool_bwd(int dtype, int ydtype, int gdtype, const void* Y, const void* dP, const void* dxl, const float* scale,
                               const float* shift, const float* mean, const float* rstd, float* stat, void* dY,
                               float* dgamma, float* dbeta, int N, int Ti, int Fi, void* stream);
+/* The same with the statistics pass (dbeta, dgamma) taken from the block's POOLED forward output P [N][Ti/2][Fi/2][64] (activation
+ * dtype) instead of a first sweep over Y: the routed gradient lives where P > 0, and there xhat = ((P - shift) / scale - mean) rstd. */
+int audiossl_bn_relu_pool_bwd_p(int dtype, int ydtype, int gdtype, const void* Y, const void* P, const void* dP, const void* dxl,
+                                const float* scale, const float* shift, const float* mean, const float* rstd, float* stat, void* dY,
+                                float* dgamma, float* dbeta, int N, int Ti, int Fi, void* stream);
 /* ---- SyncBatchNorm halves (C2: `nn.SyncBatchNorm.convert_sync_batchnorm`, extras/decar-v2/main.py:82).  Every train-mode
  * BatchNorm of the path exists as "sums" + "finalize / apply" with the rank's sums in plain buffers in between, so the caller can
  * all-reduce them (RCCL) and pass the GLOBAL element count:

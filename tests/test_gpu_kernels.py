@@ -509,6 +509,51 @@ def test_conv3x3_implicit_gemm_fwd_dgrad_wgrad(N, shape):
         assert rel_l2(dW.cpu(), ref_dw.cpu()) < 1e-5
 
 
+# ----------------------------------------------------------------- BatchNorm2d(train) + ReLU + MaxPool2d(2) backward
+@pytest.mark.parametrize("shape", [(5, 24, 16), (3, 25, 32), (40, 50, 32)])
+def test_bn_relu_pool_bwd_sums_from_the_pooled_output(N, shape):
+    """`bn_relu_pool_bwd_p` (dbeta / dgamma from the pooled forward output) against `bn_relu_pool_bwd` (a first sweep over the
+    conv output) and against torch autograd through BatchNorm2d(train) -> ReLU -> MaxPool2d(2) in fp64 on the same bf16 conv
+    output.  Odd Ti: the last time row is outside the pooled area."""
+    Nimg, Ti, Fi = shape
+    To, Fo = Ti // 2, Fi // 2
+    g = torch.Generator().manual_seed(11 + Ti)
+    Y = (torch.randn(Nimg, Ti, Fi, 64, generator=g) * 1.3 + 0.2).cuda().bfloat16()
+    gamma = (torch.rand(64, generator=g) + 0.5).cuda()
+    gamma[3] = -0.7                                                  # a negative scale: the window's arg-max is the conv output's arg-min
+    beta = (torch.randn(64, generator=g) * 0.3).cuda()
+    dP = torch.randn(Nimg, To, Fo, 64, generator=g).cuda()
+    dxl = torch.randn(Nimg, Fo, 64, generator=g).cuda()
+    # reference (fp64 autograd)
+    y64 = Y.double().requires_grad_(True)
+    g64, b64 = gamma.double().requires_grad_(True), beta.double().requires_grad_(True)
+    mean, var = y64.mean((0, 1, 2)), y64.var((0, 1, 2), unbiased=False)
+    a = (y64 - mean) / torch.sqrt(var + 1e-5) * g64 + b64
+    # torch's layout is [N][C][F][T] (audiontt.py): ties inside a window (a few % of the bf16 windows) go to the first maximum in (f, t) order
+    P64 = torch.nn.functional.max_pool2d(torch.relu(a).permute(0, 3, 2, 1), 2).permute(0, 3, 2, 1)     # -> [N][To][Fo][64]
+    (P64 * dP.double()).sum().add((P64.mean(1) * dxl.double()).sum()).backward()
+    rstd = 1.0 / torch.sqrt(var.detach() + 1e-5)
+    scale = (gamma.double() * rstd).float().contiguous()
+    shift = (beta.double() - mean.detach() * gamma.double() * rstd).float().contiguous()
+    mean32, rstd32 = mean.detach().float().contiguous(), rstd.float().contiguous()
+    Pb = P64.detach().bfloat16().contiguous()                       # what the forward kernel stores
+    outs = []
+    for entry in ("bn_relu_pool_bwd", "bn_relu_pool_bwd_p"):
+        stat = torch.empty(33 * 128, device="cuda")
+        dY = torch.empty(Nimg, Ti, Fi, 64, device="cuda", dtype=torch.bfloat16)
+        dg, db = torch.zeros(64, device="cuda"), torch.zeros(64, device="cuda")
+        args = (N.BF16, N.BF16, N.F32, Y) + ((Pb,) if entry.endswith("_p") else ()) + (dP, dxl, scale, shift, mean32, rstd32, stat, dY, dg, db,
+                                                                                        Nimg, Ti, Fi)
+        N.call(entry, *args)
+        torch.cuda.synchronize()
+        outs.append((dg.cpu(), db.cpu(), dY.float().cpu()))
+        assert rel_l2(dg.cpu(), g64.grad.float().cpu()) < 4e-3, entry
+        assert rel_l2(db.cpu(), b64.grad.float().cpu()) < 4e-3, entry
+        assert rel_l2(dY.float().cpu(), y64.grad.float().cpu()) < 8e-3, entry
+    (dg0, db0, dY0), (dg1, db1, dY1) = outs
+    assert rel_l2(dg1, dg0) < 2e-3 and rel_l2(db1, db0) < 2e-3 and rel_l2(dY1, dY0) < 4e-3
+
+
 # ------------------------------------------------------------------------- fused BatchNorm1d(train) of the projector
 @pytest.mark.parametrize("adtype,gdtype", [(1, 0), (0, 0), (1, 1)])
 @pytest.mark.parametrize("M,C,affine,relu", [(512, 256, True, 1), (200, 64, False, 0), (1000, 96, True, 1)])
