@@ -614,10 +614,10 @@ def projector_forward(PP, Y, dtype, groups, B, update_running=True, Wc=None):
     c.D = D
     M = groups * B
 
-    def bn(a, prefix, affine, relu, out):
+    def bn(a, prefix, affine, relu, out, adt=None):
         g = PP[prefix + ".weight"] if affine else None
         b = PP[prefix + ".bias"] if affine else None
-        return bn_train_apply(dtype, ad, a, B, D, g, b, PP[prefix + ".running_mean"], PP[prefix + ".running_var"],
+        return bn_train_apply(dtype, ad if adt is None else adt, a, B, D, g, b, PP[prefix + ".running_mean"], PP[prefix + ".running_var"],
                               update_running, groups, relu, out)
     td = N.torch_dtype(dtype)
     ad = _ad(dtype)
@@ -626,7 +626,7 @@ def projector_forward(PP, Y, dtype, groups, B, update_running=True, Wc=None):
     # pre-BatchNorm tensors (a1, a2, z) are fp32 GEMM outputs on the fp32 / bf16_hp paths; the normalised activations
     # (MFMA operands) are `dtype`
     c.cmean = None
-    if dtype == N.BF16 and Y.dtype == torch.float32 and not HP and B <= 1024 and kin % 32 == 0:
+    if dtype == N.BF16 and Y.dtype == torch.float32 and not HP and B <= 1024 and kin % 32 == 0 and SYNC_BN is None:
         # time-pooled post-ReLU features: |mean| >> batch-std, so a single bf16 rounding would eat the batch variation
         # that BatchNorm amplifies.  The layer is Linear(no bias) -> train-mode BatchNorm, i.e. blind to a constant per input
         # column: feed it the CENTRED features (csrc/heads.hip center_cast_kernel); the weight gradient is unchanged too.
@@ -634,7 +634,8 @@ def projector_forward(PP, Y, dtype, groups, B, update_running=True, Wc=None):
         c.y_lo = None
         c.a1 = linear_fwd(dtype, c.y_hi, W[0], M, D, kin, out_f32=o32)
     elif dtype == N.BF16 and Y.dtype == torch.float32:
-        # bf16_hp: the first GEMM on hi + lo bf16 pieces of the operand (fp32 accumulate into the same output)
+        # bf16_hp - and SyncBatchNorm, where a per-RANK column mean is not a constant of the (global) batch any more: the first GEMM
+        # on hi + lo bf16 pieces of the operand (fp32 accumulate into the same output)
         c.y_hi, c.y_lo = _empty((M, kin), td, like=Y), _empty((M, kin), td, like=Y)
         N.call("split_bf16", Y, c.y_hi, c.y_lo, M * kin)
         c.a1 = torch.zeros(M, D, dtype=torch.float32, device=Y.device)
@@ -643,8 +644,9 @@ def projector_forward(PP, Y, dtype, groups, B, update_running=True, Wc=None):
     else:
         c.y_hi, c.y_lo = Y, None
         c.a1 = linear_fwd(dtype, Y, W[0], M, D, kin, out_f32=o32)
+    c.ad1 = N.F32 if c.a1.dtype == torch.float32 else ad     # the hi + lo form accumulates the first layer in fp32 whatever the path
     c.h1 = _empty((M, D), td, like=Y)
-    c.st1 = bn(c.a1, "projector.1", True, 1, c.h1)
+    c.st1 = bn(c.a1, "projector.1", True, 1, c.h1, adt=c.ad1)
     if c.cmean is not None and update_running:
         N.call("shift_running_mean", W[0], c.cmean, PP["projector.1.running_mean"], D, kin, groups, BN_MOMENTUM)
     c.a2 = linear_fwd(dtype, c.h1, W[1], M, D, D, out_f32=o32)
@@ -659,25 +661,39 @@ def projector_forward(PP, Y, dtype, groups, B, update_running=True, Wc=None):
 def projector_backward(c, PP, G, dzn, dy_rows=None):
     """dzn [groups*B, D] (activation dtype) -> accumulates projector grads into G; returns dY for the first `dy_rows`
     rows of the stacked input (None: all rows, 0: skip)."""
-    if SYNC_BN is not None:
-        raise NotImplementedError("SyncBatchNorm is wired for the encoder and BatchNorm1dFn (DeepCluster-v2), not for the Barlow projector")
     dtype, B, D, kin, groups = c.dtype, c.B, c.D, c.kin, c.groups
     M = groups * B
     td = N.torch_dtype(dtype)
-    def tmp():                                   # one fresh (zeroed) statistics scratch per BatchNorm backward
-        return ARENA.scratch((2 * groups * D,), torch.float64, dzn)
+
+    def bn_bwd(a, dh, st, relu, da, g_gamma, g_beta, adt=None):
+        adt = c.ad if adt is None else adt
+        """BatchNorm1d(train) backward per group (view).  SyncBatchNorm (`extras/delores-s/main.py:79` converts every BatchNorm of
+        the model, the projector's included): the two means of the backward are over the GLOBAL batch of the view - this rank's
+        sums are all-reduced between the statistics pass and the apply pass; the parameter gradients stay this rank's own sums
+        (the data-parallel gradient all-reduce adds the ranks up afterwards)."""
+        t = ARENA.scratch((2 * groups * D,), torch.float64, dzn)      # a fresh (zeroed) statistics scratch per BatchNorm backward
+        if SYNC_BN is None:
+            N.call("colbn_bwd", dtype, adt, GD, a, dh, *st, relu, groups, B, D, t, da, g_gamma, g_beta)
+            return
+        N.call("colbn_bwd_stats", dtype, adt, GD, a, dh, *st, relu, groups, B, D, t)
+        tg = SYNC_BN.all_reduce(t.clone())
+        N.call("colbn_bwd_apply", dtype, adt, GD, a, dh, *st, relu, groups, B, D, tg, float(B * SYNC_BN.world), da)
+        if g_gamma is not None:
+            for g in range(groups):              # t = [dbeta sums: groups x D][dgamma sums: groups x D]
+                N.call("add_d2f", t[g * D:(g + 1) * D], g_beta, D)
+                N.call("add_d2f", t[(groups + g) * D:(groups + g + 1) * D], g_gamma, D)
     dz = _empty((M, D), td, like=c.zn)
     # gradients entering a BatchNorm backward (dzn, dh2, dh1) are fp32 GEMM outputs; its outputs (dz, da2, da1) are
     # MFMA operands only and are stored in the activation dtype
-    N.call("colbn_bwd", dtype, c.ad, GD, c.z, dzn, *c.st0, 0, groups, B, D, tmp(), dz, None, None)
+    bn_bwd(c.z, dzn, c.st0, 0, dz, None, None)
     linear_bwd_w(dtype, dz, c.h2, G["projector.6.weight"], M, D, D)
     dh2 = linear_bwd_x(dtype, dz, c.W[2], M, D, D, out_f32=1)
     da2 = _empty((M, D), td, like=c.zn)
-    N.call("colbn_bwd", dtype, c.ad, GD, c.a2, dh2, *c.st2, 1, groups, B, D, tmp(), da2, G["projector.4.weight"], G["projector.4.bias"])
+    bn_bwd(c.a2, dh2, c.st2, 1, da2, G["projector.4.weight"], G["projector.4.bias"])
     linear_bwd_w(dtype, da2, c.h1, G["projector.3.weight"], M, D, D)
     dh1 = linear_bwd_x(dtype, da2, c.W[1], M, D, D, out_f32=1)
     da1 = _empty((M, D), td, like=c.zn)
-    N.call("colbn_bwd", dtype, c.ad, GD, c.a1, dh1, *c.st1, 1, groups, B, D, tmp(), da1, G["projector.1.weight"], G["projector.1.bias"])
+    bn_bwd(c.a1, dh1, c.st1, 1, da1, G["projector.1.weight"], G["projector.1.bias"], adt=c.ad1)
     linear_bwd_w(dtype, da1, c.y_hi, G["projector.0.weight"], M, D, kin)
     if c.y_lo is not None:
         linear_bwd_w(dtype, da1, c.y_lo, G["projector.0.weight"], M, D, kin)

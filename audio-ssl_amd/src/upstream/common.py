@@ -369,7 +369,8 @@ class FusedExpertMixin:
         return GraphedStep(self, opt, eager_steps, world, phases)
 
     def graph_phases_supported(self):
-        return True
+        from src import engine as E
+        return E.SYNC_BN is None                # SyncBatchNorm puts all-reduces inside the phases: eager steps
 
     def publish_grads(self, g):
         if self.hip_optimizer is None:

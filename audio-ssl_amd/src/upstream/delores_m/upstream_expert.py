@@ -130,7 +130,7 @@ class Upstream_Expert(MocoQueueMixin, FusedExpertMixin, UpstreamModule):
 
         # the grouped heads STORE their nine weight gradients (single unsplit writer each): those need no clearing between steps
         heads = (self.p1, self.p2, self.p3)
-        grouped = not (self.high_precision or dt == N.F32 or not self.grouped_heads)
+        grouped = not (self.high_precision or dt == N.F32 or not self.grouped_heads or E.SYNC_BN is not None)   # SyncBatchNorm: per-head chains
         D_ = self.p1.param_dict()["projector.3.weight"].shape[0]
         kins_ = [p.param_dict()["projector.0.weight"].shape[1] for p in heads]
         stored_grads = tuple(f"p{i + 1}.projector.{j}.weight" for i in range(3) for j in (0, 3, 6)) \

@@ -96,7 +96,7 @@ class Upstream_Expert(FusedExpertMixin, UpstreamModule):
 
     def graph_phases_supported(self):
         ar, _ = self._barlow_reduce()
-        return ar is None                                   # cross-GPU Barlow has an all-reduce inside the forward phase
+        return ar is None and E.SYNC_BN is None             # cross-GPU Barlow / SyncBatchNorm: all-reduces inside the phases
 
     def _barlow_reduce(self):
         import torch.distributed as dist

@@ -69,6 +69,11 @@ class HipTrainer:
             sampler = torch.utils.data.distributed.DistributedSampler(dm.train_dataset, self.world, self.rank, shuffle=True)
         loader = dm.train_dataloader(sampler=sampler)
         opt = self.optimizer = model.configure_optimizers()
+        # run.sync_batchnorm: `nn.SyncBatchNorm.convert_sync_batchnorm` of the extras trainers (extras/delores-s/main.py:79): every
+        # train-mode BatchNorm - stem, conv blocks, projector - takes its statistics (forward and backward) over the global batch
+        from src import engine as E
+        sync = bool(getattr(model, "config", {}).get("run", {}).get("sync_batchnorm", False))
+        E.set_sync_bn(E.SyncBN() if (sync and self.world > 1) else None)
         if self.resume:
             ck = torch.load(self.resume, map_location=dev, weights_only=True)
             model.load_state_dict(ck["state_dict"], strict=False)

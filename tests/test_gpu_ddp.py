@@ -259,6 +259,81 @@ def test_two_rank_sync_batchnorm_equals_one_rank_on_the_whole_batch():
         np.testing.assert_array_equal(r0[k], r1[k], err_msg=k)
 
 
+def _delores_s_syncbn_step(world, rank, prec):
+    """One fused forward / backward of DeLoRes-S on this rank's slice of a fixed 16-clip batch, with the extras trainer's
+    semantics at world > 1: SyncBatchNorm everywhere (projector included) and the cross-GPU Barlow correlation."""
+    from oracle import fill
+    from helpers import drop_mask, views
+    from src import engine as E
+    from src.encoder import AudioNTT2020Task6
+    from src.upstream.delores_s.upstream_expert import Upstream_Expert
+    B, T = 16, 96
+    cfg = copy.deepcopy(CFG_S)
+    cfg["run"]["precision"] = prec
+    cfg["run"]["cross_gpu_barlow"] = world > 1
+    m = Upstream_Expert(cfg, base_encoder=AudioNTT2020Task6)
+    fill.fill_state_dict_(m, seed=35)
+    m = m.cuda().train()
+    flat = m.ensure_flat()
+    lo, hi = rank * (B // world), (rank + 1) * (B // world)
+    x1, x2 = views(B, T, 9700)[lo:hi].cuda(), views(B, T, 9701)[lo:hi].cuda()
+    m.encoder.encoder.dropout_masks.queue = [drop_mask((B, T // 8, 2048), 9702)[lo:hi], drop_mask((B, T // 8, 2048), 9703)[lo:hi]]
+    E.set_sync_bn(E.SyncBN() if world > 1 else None)
+    try:
+        loss = m.fused_loss(x1, x2, True)
+        if world > 1:
+            m.all_reduce_grads()                                    # joins the step's own all-reduces: the MEAN over ranks, as DistributedDataParallel
+            flat.grad.mul_(world)                                   # with the global correlation every rank backpropagates the same loss through its
+        torch.cuda.synchronize()                                    # own clips: the SUM over ranks is the whole-batch gradient
+    finally:
+        E.set_sync_bn(None)
+    sd = m.state_dict()
+    return {"loss": float(loss), "g": {n: flat.grad_view(i).detach().cpu().numpy().copy() for i, n in enumerate(flat.names)},
+            "rm": {k: v.float().cpu().numpy() for k, v in sd.items() if k.endswith(("running_mean", "running_var"))}}
+
+
+def _worker_syncbn_s(rank, world, port, prec, ret):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        ret[rank] = _delores_s_syncbn_step(world, rank, prec)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("prec", ["fp32", "bf16"])
+def test_two_rank_sync_batchnorm_barlow_projector_equals_one_rank(prec):
+    """SyncBatchNorm of the Barlow projector (`extras/delores-s/main.py:79` converts EVERY BatchNorm; models_byol.py:108-112 sums
+    the correlation over the ranks): two ranks with 8 clips each - global statistics in every BatchNorm forward and backward of
+    encoder AND projector, the first projector GEMM on the un-centred hi + lo operand, the D x D correlation all-reduced - against
+    ONE rank on all 16 clips with plain BatchNorm: same loss on both ranks, the summed gradients equal the whole-batch gradient,
+    the running statistics agree.  bf16: the one-rank run centres the projector input per view, the two-rank run splits it."""
+    from helpers import rel_l2
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker_syncbn_s, args=(2, port, prec, ret), nprocs=2, join=True)
+    one = _delores_s_syncbn_step(1, 0, prec)
+    r0, r1 = ret[0], ret[1]
+    # bf16: two bf16 runs with different arithmetic in the first projector layer and different BatchNorm partial sums; the end of the
+    # backward chain (stem weights) differs most
+    tol_l, tol_g = (2e-4, 3e-3) if prec == "fp32" else (2e-2, 1e-1)
+    assert abs(r0["loss"] - r1["loss"]) <= 2e-6 * abs(r0["loss"])    # the loss of the GLOBAL correlation on both ranks (replica sums: fp32 atomics)
+    assert abs(r0["loss"] - one["loss"]) <= tol_l * abs(one["loss"])
+    for n, g in one["g"].items():
+        np.testing.assert_array_equal(r0["g"][n], r1["g"][n], err_msg=n)
+        if float(np.abs(g).max()) < 1e-6 and float(np.abs(r0["g"][n]).max()) < 1e-5:
+            continue                                                # a bias in front of a train-mode BatchNorm: zero gradient
+        assert rel_l2(torch.from_numpy(r0["g"][n]), torch.from_numpy(g)) < tol_g, n
+    for k in one["rm"]:
+        np.testing.assert_allclose(r0["rm"][k], one["rm"][k], rtol=2e-3 if prec == "fp32" else 2e-2, atol=1e-5 if prec == "fp32" else 2e-3,
+                                   err_msg=k)
+        np.testing.assert_array_equal(r0["rm"][k], r1["rm"][k], err_msg=k)
+
+
 @pytest.mark.parametrize("which", ["ssmast", "ssmast_mvit"])
 def test_two_rank_ssmast_eager_and_graph_phases(which):
     """BASELINE config 4 is an 8-GPU configuration: the SS-MAST step (`extras/mast_new/mast/moco_model.py:253-340`: both directions,
