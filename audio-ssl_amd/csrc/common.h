@@ -82,6 +82,15 @@ template <> struct Vec8<float> {
     __device__ __forceinline__ void setraw(int i, float x) { set(i, x); }
 };
 
+// ---- torch.optim.SGD on one element: g += wd p; buf = first ? g : momentum buf + g; p -= lr buf -------------------------
+// ONE definition with explicit fused multiply-adds for the flat SGD pass (heads.hip) and the weight-gradient GEMM epilogue that
+// applies the update in place (gemm.hip): the two must agree bit for bit, whatever the compiler would contract on its own.
+__device__ __forceinline__ void sgd_step(float& p, float g, float& buf, float lr, float mom, float wd, float gscale, bool first) {
+    const float gg = __builtin_fmaf(wd, p, g * gscale);
+    buf = first ? gg : __builtin_fmaf(mom, buf, gg);
+    p = __builtin_fmaf(-lr, buf, p);
+}
+
 // ---- wave / block reductions ----------------------------------------------------------
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

@@ -57,6 +57,12 @@ struct GemmArgs {
     int bl_mode;
     float* bl_loss;           // [32] fp32 replicas (workgroup i adds into replica i & 31; the caller sums them)
     float bl_coef, bl_dscale;
+    // SGD epilogue (audiossl_gemm_multi_sgd): the fp32 result is a weight gradient that is consumed on the spot - parameter sgd_p and
+    // momentum sgd_m ([M][ldc] fp32, indexed like C) are updated in place, the bf16 copy of the new parameter goes to sgd_s (nullable);
+    // nothing is written to C
+    float* sgd_p; float* sgd_m; bf16* sgd_s;
+    const float* sgd_gs_dev;  // optional device scalar multiplied into the gradient scale
+    float sgd_lr, sgd_mu, sgd_wd, sgd_gs;
 };
 
 // kernel names as rocprofv3 prints them (demangled, except for instantiations on __bf16, which its demangler leaves mangled)
@@ -151,6 +157,13 @@ __device__ __forceinline__ void epilogue_lds(const GemmArgs& g, ACC& acc, char* 
         for (int u = 0; u < 8; ++u) {
             if (r0 + u >= rows) break;
             const long o = (long)(row0 + r0 + u) * g.ldc + col;
+            if (g.sgd_p) {
+                float pj = g.sgd_p[o], b = g.sgd_m[o];
+                sgd_step(pj, v[u], b, g.sgd_lr, g.sgd_mu, g.sgd_wd, g.sgd_gs_dev ? g.sgd_gs * g.sgd_gs_dev[0] : g.sgd_gs, false);
+                g.sgd_p[o] = pj; g.sgd_m[o] = b;
+                if (g.sgd_s) g.sgd_s[o] = (bf16)pj;
+                continue;
+            }
             if (g.atomic == 1)  atomicAdd(static_cast<float*>(g.C) + o, v[u]);
             else if (g.atomic)  static_cast<float*>(g.C)[o] += v[u];
             else if (g.out_f32) static_cast<float*>(g.C)[o] = v[u];
@@ -215,6 +228,21 @@ __device__ __forceinline__ void epilogue_vec(const GemmArgs& g, ACC& acc, char* 
             for (int u = 0; u < 8; ++u) v[u] += rs.get(u);
         }
         const long o = row * g.ldc + col;
+        if (g.sgd_p) {
+            const float gs = g.sgd_gs_dev ? g.sgd_gs * g.sgd_gs_dev[0] : g.sgd_gs;
+            Vec8<float> pv = Vec8<float>::load(g.sgd_p + o), mv = Vec8<float>::load(g.sgd_m + o);
+            Vec8<bf16> sv;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                float pj = pv.get(u), b = mv.get(u);
+                sgd_step(pj, v[u], b, g.sgd_lr, g.sgd_mu, g.sgd_wd, gs, false);
+                pv.set(u, pj); mv.set(u, b); sv.set(u, pj);
+            }
+            pv.store(g.sgd_p + o);
+            mv.store(g.sgd_m + o);
+            if (g.sgd_s) sv.store(g.sgd_s + o);
+            continue;
+        }
         if (g.out_f32) {
             Vec8<float> out;
             if (g.atomic) {                                   // exclusive accumulation (atomic == 2)
@@ -1684,6 +1712,40 @@ extern "C" int audiossl_gemm_multi(int count, int trans_a, int trans_b, int M, c
         kmin = min(kmin, K[i]);
     }
     return dispatch_multi(gm, count, M, N, kmin, ksplit, trans_a, trans_b, static_cast<hipStream_t>(stream), K, Nv);
+}
+
+// Weight gradients that are applied where they are produced: G_i = alpha * op(A_i) op(B_i) is the gradient of parameter P_i ([M][N_i]
+// fp32, leading dimension ldp[i]); the epilogue runs torch.optim.SGD's update on P_i and its momentum buffer Mom_i in place (sgd_step,
+// common.h - the same arithmetic as audiossl_sgd_momentum, bit for bit) and writes the bf16 copy of the new parameter to Shadow_i
+// (array or entries nullable).  G is never stored: per step that saves the 4-byte write and the optimiser's 4-byte read of every element
+// of the projector weights (264 MB at DeLoRes-M's three heads).  One K split only; the momentum buffers must exist (not the first step).
+extern "C" int audiossl_gemm_multi_sgd(int count, int trans_a, int trans_b, int M, const int* Nv, const int* K, float alpha,
+                                       const void* const* A, const long* lda, const void* const* B, const long* ldb,
+                                       float* const* P, float* const* Mom, void* const* Shadow, const long* ldp, float lr, float momentum,
+                                       float weight_decay, float grad_scale, const float* grad_scale_dev, void* stream) {
+    ASSL_REQUIRE(count >= 1 && count <= MAX_MULTI && Nv && K && A && B && P && Mom && lda && ldb && ldp && M > 0);
+    int N = 0;
+    for (int i = 0; i < count; ++i) { ASSL_REQUIRE(Nv[i] > 0); N = max(N, Nv[i]); }
+    GemmMulti gm;
+    int kmin = 1 << 30;
+    for (int i = 0; i < count; ++i) {
+        ASSL_REQUIRE(A[i] && B[i] && P[i] && Mom[i] && K[i] > 0);
+        ASSL_REQUIRE((trans_a ? M : K[i]) % 8 == 0 && (trans_b ? Nv[i] : K[i]) % 8 == 0);
+        if (!ASSL_ALIGNED16(A[i]) || !ASSL_ALIGNED16(B[i]) || lda[i] % 8 || ldb[i] % 8) return ASSL_EALIGN;
+        if (!ASSL_ALIGNED16(P[i]) || !ASSL_ALIGNED16(Mom[i]) || ldp[i] % 8 || Nv[i] % 8) return ASSL_EALIGN;
+        void* sh = Shadow ? Shadow[i] : nullptr;
+        if (sh && !ASSL_ALIGNED16(sh)) return ASSL_EALIGN;
+        const long a_ext = (trans_a ? ((long)(K[i] - 1) * lda[i] + M) : ((long)(M - 1) * lda[i] + K[i])) * 2;
+        const long b_ext = (trans_b ? ((long)(K[i] - 1) * ldb[i] + Nv[i]) : ((long)(Nv[i] - 1) * ldb[i] + K[i])) * 2;
+        ASSL_REQUIRE(a_ext < 0xFFFFFF00L && b_ext < 0xFFFFFF00L);
+        gm.p[i] = GemmArgs{A[i], B[i], P[i], M, Nv[i], K[i], lda[i], ldb[i], ldp[i], alpha, nullptr, 0, nullptr, 0, 1.f, nullptr, 0,
+                           1, 0, 1, nullptr, 0, (unsigned)a_ext, (unsigned)b_ext, 0};
+        gm.p[i].vec_epi = epi_vectorisable(gm.p[i], 1);
+        gm.p[i].sgd_p = P[i]; gm.p[i].sgd_m = Mom[i]; gm.p[i].sgd_s = static_cast<bf16*>(sh); gm.p[i].sgd_gs_dev = grad_scale_dev;
+        gm.p[i].sgd_lr = lr; gm.p[i].sgd_mu = momentum; gm.p[i].sgd_wd = weight_decay; gm.p[i].sgd_gs = grad_scale;
+        kmin = min(kmin, K[i]);
+    }
+    return dispatch_multi(gm, count, M, N, kmin, 1, trans_a, trans_b, static_cast<hipStream_t>(stream), K, Nv);
 }
 
 // The Barlow-twins cross-correlation of several heads, c_h = alpha * A_h^T B_h (A_h, B_h: [K_h][M] / [K_h][N] row-major, i.e. the

@@ -610,9 +610,9 @@ __global__ __launch_bounds__(256) void sgd_kernel(float* __restrict__ p, float* 
             f32x4 bv = first ? f32x4{0, 0, 0, 0} : *reinterpret_cast<f32x4*>(buf + i);
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-                const float gg = gv[k] * gscale + wd * pv[k];
-                bv[k] = first ? gg : mom * bv[k] + gg;
-                pv[k] -= lr * bv[k];
+                float pk = pv[k], bk = bv[k];
+                sgd_step(pk, gv[k], bk, lr, mom, wd, gscale, first);
+                pv[k] = pk; bv[k] = bk;
             }
             *reinterpret_cast<f32x4*>(buf + i) = bv;
             *reinterpret_cast<f32x4*>(p + i) = pv;
@@ -620,11 +620,49 @@ __global__ __launch_bounds__(256) void sgd_kernel(float* __restrict__ p, float* 
             if (zero_grad) *reinterpret_cast<f32x4*>(g + i) = f32x4{0.f, 0.f, 0.f, 0.f};
         } else {
             for (long j = i; j < n; ++j) {
-                const float gg = g[j] * gscale + wd * p[j];
-                const float b = first ? gg : mom * buf[j] + gg;
+                float pj = p[j], b = first ? 0.f : buf[j];
+                sgd_step(pj, g[j], b, lr, mom, wd, gscale, first);
                 buf[j] = b;
-                p[j] -= lr * b;
-                if (shadow) shadow[j] = (bf16)p[j];
+                p[j] = pj;
+                if (shadow) shadow[j] = (bf16)pj;
+                if (zero_grad) g[j] = 0.f;
+            }
+        }
+    }
+}
+
+// The same over a table of segments of the flat buffers (blockIdx.y = segment; offsets and lengths are multiples of 4 elements:
+// FlatGroup aligns every tensor to 64): the tensors of a slice whose other tensors were already stepped by the weight-gradient
+// GEMMs themselves (audiossl_gemm_multi_sgd)
+__global__ __launch_bounds__(256) void sgd_segments_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ buf,
+                                                           const long* __restrict__ segs, float lr, float mom, float wd, int first,
+                                                           float gscale_host, const float* __restrict__ gscale_dev,
+                                                           bf16* __restrict__ shadow, int zero_grad) {
+    const float gscale = gscale_dev ? gscale_host * gscale_dev[0] : gscale_host;
+    const long off = segs[2 * blockIdx.y], n = segs[2 * blockIdx.y + 1];
+    for (long i = ((long)blockIdx.x * 256 + threadIdx.x) * 4; i < n; i += (long)gridDim.x * 1024) {
+        const long e = off + i;
+        if (i + 4 <= n) {
+            f32x4 pv = *reinterpret_cast<f32x4*>(p + e);
+            const f32x4 gv = *reinterpret_cast<const f32x4*>(g + e);
+            f32x4 bv = first ? f32x4{0, 0, 0, 0} : *reinterpret_cast<f32x4*>(buf + e);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                float pk = pv[k], bk = bv[k];
+                sgd_step(pk, gv[k], bk, lr, mom, wd, gscale, first);
+                pv[k] = pk; bv[k] = bk;
+            }
+            *reinterpret_cast<f32x4*>(buf + e) = bv;
+            *reinterpret_cast<f32x4*>(p + e) = pv;
+            if (shadow) *reinterpret_cast<bf16x4*>(shadow + e) = bf16x4{(bf16)pv[0], (bf16)pv[1], (bf16)pv[2], (bf16)pv[3]};
+            if (zero_grad) *reinterpret_cast<f32x4*>(g + e) = f32x4{0.f, 0.f, 0.f, 0.f};
+        } else {
+            for (long j = e; j < off + n; ++j) {
+                float pj = p[j], b = first ? 0.f : buf[j];
+                sgd_step(pj, g[j], b, lr, mom, wd, gscale, first);
+                buf[j] = b;
+                p[j] = pj;
+                if (shadow) shadow[j] = (bf16)pj;
                 if (zero_grad) g[j] = 0.f;
             }
         }
@@ -1020,6 +1058,18 @@ extern "C" int audiossl_sgd_momentum(float* p, float* g, float* buf, long n, flo
     const int grid = (int)min((long)2048, (n + 1023) / 1024);
     hipLaunchKernelGGL(sgd_kernel, dim3(grid), dim3(256), 0, S_(stream), p, g, buf, n, lr, momentum, weight_decay, first, grad_scale,
                        grad_scale_dev, static_cast<bf16*>(shadow_bf16), zero_grad);
+    ASSL_LAUNCH_CHECK();
+}
+
+extern "C" int audiossl_sgd_momentum_segments(float* p, float* g, float* buf, const long* segs, int nseg, long max_n, float lr,
+                                              float momentum, float weight_decay, int first, float grad_scale,
+                                              const float* grad_scale_dev, void* shadow_bf16, int zero_grad, void* stream) {
+    ASSL_REQUIRE(p && g && buf && segs && nseg > 0 && nseg <= 65535 && max_n > 0);
+    if (!ASSL_ALIGNED16(p) || !ASSL_ALIGNED16(g) || !ASSL_ALIGNED16(buf)) return ASSL_EALIGN;
+    if (shadow_bf16 && (reinterpret_cast<size_t>(shadow_bf16) & 7)) return ASSL_EALIGN;
+    const int gx = (int)min((long)256, (max_n + 1023) / 1024);
+    hipLaunchKernelGGL(sgd_segments_kernel, dim3(gx, nseg), dim3(256), 0, S_(stream), p, g, buf, segs, lr, momentum, weight_decay, first,
+                       grad_scale, grad_scale_dev, static_cast<bf16*>(shadow_bf16), zero_grad);
     ASSL_LAUNCH_CHECK();
 }
 

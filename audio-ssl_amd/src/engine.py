@@ -763,6 +763,26 @@ def gemm_multi(ta, tb, M, Nn, Ks, As, ldas, Bs, ldbs, Cs, ldc, alpha=1.0, out_f3
            out_f32, atomic, ksplit)
 
 
+def gemm_multi_sgd(ta, tb, M, Nn, Ks, As, ldas, Bs, ldbs, Ps, Moms, Shadows, ldp, hyper, alpha=1.0):
+    """`gemm_multi` whose results are weight gradients applied on the spot (audiossl_gemm_multi_sgd): Ps / Moms fp32 parameters and
+    momentum buffers, Shadows the bf16 copies (or None); hyper = (lr, momentum, weight_decay, grad_scale, grad_scale_tensor)."""
+    import ctypes
+    n = len(As)
+    _multi_check(As, Bs, Ps, Moms, [] if Shadows is None else Shadows)
+    Ns = [Nn] * n if isinstance(Nn, int) else list(Nn)
+    ldps = [ldp] * n if isinstance(ldp, int) else list(ldp)
+    adr = ctypes.addressof
+    vp = ctypes.c_void_p
+    arrs = (_harr(ctypes.c_int, Ns), _harr(ctypes.c_int, Ks), _harr(vp, As), _harr(ctypes.c_long, ldas), _harr(vp, Bs),
+            _harr(ctypes.c_long, ldbs), _harr(vp, Ps), _harr(vp, Moms), _harr(vp, Shadows if Shadows is not None else [None] * n),
+            _harr(ctypes.c_long, ldps))
+    if N.PROFILE is not None:
+        N.PROFILE_NOTE = float(sum(2.0 * M * nn * kk for nn, kk in zip(Ns, Ks)))
+    lr, mu, wd, gs, gs_dev = hyper
+    N.call("gemm_multi_sgd", n, ta, tb, M, adr(arrs[0]), adr(arrs[1]), float(alpha), adr(arrs[2]), adr(arrs[3]), adr(arrs[4]), adr(arrs[5]),
+           adr(arrs[6]), adr(arrs[7]), adr(arrs[8]), adr(arrs[9]), float(lr), float(mu), float(wd), float(gs), gs_dev)
+
+
 def _heads_wgrad_split(D, kmax, M, nh):
     return _ksplit(D, kmax, M, max(256 // nh, 1))
 
@@ -775,7 +795,7 @@ def heads_wgrads_store(D, kins, M, grads_zero=True):
 
 
 def barlow_heads_forward_backward(PPs, Gs, Ys, dtype, lambds, scale_losses, loss_outs, update_running=True, backward=True,
-                                  Wcs=None, grads_zero=False, dy_ready=None):
+                                  Wcs=None, grads_zero=False, dy_ready=None, sgd=None):
     """`barlow_forward_backward` for several heads in lock-step: every step of the chain - GEMM, train-mode BatchNorm, loss -
     is ONE multi-problem launch over the heads (they differ only in the width of the first layer's input).
     Ys[h]: [2B, in_h] stacked views; returns dY_h [B, in_h] (gradient of view 1's input) per head, fp32.
@@ -862,6 +882,15 @@ def barlow_heads_forward_backward(PPs, Gs, Ys, dtype, lambds, scale_losses, loss
 
     def wgrad(dys, xs, name, ks):                        # dW_h [D, k_h] += dy_h^T x_h; one writer per dW, so no atomics unless split
         split = _heads_wgrad_split(D, max(ks), M, nh)
+        if sgd is not None:
+            # the optimiser's update of these weights happens in the GEMM's epilogue (HipSGD.fused_wgrad): the gradient never reaches
+            # memory.  The weight shadows W[h][i] it rewrites were last read by the data-gradient launches issued before on this stream.
+            if split != 1 or Wcs is None:
+                raise RuntimeError("fused SGD needs unsplit weight gradients and the flat weight shadows")
+            li = {"projector.0.weight": 0, "projector.3.weight": 1, "projector.6.weight": 2}[name]
+            gemm_multi_sgd(1, 1, D, ks, [M] * nh, dys, [D] * nh, xs, ks, [PPs[h][name] for h in H], [sgd["momentum"][h][name] for h in H],
+                           [W[h][li] for h in H], ks, sgd["hyper"])
+            return
         # grads_zero: the caller guarantees the gradient buffers are zero and written once in this step, so the single writer
         # stores its result instead of reading 50 MB of zeros per launch to add to them
         gemm_multi(1, 1, D, ks, [M] * nh, dys, [D] * nh, xs, ks, [Gs[h][name] for h in H], ks, out_f32=1,

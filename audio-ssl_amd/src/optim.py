@@ -83,7 +83,7 @@ class HipSGD(FlatState, torch.optim.Optimizer):
         self.steps += 1
 
     @torch.no_grad()
-    def step_tail(self, fg, start, stored=()):
+    def step_tail(self, fg, start, stored=(), stepped=False):
         """Step the slice [start, numel) of one flat group now, on the current stream; the next step() covers the rest.
         Used by the fused experts to update the loss-head parameters (83 % of delores_m's buffer) as soon as their
         gradients are final, underneath the encoder backward, instead of in the serial tail of the step.
@@ -95,6 +95,15 @@ class HipSGD(FlatState, torch.optim.Optimizer):
         g0 = self.param_groups[0]
         shadow, zero = self._tail(fg, start, fg.numel)
         segs = self._zero_table(fg, start, stored) if (zero and stored) else None
+        if stepped:
+            # stepped: the `stored` tensors were already updated by their weight-gradient GEMMs (fused_wgrad) - the SGD pass covers the
+            # other tensors of the slice only, and clears their gradients in the same launch
+            if segs is None:
+                raise RuntimeError("step_tail(stepped=True) needs the fused tail and the list of stepped tensors")
+            N.call("sgd_momentum_segments", fg.data, fg.grad, fg.momentum, segs[0], segs[1], segs[2], float(g0["lr"]),
+                   float(g0["momentum"]), float(g0["weight_decay"]), 0, float(self.grad_scale), self.grad_scale_tensor, fg._shadow, 1)
+            fg._early_fused = "partial"
+            return True
         N.call("sgd_momentum", fg.data[start:], fg.grad[start:], fg.momentum[start:], fg.numel - start, float(g0["lr"]),
                float(g0["momentum"]), float(g0["weight_decay"]), 0, float(self.grad_scale), self.grad_scale_tensor, shadow,
                0 if segs is not None else zero)
@@ -102,6 +111,21 @@ class HipSGD(FlatState, torch.optim.Optimizer):
             N.call("zero_segments", fg.grad, segs[0], segs[1], segs[2])
         fg._early_fused = ("partial" if segs is not None else True) if zero else False
         return True
+
+    def fused_wgrad(self, fg, prefixes):
+        """Context for weight-gradient GEMMs that apply this optimiser's update themselves (engine.gemm_multi_sgd): per prefix a
+        dict name -> momentum view, plus the hyper-parameters of the launch.  None while the momentum buffer does not exist (first
+        step) or the fused tail is off."""
+        if fg.momentum is None or not self.fused_refresh or fg._shadow is None:
+            return None
+        key = ("mom", fg.momentum.data_ptr(), tuple(prefixes))
+        views = fg._views.get(key)
+        if views is None:
+            views = fg._views[key] = [{n[len(pre):]: fg.momentum[o:o + p.numel()].view(p.shape)
+                                       for n, p, o in zip(fg.names, fg.params, fg.offsets) if n.startswith(pre)} for pre in prefixes]
+        g0 = self.param_groups[0]
+        return {"momentum": views, "hyper": (float(g0["lr"]), float(g0["momentum"]), float(g0["weight_decay"]), float(self.grad_scale),
+                                             self.grad_scale_tensor)}
 
     def _zero_table(self, fg, start, stored):
         """Device table of the (offset, length) runs of [start, numel) that are NOT gradients of `stored` parameters; None when

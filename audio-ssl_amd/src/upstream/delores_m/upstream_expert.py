@@ -25,6 +25,7 @@ from src.utils import concat_all_gather
 
 _PREP_ASIDE = os.environ.get("AUDIOSSL_PREP_ASIDE", "1") != "0"
 _HEADS_ASIDE = os.environ.get("AUDIOSSL_HEADS_ASIDE", "1") != "0"        # 0: the grouped Barlow heads are issued on the main stream
+_FUSED_SGD = os.environ.get("AUDIOSSL_FUSED_SGD", "1") != "0"          # 0: the heads' weight gradients go through memory to the SGD pass
 _SKIP_ZERO = os.environ.get("AUDIOSSL_SKIP_ZERO", "1") != "0"            # 0: the head-segment SGD clears the whole gradient slice again
 _GRADS_ZERO = os.environ.get("AUDIOSSL_GRADS_ZERO", "1") != "0"          # 0: weight-gradient GEMMs of the heads add to the (zero) buffers
 _DY_EVENT = os.environ.get("AUDIOSSL_DY_EVENT", "1") != "0"              # 0: the main stream waits for the whole heads stream
@@ -136,6 +137,12 @@ class Upstream_Expert(MocoQueueMixin, FusedExpertMixin, UpstreamModule):
         stored_grads = tuple(f"p{i + 1}.projector.{j}.weight" for i in range(3) for j in (0, 3, 6)) \
             if (need_grad and grouped and _GRADS_ZERO and _SKIP_ZERO and E.heads_wgrads_store(D_, kins_, 2 * B)) else ()
 
+        # one rank with the flat SGD: those nine weights are updated in the epilogue of their weight-gradient GEMMs (no gradient written,
+        # none read back); the head-segment SGD pass then covers the small tensors only
+        sgd_ctx = None
+        if stored_grads and _FUSED_SGD and optimizer is not None and not ddp and hasattr(optimizer, "fused_wgrad"):
+            sgd_ctx = optimizer.fused_wgrad(flat, [f"p{i + 1}." for i in range(3)])
+
         # ---- query encoder (main stream)
         def query_phase():
             # clearing the flat gradient and refreshing the bf16 weight shadow are two HBM-bound sweeps (152 MB written,
@@ -198,7 +205,7 @@ class Upstream_Expert(MocoQueueMixin, FusedExpertMixin, UpstreamModule):
                     [loss[4 + i * E.LOSS_REPLICAS:4 + (i + 1) * E.LOSS_REPLICAS] for i in range(3)], update_running=self.training,
                     backward=need_grad, Wcs=[tuple(Wp[f"projector.{j}.weight"] for j in (0, 3, 6)) for Wp in Wps],
                     grads_zero=need_grad and _GRADS_ZERO,          # prep() cleared the flat gradient; each dW has one writer
-                    dy_ready=(lambda: dy_event.record()) if dy_event is not None else None)
+                    dy_ready=(lambda: dy_event.record()) if dy_event is not None else None, sgd=sgd_ctx)
             hs = streams[0] if _HEADS_ASIDE else main
             if not E.ONE_STREAM and _HEADS_ASIDE:
                 E.fork(streams[0], main)
@@ -249,9 +256,13 @@ class Upstream_Expert(MocoQueueMixin, FusedExpertMixin, UpstreamModule):
                 if not E.ONE_STREAM and _SGD_ASIDE and dy_event is None:
                     E.fork(early, main)
                 with torch.cuda.stream(early):
-                    if R.phase("sgd_heads", lambda: optimizer.step_tail(flat, self.head_offset(), stored=stored_grads)):
+                    if R.phase("sgd_heads", lambda: optimizer.step_tail(flat, self.head_offset(), stored=stored_grads,
+                                                                        stepped=sgd_ctx is not None)):
                         optimizer.mark_early(flat, self.head_offset())
                         early_box[0] = early
+                    elif sgd_ctx is not None:
+                        raise RuntimeError("the projector weights were stepped by their weight-gradient GEMMs but the head-segment "
+                                           "SGD pass declined: the optimiser's step() would step them again")
             return dys
 
         # One rank (one captured graph): the fully connected part of the encoder backward needs only the MoCo gradient, so it is

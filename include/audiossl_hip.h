@@ -223,6 +223,14 @@ int audiossl_gemm(int dtype, int trans_a, int trans_b, int M, int N, int K, floa
 int audiossl_gemm_multi(int count, int trans_a, int trans_b, int M, const int* N, const int* K, float alpha,
                         const void* const* A, const long* lda, const void* const* B, const long* ldb, void* const* C,
                         const long* ldc, int out_f32, int atomic, int ksplit, void* stream);
+/* gemm_multi whose fp32 results are weight gradients applied on the spot (no reference counterpart: the reference's optimizer.step()
+ * reads .grad tensors, `delores_m/upstream_expert.py:306-313`): P[i] / Mom[i] ([M][Nv[i]] fp32, leading dimension ldp[i]) take
+ * torch.optim.SGD's update in the epilogue - the arithmetic of audiossl_sgd_momentum bit for bit (common.h: sgd_step) - and
+ * Shadow[i] (bf16, nullable) the copy of the new parameter; the gradient itself is never stored.  One K split. */
+int audiossl_gemm_multi_sgd(int count, int trans_a, int trans_b, int M, const int* Nv, const int* K, float alpha,
+                            const void* const* A, const long* lda, const void* const* B, const long* ldb, float* const* P,
+                            float* const* Mom, void* const* Shadow, const long* ldp, float lr, float momentum, float weight_decay,
+                            float grad_scale, const float* grad_scale_dev, void* stream);
 /* The Barlow-twins cross-correlation of up to four heads with the loss folded into the epilogue (`delores_s/upstream_expert.py:118-131`,
  * `delores_m/upstream_expert.py:266-269`): c_h = alpha * A_h^T B_h, A_h / B_h = the two normalised views [K_h][D] (row-major, K_h =
  * batch rows); stores dc_h = dscale_h * (c_h - I) in bf16 [D][D] and adds coef_h * sum (c_h - I)^2 into loss_rep_h[0..31] (32 fp32
@@ -311,6 +319,11 @@ int audiossl_last_kernel(char* name, int capacity);
 int audiossl_sgd_momentum(float* p, float* g, float* buf, long n, float lr, float momentum, float weight_decay,
                           int first, float grad_scale, const float* grad_scale_dev, void* shadow_bf16, int zero_grad,
                           void* stream);
+/* sgd_momentum over nseg segments of the flat buffers (segs: DEVICE table of (offset, length) pairs in elements, multiples of 4;
+ * max_n = the longest; shadow_bf16 nullable, indexed like p): the remaining tensors of a slice whose large ones gemm_multi_sgd updated. */
+int audiossl_sgd_momentum_segments(float* p, float* g, float* buf, const long* segs, int nseg, long max_n, float lr, float momentum,
+                                   float weight_decay, int first, float grad_scale, const float* grad_scale_dev, void* shadow_bf16,
+                                   int zero_grad, void* stream);
 /* g[segs[2s] .. + segs[2s+1]) = 0 for nseg segments (segs: DEVICE table of (offset, length) pairs in elements, max_n = the longest):
  * clears the small tensors of a flat gradient whose large ones are stored, not accumulated, by their single writer
  * (src/optim.py: HipSGD.step_tail(keep_stale=...)); no reference counterpart - the reference's optimizer.zero_grad() clears all. */

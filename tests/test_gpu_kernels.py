@@ -767,6 +767,36 @@ def test_gemm_multi_hand_scheduled_kernels(N):
             assert rel_l2(c.double().cpu(), ref.cpu()) < (1e-5 if f32 else 4e-3), (ta, tb, m, Ns, Ks)
 
 
+def test_gemm_multi_sgd_epilogue_equals_gemm_then_sgd(N):
+    """`gemm_multi_sgd` (the optimiser's update in the weight-gradient GEMM's epilogue) against the two-launch form it replaces -
+    `gemm_multi` storing the gradient, then `sgd_momentum` with the bf16 shadow - BIT FOR BIT: parameters, momentum, shadow.
+    The heads' shapes (256 x 256 tiles, three problems of different width -> 256 x 128 tiles) and a small ragged one."""
+    from src import engine as E
+    g = torch.Generator().manual_seed(23)
+    lr, mu, wd, gs = 0.05, 0.9, 1e-4, 0.5
+    for D, ks, M in ((2048, [2048, 2048, 2048], 1024), (2048, [2048, 1024, 512], 1024), (264, [136, 72], 200)):
+        nh = len(ks)
+        dys = [(torch.randn(M, D, generator=g) * 0.3).cuda().bfloat16() for _ in range(nh)]
+        xs = [(torch.randn(M, k, generator=g) * 0.3).cuda().bfloat16() for k in ks]
+        P0 = [torch.randn(D, k, generator=g).cuda() for k in ks]
+        M0 = [torch.randn(D, k, generator=g).cuda() for k in ks]
+        # two launches
+        Pa, Ma = [p.clone() for p in P0], [m.clone() for m in M0]
+        Ga = [torch.empty(D, k, device="cuda") for k in ks]
+        Sa = [torch.empty(D, k, device="cuda", dtype=torch.bfloat16) for k in ks]
+        E.gemm_multi(1, 1, D, ks, [M] * nh, dys, [D] * nh, xs, ks, Ga, ks, out_f32=1, atomic=0)
+        for p_, g_, m_, s_ in zip(Pa, Ga, Ma, Sa):
+            N.call("sgd_momentum", p_, g_, m_, p_.numel(), lr, mu, wd, 0, gs, None, s_, 0)
+        # one launch
+        Pb, Mb = [p.clone() for p in P0], [m.clone() for m in M0]
+        Sb = [torch.empty(D, k, device="cuda", dtype=torch.bfloat16) for k in ks]
+        E.gemm_multi_sgd(1, 1, D, ks, [M] * nh, dys, [D] * nh, xs, ks, Pb, Mb, Sb, ks, (lr, mu, wd, gs, None))
+        torch.cuda.synchronize()
+        for h in range(nh):
+            assert torch.equal(Pb[h], Pa[h]) and torch.equal(Mb[h], Ma[h]) and torch.equal(Sb[h], Sa[h]), (D, ks, h)
+            assert not torch.equal(Pb[h], P0[h])
+
+
 _VARIANT_SCRIPT = r"""
 import sys, torch
 sys.path[:0] = [{root!r}, {pkg!r}]

@@ -493,6 +493,45 @@ def test_delores_m_eager_step_orders_main_stream_after_the_heads_weight_gradient
         assert torch.equal(snap, final), f"repetition {rep}: the main stream read the head gradients before they were complete"
 
 
+def test_delores_m_fused_sgd_epilogue_equals_the_separate_sgd_pass(cfg_m, monkeypatch):
+    """Five graph-mode steps (two eager priming steps, capture, replays) with the projector weights stepped inside their
+    weight-gradient GEMMs against the same steps with the gradients written out and stepped by the head-segment SGD pass.  The
+    arithmetic is the same bit for bit (tests/test_gpu_kernels.py); separate executions of the step differ by the order of the fp32
+    atomics elsewhere, so the yardstick is a SECOND run of the unfused form: fused vs unfused must be no further apart than
+    three times unfused vs unfused (+ 1e-6)."""
+    import src.upstream.delores_m.upstream_expert as UM
+    from src.encoder import AudioNTT2020Task6
+    B, T, K = 64, 96, 256
+    runs = []
+    for fused in (True, False, False):
+        monkeypatch.setattr(UM, "_FUSED_SGD", fused)
+        em = UM.Upstream_Expert(_cfg(cfg_m, "bf16"), base_encoder=AudioNTT2020Task6, num_negatives=K)
+        fill.fill_state_dict_(em, seed=12)
+        for pq, pk in zip(em.encoder_q.parameters(), em.encoder_k.parameters()):
+            pk.data.copy_(pq.data)
+        em.queue.copy_(closed_queue(128, K))
+        em = em.cuda().train()
+        opt = em.configure_optimizers()
+        step = em.graphed_step(opt, eager_steps=2)
+        for s_ in range(5):
+            a, b = views(B, T, 8800 + 2 * s_).cuda(), views(B, T, 8801 + 2 * s_).cuda()
+            loss = step(a, b)                                       # dropout masks: the counter-based generator, the same draws in every run
+        torch.cuda.synchronize()
+        fg = em.flat
+        runs.append({"loss": float(loss), "p": fg.data.cpu(), "m": fg.momentum.cpu(), "s": fg._shadow.float().cpu(), "g": fg.grad.cpu(),
+                     "ho": em.head_offset(), "off": dict(zip(fg.names, fg.offsets)), "n": {n: p.numel() for n, p in zip(fg.names, fg.params)}})
+    f, u, u2 = runs
+    ho = f["ho"]
+    for key, lo in (("p", 0), ("m", 0), ("s", 0), ("p", ho), ("m", ho)):
+        noise = rel_l2(u2[key][lo:], u[key][lo:])
+        assert rel_l2(f[key][lo:], u[key][lo:]) <= 3.0 * noise + 1e-6, (key, lo, noise)
+    assert abs(f["loss"] - u["loss"]) <= 3.0 * abs(u2["loss"] - u["loss"]) + 1e-4 * abs(u["loss"])
+    o, n = f["off"]["p2.projector.3.weight"], f["n"]["p2.projector.3.weight"]
+    assert float(f["m"][o:o + n].abs().max()) > 0.0
+    assert float(f["g"][o:o + n].abs().max()) == 0.0                # fused: the gradient of a stepped weight never reaches memory
+    assert float(u["g"][o:o + n].abs().max()) > 0.0                 # unfused: stored by its GEMM, left uncleared (partial clear)
+
+
 def test_nested_stream_fork_is_refused_inside_a_capture_scope():
     """Every side stream of a captured step is forked from the capture's origin stream and joined back into it.  A fork from an
     already forked stream (round 2's experiment with the heads' weight gradients) ended in a segmentation fault inside
