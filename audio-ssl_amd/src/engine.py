@@ -776,8 +776,9 @@ def gemm_multi_sgd(ta, tb, M, Nn, Ks, As, ldas, Bs, ldbs, Ps, Moms, Shadows, ldp
     arrs = (_harr(ctypes.c_int, Ns), _harr(ctypes.c_int, Ks), _harr(vp, As), _harr(ctypes.c_long, ldas), _harr(vp, Bs),
             _harr(ctypes.c_long, ldbs), _harr(vp, Ps), _harr(vp, Moms), _harr(vp, Shadows if Shadows is not None else [None] * n),
             _harr(ctypes.c_long, ldps))
-    if N.PROFILE is not None:
-        N.PROFILE_NOTE = float(sum(2.0 * M * nn * kk for nn, kk in zip(Ns, Ks)))
+    if N.PROFILE is not None:                # (flops, algorithmic bytes: operands + parameter and momentum read / written + shadow)
+        N.PROFILE_NOTE = (float(sum(2.0 * M * nn * kk for nn, kk in zip(Ns, Ks))),
+                          float(sum(2.0 * kk * (M + nn) + M * nn * (16.0 + (2.0 if Shadows is not None else 0.0)) for nn, kk in zip(Ns, Ks))))
     lr, mu, wd, gs, gs_dev = hyper
     N.call("gemm_multi_sgd", n, ta, tb, M, adr(arrs[0]), adr(arrs[1]), float(alpha), adr(arrs[2]), adr(arrs[3]), adr(arrs[4]), adr(arrs[5]),
            adr(arrs[6]), adr(arrs[7]), adr(arrs[8]), adr(arrs[9]), float(lr), float(mu), float(wd), float(gs), gs_dev)
