@@ -274,10 +274,18 @@ class Upstream_Expert(MocoQueueMixin, FusedExpertMixin, UpstreamModule):
         if need_grad:
             def backward_phase():
                 if late:
-                    E.encoder_backward(cq, G("encoder_q.encoder."), dA2=dA2, dx_late=join_heads, grads_zero=_GRADS_ZERO)
-                else:
-                    E.encoder_backward(cq, G("encoder_q.encoder."), dA2=dA2, dx1=dys[0], dx2=dys[1], dx3=dys[2],
-                                       grads_zero=_GRADS_ZERO)
+                    # every loss term is final once the main stream has joined the heads: the sum is taken there, in front of the
+                    # convolution backward, not as one more small launch (+ its gaps) at the serial end of the step
+                    box = [None]
+
+                    def join_and_sum():
+                        d = join_heads()
+                        box[0] = loss.sum()
+                        return d
+                    E.encoder_backward(cq, G("encoder_q.encoder."), dA2=dA2, dx_late=join_and_sum, grads_zero=_GRADS_ZERO)
+                    return box[0]
+                E.encoder_backward(cq, G("encoder_q.encoder."), dA2=dA2, dx1=dys[0], dx2=dys[1], dx3=dys[2],
+                                   grads_zero=_GRADS_ZERO)
                 return loss.sum()
             total = R.phase("encoder_bwd", backward_phase)
             if early_box[0] is not None and not E.ONE_STREAM and _SGD_ASIDE:
