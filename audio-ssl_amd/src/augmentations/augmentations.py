@@ -15,6 +15,7 @@ The reference's FIFO receives every clip twice (once per view).  Entry g of that
 clip g//2, so `bank[k]` resolves to a clip index and the device ring only keeps the last 1025 + B
 distinct normalised clips.  Semantics are those of one sequential stream (DataLoader worker count 0).
 """
+import os
 import random
 
 import numpy as np
@@ -388,9 +389,15 @@ class AugmentationModule:
         if self.bank is None and n is not None:
             self.bank = torch.zeros(self.R, n, dtype=torch.float32, device=device)
 
-    def _upload(self, key, arr, dev, depth=4):
+    def _upload(self, key, arr, dev, depth=int(os.environ.get("AUDIOSSL_UPLOAD_DEPTH", "2"))):
         """Host table -> device through a small ring of PINNED staging buffers.  A pageable source would make the copy
-        synchronous, i.e. one host/device rendezvous per step that keeps the launch side from running ahead."""
+        synchronous, i.e. one host/device rendezvous per step that keeps the launch side from running ahead.
+        The ring is also what bounds HOW FAR the launch side runs ahead (a slot is reused once its copy of `depth` batches ago has
+        completed).  Two batches is enough to keep the device fed (the host needs ~0.8 ms per 2 ms step) and it matters early in a
+        process: with four batches in flight the first ~20 graph replays after start-up contained two 1-2 ms stalls of the DEVICE -
+        the host blocked for 6-12 ms inside an asynchronous copy while the runtime grew its pools, the device ran dry
+        (tools/step_times.py: 2.14 ms per step over bench.py's 20-step window with depth 4, 2.06 with 3, 2.02 with 2; later windows of
+        the same process read 1.98 either way)."""
         ring = self.__dict__.setdefault("_staging", {}).setdefault((key, arr.shape, arr.dtype.str), {"i": 0, "slots": []})
         if len(ring["slots"]) < depth:
             ring["slots"].append([torch.from_numpy(np.empty_like(arr)).pin_memory(), None])

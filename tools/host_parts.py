@@ -33,3 +33,14 @@ for i in range(n):
 th = time.perf_counter() - t00
 torch.cuda.synchronize(); td = time.perf_counter() - t00
 print({k: round(v / n * 1e3, 3) for k, v in parts.items()}, "host total %.3f ms/step, device %.3f ms/step" % (th / n * 1e3, td / n * 1e3))
+if os.environ.get("HOST_PARTS_PROFILE", "1") == "1":
+    # where inside submit does the host wait?  (cProfile over the same loop: a call that blocks on the device shows its wait as tottime)
+    import cProfile, pstats
+    pr = cProfile.Profile()
+    pr.enable()
+    for i in range(n):
+        a, b = front.collect(t); t = front.submit(waves); gstep(a, b)
+    pr.disable()
+    torch.cuda.synchronize()
+    pstats.Stats(pr, stream=sys.stdout).sort_stats("tottime").print_stats(14)
+
