@@ -591,33 +591,41 @@ __global__ __launch_bounds__(256, 3) void conv1_bwd_mfma_kernel(const float* __r
     }
 }
 
-__global__ void conv1_bwd_finalize_kernel(const float* __restrict__ acc, const double* __restrict__ mom,
+// 704 threads: thread i folds entry i of the 32 replicas (fp64, replica order - coalesced across the workgroup; one thread per channel
+// walking 11 x 32 strided loads took 12 us at the serial end of the step), then one thread per (channel, tap) finishes dW
+__global__ __launch_bounds__(704) void conv1_bwd_finalize_kernel(const float* __restrict__ acc, const double* __restrict__ mom,
                                           const float* __restrict__ w, const float* __restrict__ bias,
                                           const float* __restrict__ gamma, const float* __restrict__ mean,
                                           const float* __restrict__ rstd, double count, float* dW, float* dbias,
                                           float* dgamma, float* dbeta, const float* __restrict__ gstat, float* lstat) {
-    const int c = threadIdx.x;
-    if (c >= 64) return;
-    double a11[11];
-    for (int k = 0; k < 11; ++k) {
+    __shared__ double s11[704];                                   // [channel][9 tap sums, dbeta, dgamma]
+    const int i = threadIdx.x;
+    if (i < 704) {
         double t = 0.0;
-        for (int r = 0; r < 32; ++r) t += (double)acc[r * 704 + c * 11 + k];
-        a11[k] = t;
+        for (int r = 0; r < 32; ++r) t += (double)acc[r * 704 + i];
+        s11[i] = t;
     }
-    if (lstat) { lstat[c] = (float)a11[9]; lstat[64 + c] = (float)a11[10]; return; }     // sums only: this rank's (dbeta, dgamma)
-    // SyncBatchNorm: the two means of the BatchNorm backward are over the GLOBAL batch (gstat = all-reduced sums, count global);
-    // the parameter gradients and the tap sums stay this rank's own
-    const double db = gstat ? (double)gstat[c] : a11[9], dg = gstat ? (double)gstat[64 + c] : a11[10];
-    const double rs = rstd[c], mu = mean[c], gm = gamma[c];
-    for (int t = 0; t < 9; ++t) {
+    __syncthreads();
+    if (lstat) {                                                  // sums only: this rank's (dbeta, dgamma)
+        if (i < 64) { lstat[i] = (float)s11[i * 11 + 9]; lstat[64 + i] = (float)s11[i * 11 + 10]; }
+        return;
+    }
+    if (i < 576) {
+        const int c = i / 9, t = i - c * 9;
+        // SyncBatchNorm: the two means of the BatchNorm backward are over the GLOBAL batch (gstat = all-reduced sums, count global);
+        // the parameter gradients and the tap sums stay this rank's own
+        const double db = gstat ? (double)gstat[c] : s11[c * 11 + 9], dg = gstat ? (double)gstat[64 + c] : s11[c * 11 + 10];
+        const double rs = rstd[c], mu = mean[c], gm = gamma[c];
         double wS2 = 0.0;
         for (int a = 0; a < 9; ++a) wS2 += (double)w[c * 9 + a] * mom[9 + (a <= t ? tri(a, t) : tri(t, a))];
         const double yhat_x = rs * (wS2 + ((double)bias[c] - mu) * mom[t]);           // sum_pos yhat_c * x_tap
-        const double v = gm * rs * (a11[t] - db / count * mom[t] - dg / count * yhat_x);
+        const double v = gm * rs * (s11[c * 11 + t] - db / count * mom[t] - dg / count * yhat_x);
         dW[c * 9 + t] += (float)v;
     }
-    dgamma[c] += (float)a11[10];
-    dbeta[c] += (float)a11[9];
+    if (i < 64) {
+        dgamma[i] += (float)s11[i * 11 + 10];
+        dbeta[i] += (float)s11[i * 11 + 9];
+    }
     (void)dbias;            // d(conv bias) is identically zero under train-mode BN
 }
 
@@ -743,7 +751,7 @@ extern "C" int audiossl_conv1_bwd(int dtype, int conv_dtype, const float* img, i
     ASSL_REQUIRE(dW && dgamma && dbeta);
     const int rc = conv1_bwd_main(dtype, conv_dtype, img, N, F, T, w, bias, gamma, scale, shift, mean, rstd, mom, dP, dxl, acc, stream);
     if (rc != ASSL_OK) return rc;
-    hipLaunchKernelGGL(conv1_bwd_finalize_kernel, dim3(1), dim3(64), 0, static_cast<hipStream_t>(stream), acc, mom, w, bias, gamma, mean,
+    hipLaunchKernelGGL(conv1_bwd_finalize_kernel, dim3(1), dim3(704), 0, static_cast<hipStream_t>(stream), acc, mom, w, bias, gamma, mean,
                        rstd, (double)N * F * T, dW, dbias, dgamma, dbeta, (const float*)nullptr, (float*)nullptr);
     ASSL_LAUNCH_CHECK();
 }
@@ -757,7 +765,7 @@ extern "C" int audiossl_conv1_bwd_sums(int dtype, int conv_dtype, const float* i
     ASSL_REQUIRE(lstat);
     const int rc = conv1_bwd_main(dtype, conv_dtype, img, N, F, T, w, bias, gamma, scale, shift, mean, rstd, mom, dP, dxl, acc, stream);
     if (rc != ASSL_OK) return rc;
-    hipLaunchKernelGGL(conv1_bwd_finalize_kernel, dim3(1), dim3(64), 0, static_cast<hipStream_t>(stream), acc, mom, w, bias, gamma, mean,
+    hipLaunchKernelGGL(conv1_bwd_finalize_kernel, dim3(1), dim3(704), 0, static_cast<hipStream_t>(stream), acc, mom, w, bias, gamma, mean,
                        rstd, 1.0, (float*)nullptr, (float*)nullptr, (float*)nullptr, (float*)nullptr, (const float*)nullptr, lstat);
     ASSL_LAUNCH_CHECK();
 }
@@ -765,7 +773,7 @@ extern "C" int audiossl_conv1_bwd_finalize(const float* acc, const double* mom, 
                                            const float* mean, const float* rstd, double count_global, const float* gstat, float* dW,
                                            float* dbias, float* dgamma, float* dbeta, void* stream) {
     ASSL_REQUIRE(acc && mom && w && bias && gamma && mean && rstd && gstat && dW && dgamma && dbeta && count_global > 1.0);
-    hipLaunchKernelGGL(conv1_bwd_finalize_kernel, dim3(1), dim3(64), 0, static_cast<hipStream_t>(stream), acc, mom, w, bias, gamma, mean,
+    hipLaunchKernelGGL(conv1_bwd_finalize_kernel, dim3(1), dim3(704), 0, static_cast<hipStream_t>(stream), acc, mom, w, bias, gamma, mean,
                        rstd, count_global, dW, dbias, dgamma, dbeta, gstat, (float*)nullptr);
     ASSL_LAUNCH_CHECK();
 }
