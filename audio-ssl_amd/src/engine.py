@@ -837,12 +837,19 @@ def barlow_heads_forward_backward(PPs, Gs, Ys, dtype, lambds, scale_losses, loss
     arrs = (_harr(vp, list(Ys)), _harr(vp, ycs), _harr(vp, cms), _harr(ctypes.c_int, kins))
     N.call("center_cast_multi", nh, adr(arrs[0]), adr(arrs[1]), adr(arrs[2]), adr(arrs[3]), 2, B)
     a1, st1, h1 = layer(ycs, [W[h][0] for h in H], kins, "projector.1", True, 1)
-    if update_running:
+
+    def shift_running():
+        # repairs the one thing that sees the centring of the first layer's input (include/audiossl_hip.h: center_cast); nothing in
+        # the step reads the running mean, so with a backward the launch waits until the data-gradient chain is through (it must
+        # still precede the first layer's weight gradient, which - when it carries the SGD update - rewrites the weight shadow)
         rms = [PP["projector.1.running_mean"] for PP in PPs]
         w0 = [W[h][0] for h in H]
         _multi_check(w0, rms)
         arrs = (_harr(vp, w0), _harr(vp, cms), _harr(vp, rms), _harr(ctypes.c_int, kins))
         N.call("shift_running_mean_multi", nh, adr(arrs[0]), adr(arrs[1]), adr(arrs[2]), D, adr(arrs[3]), 2, BN_MOMENTUM)
+    shift_late = update_running and backward and dy_ready is not None      # only then are the weight gradients issued after the chain
+    if update_running and not shift_late:
+        shift_running()
     a2, st2, h2 = layer(h1, [W[h][1] for h in H], [D] * nh, "projector.4", True, 1)
     z, st0, zn = layer(h2, [W[h][2] for h in H], [D] * nh, "bn", False, 0)
     # correlation c_h = zn1^T zn2 / B, loss, dc
@@ -917,8 +924,10 @@ def barlow_heads_forward_backward(PPs, Gs, Ys, dtype, lambds, scale_losses, loss
     dy = dgrad(da1, [W[h][0] for h in H], kins, B)        # dY for view 1 only (rows [0, B)); widths differ per head
     if dy_ready is not None:
         dy_ready()
-        for fn in later:
-            fn()
+    if shift_late:
+        shift_running()
+    for fn in later:
+        fn()
     return dy
 
 
