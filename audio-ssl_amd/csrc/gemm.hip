@@ -1819,6 +1819,14 @@ static int run_bf16(const GemmArgs& g, int trans_a, int trans_b, hipStream_t s) 
     // the hand-scheduled 256 x 256 kernel: AUDIOSSL_GEMM_P8 = 1 forces it wherever it is legal, 0 disables it
     static const int p8 = getenv("AUDIOSSL_GEMM_P8") ? atoi(getenv("AUDIOSSL_GEMM_P8")) : -1;
     const bool p8_ok = K % GBK == 0 && M >= 8 && N >= 8 && (!trans_a || M % 8 == 0) && (!trans_b || N % 8 == 0);
+    // transposed-A problems whose split-K launch fills the chip with 256 x 128 tiles: the software-pipelined kernel with the caller's
+    // split beats the 256 x 256 kernel with the split raised to fill the chip (the encoder's fc.3 weight gradient, 2048 x 2048 x 6144
+    // split in two: 97.4 -> 77.6 us, 664 TFLOP/s; AUDIOSSL_GEMM_P6=0 disables)
+    static const int p6_first = getenv("AUDIOSSL_GEMM_P6") ? atoi(getenv("AUDIOSSL_GEMM_P6")) : -1;
+    if (p6_first != 0 && p8 != 1 && p8_ok && trans_a && g.atomic == 1 && !g.lse_mode && M >= 256 && N >= 128) {
+        const long t6s = (long)ceil_div(M, 256) * ceil_div(N, 128) * ksplit;
+        if (t6s >= 192 && t6s <= 288 && K / ksplit >= 2048) return dispatch_sp<6>(g, trans_a, trans_b, s);
+    }
     if (p8 != 0 && p8_ok && M >= 256 && N >= 256) {
         // measured (tools/gemm_shapes.py, gemm_one.py): it wins once the 256 x 256 tiles occupy at least half of the CUs and every
         // workgroup walks >= 16 K-tiles (6144 x 2048 x 2048 NT 83.9 -> 63.0 us with the bias / ReLU / dropout epilogue, NN 71.0 ->
