@@ -82,6 +82,21 @@ template <> struct Vec8<float> {
     __device__ __forceinline__ void setraw(int i, float x) { set(i, x); }
 };
 
+// ---- counter-based dropout keep bit: keep iff hash(seed, index) >= p * 2^32 (splitmix64 finaliser).  ONE definition for the mask
+// kernel (heads.hip: dropout_mask_kernel) and for the GEMM epilogue that draws the mask of its own elements (gemm.hip): the two
+// produce the same mask from the same (seed, counter).
+__device__ __forceinline__ unsigned long long dropout_seed(unsigned long long seed, const long long* counter) {
+    return counter ? (seed + (unsigned long long)counter[0]) & 0xFFFFFFFFFFFFull : seed;
+}
+__device__ __forceinline__ unsigned int dropout_threshold(float p) { return (unsigned int)fminf(p * 4294967296.f, 4294967295.f); }
+__device__ __forceinline__ unsigned int dropout_keep(unsigned long long seed, long i, unsigned int thr) {
+    unsigned long long z = seed + 0x9E3779B97F4A7C15ull * (unsigned long long)(i + 1);
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    z = z ^ (z >> 31);
+    return ((unsigned int)(z >> 32) >= thr) ? 1u : 0u;
+}
+
 // ---- torch.optim.SGD on one element: g += wd p; buf = first ? g : momentum buf + g; p -= lr buf -------------------------
 // ONE definition with explicit fused multiply-adds for the flat SGD pass (heads.hip) and the weight-gradient GEMM epilogue that
 // applies the update in place (gemm.hip): the two must agree bit for bit, whatever the compiler would contract on its own.

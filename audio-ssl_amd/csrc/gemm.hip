@@ -63,6 +63,12 @@ struct GemmArgs {
     float* sgd_p; float* sgd_m; bf16* sgd_s;
     const float* sgd_gs_dev;  // optional device scalar multiplied into the gradient scale
     float sgd_lr, sgd_mu, sgd_wd, sgd_gs;
+    // dropout drawn in the epilogue (audiossl_gemm_dropout): element (row, col) is kept iff dropout_keep(seed', row * N + col) - the very
+    // mask audiossl_dropout_mask would have written for an [M][N] tensor - and scaled by keep_scale; no mask tensor exists
+    int drop_on;
+    unsigned int drop_thr;
+    unsigned long long drop_seed;
+    const long long* drop_counter;
 };
 
 // kernel names as rocprofv3 prints them (demangled, except for instantiations on __bf16, which its demangler leaves mangled)
@@ -149,6 +155,7 @@ __device__ __forceinline__ void epilogue_lds(const GemmArgs& g, ACC& acc, char* 
             const long row = row0 + min(r0 + u, rows - 1);
             float x = fmaxf(g.alpha * v[u] + bias, floor_);
             if (g.keep) x = g.keep[row * g.ldk + col] ? x * g.keep_scale : 0.f;
+            if (g.drop_on) x = dropout_keep(dropout_seed(g.drop_seed, g.drop_counter), row * g.N + col, g.drop_thr) ? x * g.keep_scale : 0.f;
             if (gate) x = to_f32(gate[row * g.ldg + col]) > 0.f ? x : 0.f;
             if (g.resid) x += g.resid[row * g.ldr + col];
             v[u] = x;
@@ -216,6 +223,11 @@ __device__ __forceinline__ void epilogue_vec(const GemmArgs& g, ACC& acc, char* 
             const unsigned long long k8 = *reinterpret_cast<const unsigned long long*>(g.keep + row * g.ldk + col);
 #pragma unroll
             for (int u = 0; u < 8; ++u) v[u] = ((k8 >> (8 * u)) & 0xFFull) ? v[u] * g.keep_scale : 0.f;
+        }
+        if (g.drop_on) {
+            const unsigned long long sd = dropout_seed(g.drop_seed, g.drop_counter);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = dropout_keep(sd, row * g.N + col + u, g.drop_thr) ? v[u] * g.keep_scale : 0.f;
         }
         if (gate) {
             const Vec8<bf16> gt = Vec8<bf16>::load(gate + row * g.ldg + col);
@@ -1919,6 +1931,29 @@ extern "C" int audiossl_gemm(int dtype, int trans_a, int trans_b, int M, int N, 
     return run_bf16(g, trans_a, trans_b, s);
 }
 
+
+// Linear -> ReLU -> Dropout of the encoder's first fully connected layer (`src/encoder/audiontt.py:62-66`) with the keep mask drawn in
+// the epilogue: C = dropout(relu(alpha * op(A) op(B) + bias)), element (row, col) kept iff dropout_keep(seed', row * N + col) with
+// seed' = (seed + *counter) mod 2^48 - bit for bit the mask audiossl_dropout_mask(keep [M][N], seed, p, counter) writes, which this
+// launch neither needs written (12.6 MB at B = 512) nor read back.  The backward needs no mask: it gates on the stored output.
+extern "C" int audiossl_gemm_dropout(int trans_a, int trans_b, int M, int N, int K, float alpha, const void* A, long lda,
+                                     const void* B, long ldb, void* C, long ldc, const float* bias, int relu,
+                                     unsigned long long seed, float p, const long long* counter, float keep_scale, void* stream) {
+    ASSL_REQUIRE(A && B && C && M > 0 && N > 0 && K > 0 && p >= 0.f && p < 1.f);
+    ASSL_REQUIRE((trans_a ? M : K) % 8 == 0 && (trans_b ? N : K) % 8 == 0);
+    if (!ASSL_ALIGNED16(A) || !ASSL_ALIGNED16(B) || lda % 8 || ldb % 8) return ASSL_EALIGN;
+    const long a_ext = (trans_a ? ((long)(K - 1) * lda + M) : ((long)(M - 1) * lda + K)) * 2;
+    const long b_ext = (trans_b ? ((long)(K - 1) * ldb + N) : ((long)(N - 1) * ldb + K)) * 2;
+    ASSL_REQUIRE(a_ext < 0xFFFFFF00L && b_ext < 0xFFFFFF00L);
+    GemmArgs g{A, B, C, M, N, K, lda, ldb, ldc, alpha, bias, relu, nullptr, 0, keep_scale, nullptr, 0,
+               0, 0, 1, nullptr, 0, (unsigned)a_ext, (unsigned)b_ext, 0};
+    g.vec_epi = epi_vectorisable(g, 1);
+    g.drop_on = 1;
+    g.drop_thr = (unsigned int)fminf(p * 4294967296.f, 4294967295.f);
+    g.drop_seed = seed;
+    g.drop_counter = counter;
+    return run_bf16(g, trans_a, trans_b, static_cast<hipStream_t>(stream));
+}
 
 // MoCo InfoNCE logits  qn [B][dim] * queue [dim][K] / T  with the row soft-max folded into the GEMM epilogue
 // (`src/upstream/delores_m/upstream_expert.py:250-264`): mode 1 writes per-row (max, sum exp) partials of every 64-column

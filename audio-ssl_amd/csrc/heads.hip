@@ -734,15 +734,9 @@ __global__ __launch_bounds__(256) void cast_back_kernel(const T_* __restrict__ s
 // counter-based keep mask: keep iff hash(seed, index) >= p * 2^32  (splitmix64 finaliser)
 __global__ __launch_bounds__(256) void dropout_mask_kernel(uint8_t* __restrict__ keep, long n, unsigned long long seed, float p,
                                                            const long long* __restrict__ counter) {
-    if (counter) seed = (seed + (unsigned long long)counter[0]) & 0xFFFFFFFFFFFFull;
-    const unsigned int thr = (unsigned int)fminf(p * 4294967296.f, 4294967295.f);
-    auto bit = [&](long i) -> unsigned int {
-        unsigned long long z = seed + 0x9E3779B97F4A7C15ull * (unsigned long long)(i + 1);
-        z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
-        z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-        z = z ^ (z >> 31);
-        return ((unsigned int)(z >> 32) >= thr) ? 1u : 0u;
-    };
+    seed = dropout_seed(seed, counter);
+    const unsigned int thr = dropout_threshold(p);
+    auto bit = [&](long i) -> unsigned int { return dropout_keep(seed, i, thr); };
     // 16 mask bytes per thread and trip, one 16-byte store (one byte per lane: 64-byte wave stores, 5x slower)
     const long n16 = ((reinterpret_cast<size_t>(keep) & 15) == 0) ? n / 16 : 0;
     for (long v = (long)blockIdx.x * 256 + threadIdx.x; v < n16; v += (long)gridDim.x * 256) {

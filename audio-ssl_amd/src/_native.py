@@ -133,7 +133,7 @@ def call(name, *args):
         raise RuntimeError(f"{full} failed: {ERRORS.get(rc, rc)}")
 
 
-_GEMM_FAMILY = {"audiossl_gemm", "audiossl_gemm_multi", "audiossl_gemm_multi_sgd", "audiossl_gemm_multi_barlow", "audiossl_moco_logits"}
+_GEMM_FAMILY = {"audiossl_gemm", "audiossl_gemm_dropout", "audiossl_gemm_multi", "audiossl_gemm_multi_sgd", "audiossl_gemm_multi_barlow", "audiossl_moco_logits"}
 
 
 def last_kernel():

@@ -14,6 +14,10 @@ from torch import nn
 from src import _native as N
 from src import engine as E
 
+# 1 (default): the dropout keep mask of the fc block is drawn inside the first fc GEMM's epilogue (bf16 path); 0: written out by
+# `dropout_mask` and read back (12.6 MB each way per encoder pass at B = 512)
+_DROPOUT_IN_GEMM = os.environ.get("AUDIOSSL_DROPOUT_IN_GEMM", "1") != "0"
+
 
 def default_precision():
     return {"fp32": N.F32, "bf16": N.BF16}[os.environ.get("AUDIOSSL_PRECISION", "bf16")]
@@ -55,15 +59,30 @@ class DropoutMasks:
     def calls(self):
         return 0 if self.counter is None else int(self.counter[0])
 
-    def next(self, M, d, device):
+    def next(self, M, d, device, virtual=False):
+        """The next keep mask [M, d] (uint8): a queued one (tests inject the oracle's masks), else drawn by the counter hash.
+        virtual=True: no tensor - a `VirtualKeep` that tells the fc GEMM to draw exactly that mask for its own elements in the
+        epilogue (`audiossl_gemm_dropout`); `.materialise()` writes it out if somebody needs the tensor after all."""
         if self.queue:
             m = self.queue.pop(0)
             return m.reshape(M, d).to(device=device, dtype=torch.uint8).contiguous()
-        keep = torch.empty(M, d, dtype=torch.uint8, device=device)
-        if self.counter is None or self.counter.device != keep.device:
+        if self.counter is None or self.counter.device != torch.device(device):
             self.counter = torch.zeros(1, dtype=torch.int64, device=device)
         self.counter.add_(1)
-        N.call("dropout_mask", keep, M * d, (self.seed * 0x9E3779B1) & 0xFFFFFFFFFFFF, self.p, self.counter)
+        vk = VirtualKeep((self.seed * 0x9E3779B1) & 0xFFFFFFFFFFFF, self.p, self.counter, M, d)
+        return vk if virtual else vk.materialise()
+
+
+class VirtualKeep:
+    """A dropout keep mask that exists as (seed, p, device counter) only.  Valid until the counter is advanced again ON THE DEVICE,
+    i.e. it must be consumed by a launch issued before the next `DropoutMasks.next()` of the same encoder in stream order."""
+
+    def __init__(self, seed, p, counter, M, d):
+        self.seed, self.p, self.counter, self.M, self.d = seed, p, counter, M, d
+
+    def materialise(self):
+        keep = torch.empty(self.M, self.d, dtype=torch.uint8, device=self.counter.device)
+        N.call("dropout_mask", keep, self.M * self.d, self.seed, self.p, self.counter)
         return keep
 
 
@@ -125,7 +144,7 @@ class AudioNTT2020Task6(nn.Module, NetworkCommonMixIn):
     def next_keep_mask(self, n_img, T):
         if not self.training:
             return None
-        return self.dropout_masks.next(n_img * (T // 8), self.d, self.fc[0].weight.device)
+        return self.dropout_masks.next(n_img * (T // 8), self.d, self.fc[0].weight.device, virtual=_DROPOUT_IN_GEMM)
 
     def forward(self, x):
         if not x.is_cuda:

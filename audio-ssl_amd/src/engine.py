@@ -466,9 +466,18 @@ def encoder_forward(P, x, dtype, keep=None, p_drop=0.3, train=True, update_runni
         c.fw1, c.fw2 = Wc["fc.0.weight"], Wc["fc.3.weight"]
     else:
         c.fw1, c.fw2 = cast(dtype, P["fc.0.weight"]), cast(dtype, P["fc.3.weight"])
+    if keep is not None and not isinstance(keep, torch.Tensor) and (dtype != N.BF16 or not train):
+        keep = keep.materialise()        # a virtual mask (encoder.audiontt.VirtualKeep) outside the bf16 training path: write it out
     c.keep = keep if train else None
     scale = 1.0 / (1.0 - p_drop) if c.keep is not None else 1.0
-    c.H1 = linear_fwd(dtype, c.P3, c.fw1, M, d, kin, bias=P["fc.0.bias"], relu=1, keep=c.keep, keep_scale=scale)
+    if c.keep is not None and not isinstance(c.keep, torch.Tensor):
+        # Linear -> ReLU -> Dropout with the mask drawn by the GEMM for its own elements: nothing written, nothing read back
+        vk = c.keep
+        c.H1 = torch.empty(M, d, dtype=torch.bfloat16, device=c.P3.device)
+        N.call("gemm_dropout", 0, 0, M, d, kin, 1.0, c.P3, kin, c.fw1, kin, c.H1, d, P["fc.0.bias"], 1, vk.seed, float(vk.p), vk.counter,
+               float(scale))
+    else:
+        c.H1 = linear_fwd(dtype, c.P3, c.fw1, M, d, kin, bias=P["fc.0.bias"], relu=1, keep=c.keep, keep_scale=scale)
     c.H2 = linear_fwd(dtype, c.H1, c.fw2, M, d, d, bias=P["fc.3.bias"], relu=1)
     return x1, x2, x3, c.H2.view(Nimg, T3, d), c
 

@@ -87,6 +87,8 @@ def _work(entry, a):
         return "mfma", 2.0 * n * ti * fi * 64 * 576, 1
     if entry == "gemm":
         return "mfma", 2.0 * a[3] * a[4] * a[5], a[0]
+    if entry == "gemm_dropout":                 # (trans_a, trans_b, M, N, K, ...): the fc GEMM that draws its dropout mask itself
+        return "mfma", 2.0 * a[2] * a[3] * a[4], 1
     if entry == "colbn_train_fwd":
         return "hbm", float(a[5] * a[6] * a[7] * (ES[a[1]] + ES[a[0]])), 0
     if entry == "colbn_train_fwd_multi":
@@ -141,6 +143,8 @@ def per_kernel_report(prof, prof_steps, step_ms):
             key = entry
             if entry == "gemm":
                 key = f"gemm<{'bf16' if a[0] else 'f32'},{GEMM_SYMBOL[(a[1], a[2])]}>"
+            elif entry == "gemm_dropout":
+                key = f"gemm<bf16,{GEMM_SYMBOL[(a[0], a[1])]}>"
             elif entry == "gemm_multi":
                 key = f"gemm_multi<{GEMM_SYMBOL[(a[1], a[2])]}>"
                 w = ("mfma", note, 1) if note else None

@@ -217,6 +217,14 @@ int audiossl_gemm(int dtype, int trans_a, int trans_b, int M, int N, int K, floa
                   float keep_scale, const void* gate, long ldg, int out_f32, int atomic, int ksplit, const float* resid,
                   long ldr, void* stream);
 
+/* bf16 Linear -> ReLU -> Dropout (`src/encoder/audiontt.py:62-66`: fc block of AudioNTT2020Task6) with the keep mask DRAWN in the
+ * epilogue: C (bf16) = dropout(relu(alpha op(A) op(B) + bias)) * keep_scale, element (row, col) kept iff the counter hash of
+ * audiossl_dropout_mask says so for index row * N + col (seed' = (seed + *counter) mod 2^48; counter nullable) - the same mask, never
+ * stored.  The backward gates on the stored output (gate argument of audiossl_gemm), it needs no mask either. */
+int audiossl_gemm_dropout(int trans_a, int trans_b, int M, int N, int K, float alpha, const void* A, long lda, const void* B,
+                          long ldb, void* C, long ldc, const float* bias, int relu, unsigned long long seed, float p,
+                          const long long* counter, float keep_scale, void* stream);
+
 /* `count` (<= 4) independent bf16 problems of one kind in one launch (the three Barlow heads of delores_m): same M,
  * transposes and epilogue (alpha, fp32 / accumulating output, split-K), per-problem N, K, operand pointers and leading
  * dimensions.  N, K, A, lda, B, ldb, C, ldc are HOST arrays of `count` entries. */

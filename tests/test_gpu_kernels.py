@@ -767,6 +767,31 @@ def test_gemm_multi_hand_scheduled_kernels(N):
             assert rel_l2(c.double().cpu(), ref.cpu()) < (1e-5 if f32 else 4e-3), (ta, tb, m, Ns, Ks)
 
 
+def test_gemm_dropout_draws_the_mask_the_mask_kernel_writes(N):
+    """`gemm_dropout` (Linear -> ReLU -> Dropout with the keep mask drawn in the epilogue) against `gemm` fed with the mask that
+    `dropout_mask` writes for the same (seed, p, counter): BIT FOR BIT, on the encoder's fc.0 shapes at two batch sizes (the K-step-32
+    kernel with half-height epilogue tiles and the 128-row kernels) and a ragged one (one-column-per-lane epilogue), with and
+    without the device counter."""
+    from src import engine as E
+    g = torch.Generator().manual_seed(29)
+    for M, Nn, K, use_counter in ((6144, 2048, 512, True), (768, 2048, 512, True), (200, 264, 72, False)):
+        A = (torch.randn(M, K, generator=g) * 0.5).cuda().bfloat16()
+        W = (torch.randn(Nn, K, generator=g) * 0.1).cuda().bfloat16()
+        bias = torch.randn(Nn, generator=g).cuda()
+        counter = torch.tensor([41], dtype=torch.int64, device="cuda") if use_counter else None
+        seed, p = 0x1234ABCD5E, 0.3
+        keep = torch.empty(M, Nn, dtype=torch.uint8, device="cuda")
+        N.call("dropout_mask", keep, M * Nn, seed, p, counter)
+        want = torch.empty(M, Nn, device="cuda", dtype=torch.bfloat16)
+        E.gemm(N.BF16, 0, 0, M, Nn, K, A, K, W, K, want, Nn, bias=bias, relu=1, keep=keep, ldk=Nn, keep_scale=1.0 / (1.0 - p))
+        got = torch.full((M, Nn), float("nan"), device="cuda", dtype=torch.bfloat16)
+        N.call("gemm_dropout", 0, 0, M, Nn, K, 1.0, A, K, W, K, got, Nn, bias, 1, seed, p, counter, 1.0 / (1.0 - p))
+        torch.cuda.synchronize()
+        assert torch.equal(got, want), (M, Nn, K)
+        frac = float(keep.float().mean())
+        assert abs(frac - (1.0 - p)) < 0.01
+
+
 def test_gemm_multi_sgd_epilogue_equals_gemm_then_sgd(N):
     """`gemm_multi_sgd` (the optimiser's update in the weight-gradient GEMM's epilogue) against the two-launch form it replaces -
     `gemm_multi` storing the gradient, then `sgd_momentum` with the bf16 shadow - BIT FOR BIT: parameters, momentum, shadow.
