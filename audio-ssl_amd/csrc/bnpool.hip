@@ -244,8 +244,25 @@ __global__ __launch_bounds__(256) void bn_relu_pool_bwd_kernel(const TY* __restr
                                                                const float* __restrict__ scale, const float* __restrict__ shift,
                                                                const float* __restrict__ mean, const float* __restrict__ rstd,
                                                                float* __restrict__ stat, float inv_count,
-                                                               T_* __restrict__ dY, int N, int Ti, int Fi) {
+                                                               T_* __restrict__ dY, int N, int Ti, int Fi, int fold,
+                                                               float* dgamma, float* dbeta) {
     __shared__ float red[256][16];
+    // APPLY with fold: the 32 replicas of the statistics pass are folded here, once per workgroup and in replica order (what the
+    // stat_reduce launch between the two passes did), and workgroup 0 adds the sums to the parameter gradients (the add_stat
+    // launch behind the apply pass): two small launches and their gaps off the serial chain of the convolution backward
+    __shared__ float folded[128];
+    if (APPLY && fold) {
+        if (threadIdx.x < 128) {
+            float t = 0.f;
+            for (int r = 0; r < 32; ++r) t += stat[128 + r * 128 + threadIdx.x];
+            folded[threadIdx.x] = t;
+        }
+        __syncthreads();
+        if (blockIdx.x == 0 && threadIdx.x < 64 && dgamma) {
+            dbeta[threadIdx.x] += folded[threadIdx.x];
+            dgamma[threadIdx.x] += folded[64 + threadIdx.x];
+        }
+    }
     const int To = Ti / 2, Fo = Fi / 2;
     const int Tq = (Ti + 1) / 2;                 // quads along time, the last one may be half outside the pooled area
     const long total = (long)N * Tq * Fo * 8;
@@ -266,7 +283,7 @@ __global__ __launch_bounds__(256) void bn_relu_pool_bwd_kernel(const TY* __restr
         for (int i = 0; i < 8; ++i) {
             const int c = c8 * 8 + i;
             sc[i] = scale[c]; sh[i] = shift[c]; mu[i] = mean[c]; rs[i] = rstd[c]; g[i] = 0.f;
-            if (APPLY) { cb[i] = stat[c] * inv_count; cg[i] = stat[64 + c] * inv_count; }
+            if (APPLY) { cb[i] = (fold ? folded[c] : stat[c]) * inv_count; cg[i] = (fold ? folded[64 + c] : stat[64 + c]) * inv_count; }
         }
         if (pooled) {
             const Vec8<TG> gp = Vec8<TG>::load(dP + ((((long)n * To + tq) * Fo + fo) * 64 + c8 * 8));
@@ -580,13 +597,14 @@ static int bn_relu_pool_bwd_run(int phase, int dtype, int ydtype, int gdtype, co
     const float inv_To = 1.f / (float)(Ti / 2);
     const float inv_count = (float)(1.0 / (phase == 2 ? count : (double)N * Ti * Fi));
     float* apply_stat = phase == 2 ? const_cast<float*>(gstat) : stat;
+    const int fold = phase == 0;               // one rank: fold + parameter gradients inside the apply pass (no stat_reduce / add_stat launch)
 #define BW(TY, AP, TG, TO, ST) hipLaunchKernelGGL((bn_relu_pool_bwd_kernel<TY, AP, TG, TO>), dim3(grid), dim3(256), 0, s,              \
         static_cast<const TY*>(Y), static_cast<const TG*>(dP), static_cast<const TG*>(dxl), inv_To, scale, shift, mean, rstd, ST, \
-        inv_count, static_cast<TO*>(dY), N, Ti, Fi)
+        inv_count, static_cast<TO*>(dY), N, Ti, Fi, (AP) ? fold : 0, dgamma, dbeta)
 #define BWP(TG, TO) hipLaunchKernelGGL((bn_pool_bwd_stats_p_kernel<TO, TG>), dim3(pgrid), dim3(256), 0, s, static_cast<const TO*>(P),          \
         static_cast<const TG*>(dP), static_cast<const TG*>(dxl), inv_To, scale, shift, mean, rstd, stat, N, Ti / 2, Fi / 2)
 #define BW2(TY, TG, TO) do { if (phase != 2) { if (P) BWP(TG, TO); else BW(TY, false, TG, TO, stat);                                       \
-                                               hipLaunchKernelGGL(stat_reduce_kernel, dim3(1), dim3(128), 0, s, stat); }                     \
+                                               if (!fold) hipLaunchKernelGGL(stat_reduce_kernel, dim3(1), dim3(128), 0, s, stat); }          \
                              if (phase != 1) BW(TY, true, TG, TO, apply_stat); } while (0)
     const long ptotal = (long)N * (Ti / 2) * (Fi / 2) * 8;
     const int pgrid = (int)min((long)2048, (ptotal + 255) / 256);         // 2,048 x 256 threads: a multiple of 8, see the kernel
@@ -598,7 +616,7 @@ static int bn_relu_pool_bwd_run(int phase, int dtype, int ydtype, int gdtype, co
 #undef BW2
 #undef BWP
 #undef BW
-    if (phase != 1) hipLaunchKernelGGL(add_stat_kernel, dim3(1), dim3(64), 0, s, stat, dgamma, dbeta);
+    if (phase == 2) hipLaunchKernelGGL(add_stat_kernel, dim3(1), dim3(64), 0, s, stat, dgamma, dbeta);
     ASSL_LAUNCH_CHECK();
 }
 
