@@ -14,6 +14,9 @@ def short(n):
     return (m.group(1) if m else n.split("(")[0])[:34]
 for r in ev[a:b]:
     s, e = int(r["Start_Timestamp"]) - t0, int(r["End_Timestamp"]) - t0
-    grid = r.get("Grid_Size_X") or r.get("Grid_Size") or ""
+    if r.get("Grid_Size_X"):                       # total work-items of the launch (all three grid dimensions)
+        grid = int(r["Grid_Size_X"]) * int(r.get("Grid_Size_Y") or 1) * int(r.get("Grid_Size_Z") or 1)
+    else:
+        grid = r.get("Grid_Size") or ""
     print(f"{s/1e3:9.1f} {(e-s)/1e3:8.1f} q{r.get('Queue_Id','?'):>3} g{grid:>9} {short(r['Kernel_Name'])}")
 print("step wall %.1f us" % ((int(ev[b]["Start_Timestamp"]) - t0) / 1e3))
