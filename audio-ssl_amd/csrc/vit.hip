@@ -91,6 +91,92 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
     for (int c = threadIdx.x; c < C; c += 256) { atomicAdd(dgamma + c, sg[c]); atomicAdd(dbeta + c, sb[c]); }
 }
 
+// The same with 16-byte accesses (C % 4 == 0: lane l owns the float4 chunks l, l + 64, ...) and TWO rows of a wave in flight: the
+// one-dword-per-lane form above moved 1.6 TB/s on AST-base's 27,648 x 768 launches (212 us each, 12 % of the SS-MAST step) - every
+// row was a load -> two wave reductions -> read-modify-write chain with nothing else outstanding.
+template <int NV>
+__global__ __launch_bounds__(256) void layernorm_bwd_vec_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                                const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                                const float* __restrict__ gamma, float* __restrict__ dres,
+                                                                float* __restrict__ dgamma, float* __restrict__ dbeta, int M, int C) {
+    __shared__ float sg[1024], sb[1024];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int nch = C >> 2;                                          // float4 chunks per row
+    for (int c = threadIdx.x; c < C; c += 256) { sg[c] = 0.f; sb[c] = 0.f; }
+    __syncthreads();
+    f32x4 gm[NV], pg[NV], pb[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int ch = lane + 64 * i;
+        gm[i] = ch < nch ? *reinterpret_cast<const f32x4*>(gamma + ch * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+        pg[i] = f32x4{0.f, 0.f, 0.f, 0.f}; pb[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    const int row0 = blockIdx.x * LN_ROWS + wave * (LN_ROWS / 4);
+    for (int k = 0; k < LN_ROWS / 4; k += 2) {
+        f32x4 d[2][NV], xv[2][NV], rv[2][NV];
+        float mu[2], rs[2];
+        bool live[2];
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {                                // both rows' loads are issued before anything is reduced
+            const int row = row0 + k + r;
+            live[r] = row < M;
+            mu[r] = live[r] ? mean[row] : 0.f;
+            rs[r] = live[r] ? rstd[row] : 0.f;
+#pragma unroll
+            for (int i = 0; i < NV; ++i) {
+                const int ch = lane + 64 * i;
+                const bool on = live[r] && ch < nch;
+                const long o = (long)row * C + ch * 4;
+                d[r][i] = on ? *reinterpret_cast<const f32x4*>(dy + o) : f32x4{0.f, 0.f, 0.f, 0.f};
+                xv[r][i] = on ? *reinterpret_cast<const f32x4*>(x + o) : f32x4{0.f, 0.f, 0.f, 0.f};
+                rv[r][i] = on ? *reinterpret_cast<const f32x4*>(dres + o) : f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            if (!live[r]) continue;                                  // wave-uniform
+            float s1 = 0.f, s2 = 0.f;
+            f32x4 g[NV], xh[NV];
+#pragma unroll
+            for (int i = 0; i < NV; ++i) {
+                const bool on = lane + 64 * i < nch;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float xe = on ? (xv[r][i][e] - mu[r]) * rs[r] : 0.f;
+                    const float ge = d[r][i][e] * gm[i][e];
+                    xh[i][e] = xe; g[i][e] = ge;
+                    s1 += ge; s2 += ge * xe;
+                    pg[i][e] += d[r][i][e] * xe;
+                    pb[i][e] += d[r][i][e];
+                }
+            }
+            s1 = wave_sum(s1) / (float)C;
+            s2 = wave_sum(s2) / (float)C;
+            const int row = row0 + k + r;
+#pragma unroll
+            for (int i = 0; i < NV; ++i) {
+                const int ch = lane + 64 * i;
+                if (ch < nch) {
+                    f32x4 o4;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o4[e] = rv[r][i][e] + rs[r] * (g[i][e] - s1 - xh[i][e] * s2);
+                    *reinterpret_cast<f32x4*>(dres + (long)row * C + ch * 4) = o4;
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int ch = lane + 64 * i;
+        if (ch < nch) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { atomicAdd(&sg[ch * 4 + e], pg[i][e]); atomicAdd(&sb[ch * 4 + e], pb[i][e]); }
+        }
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < C; c += 256) { atomicAdd(dgamma + c, sg[c]); atomicAdd(dbeta + c, sb[c]); }
+}
+
 __device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752f)); }
 __device__ __forceinline__ float gelu_d(float x) {
     return 0.5f * (1.f + erff(x * 0.70710678118654752f)) + x * 0.3989422804014327f * __expf(-0.5f * x * x);
@@ -197,6 +283,15 @@ extern "C" int audiossl_layernorm_fwd(const float* x, const float* gamma, const 
 extern "C" int audiossl_layernorm_bwd(const float* dy, const float* x, const float* mean, const float* rstd, const float* gamma,
                                       float* dres, float* dgamma, float* dbeta, int M, int C, void* stream) {
     ASSL_REQUIRE(dy && x && mean && rstd && gamma && dres && dgamma && dbeta && M > 0 && C > 0 && C <= 64 * LN_MAX);
+    const bool vec = C % 4 == 0 && ASSL_ALIGNED16(dy) && ASSL_ALIGNED16(x) && ASSL_ALIGNED16(dres) && ASSL_ALIGNED16(gamma);
+    if (vec) {
+        const int nv = ceil_div(C / 4, 64);                      // float4 chunks per lane: 1 ... 4
+#define LNB(NV_) hipLaunchKernelGGL(layernorm_bwd_vec_kernel<NV_>, dim3(ceil_div(M, LN_ROWS)), dim3(256), 0, S_(stream), dy, x, mean, rstd, \
+                                    gamma, dres, dgamma, dbeta, M, C)
+        if (nv == 1) LNB(1); else if (nv == 2) LNB(2); else if (nv == 3) LNB(3); else LNB(4);
+#undef LNB
+        ASSL_LAUNCH_CHECK();
+    }
     hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(ceil_div(M, LN_ROWS)), dim3(256), 0, S_(stream), dy, x, mean, rstd, gamma, dres,
                        dgamma, dbeta, M, C);
     ASSL_LAUNCH_CHECK();
