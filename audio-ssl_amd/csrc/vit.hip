@@ -43,6 +43,66 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restr
     if (lane == 0) { mean[row] = mu; rstd[row] = rs; }
 }
 
+// The same with 16-byte loads, 8-byte bf16 stores (C % 4 == 0) and two rows per wave in flight (the dword form stored 2 bytes per lane:
+// 47.6 us per 27,648 x 768 launch, 2.7 TB/s)
+template <int NV>
+__global__ __launch_bounds__(256) void layernorm_fwd_vec_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                                const float* __restrict__ beta, bf16* __restrict__ y,
+                                                                float* __restrict__ y32, float* __restrict__ mean,
+                                                                float* __restrict__ rstd, int M, int C, float eps) {
+    const int lane = threadIdx.x & 63, nch = C >> 2;
+    const int row0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 2;
+    if (row0 >= M) return;
+    f32x4 v[2][NV];
+    const bool live1 = row0 + 1 < M;
+#pragma unroll
+    for (int r = 0; r < 2; ++r)
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int ch = lane + 64 * i;
+            const bool on = ch < nch && (r == 0 || live1);
+            v[r][i] = on ? *reinterpret_cast<const f32x4*>(x + (long)(row0 + r) * C + ch * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    f32x4 gm[NV], bt[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int ch = lane + 64 * i;
+        gm[i] = ch < nch ? *reinterpret_cast<const f32x4*>(gamma + ch * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+        bt[i] = ch < nch ? *reinterpret_cast<const f32x4*>(beta + ch * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        if (r == 1 && !live1) break;
+        const int row = row0 + r;
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < NV; ++i)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) s += v[r][i][e];                       // chunks past the row are zeros
+        const float mu = wave_sum(s) / (float)C;
+        float q = 0.f;
+#pragma unroll
+        for (int i = 0; i < NV; ++i)
+            if (lane + 64 * i < nch) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { const float d = v[r][i][e] - mu; q += d * d; }
+            }
+        const float rs = rsqrtf(wave_sum(q) / (float)C + eps);
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int ch = lane + 64 * i;
+            if (ch < nch) {
+                f32x4 o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = (v[r][i][e] - mu) * rs * gm[i][e] + bt[i][e];
+                *reinterpret_cast<bf16x4*>(y + (long)row * C + ch * 4) = bf16x4{(bf16)o[0], (bf16)o[1], (bf16)o[2], (bf16)o[3]};
+                if (y32) *reinterpret_cast<f32x4*>(y32 + (long)row * C + ch * 4) = o;
+            }
+        }
+        if (lane == 0) { mean[row] = mu; rstd[row] = rs; }
+    }
+}
+
 // dres[row] += dx,  dx = rstd * (g - mean_c(g) - xhat * mean_c(g * xhat)),  g = dy * gamma
 // dgamma += sum_rows dy * xhat, dbeta += sum_rows dy   (per-workgroup partials in LDS, then one atomic per column)
 constexpr int LN_ROWS = 64;      // rows per workgroup (16 per wave)
@@ -275,6 +335,16 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const
 extern "C" int audiossl_layernorm_fwd(const float* x, const float* gamma, const float* beta, void* y, float* y32, float* mean, float* rstd,
                                       int M, int C, float eps, void* stream) {
     ASSL_REQUIRE(x && gamma && beta && y && mean && rstd && M > 0 && C > 0 && C <= 64 * LN_MAX);
+    const bool vec = C % 4 == 0 && ASSL_ALIGNED16(x) && ASSL_ALIGNED16(gamma) && ASSL_ALIGNED16(beta) &&
+                     (reinterpret_cast<size_t>(y) & 7) == 0 && (!y32 || ASSL_ALIGNED16(y32));
+    if (vec) {
+        const int nv = ceil_div(C / 4, 64);
+#define LNF(NV_) hipLaunchKernelGGL(layernorm_fwd_vec_kernel<NV_>, dim3(ceil_div(M, 8)), dim3(256), 0, S_(stream), x, gamma, beta, \
+                                    static_cast<bf16*>(y), y32, mean, rstd, M, C, eps)
+        if (nv == 1) LNF(1); else if (nv == 2) LNF(2); else if (nv == 3) LNF(3); else LNF(4);
+#undef LNF
+        ASSL_LAUNCH_CHECK();
+    }
     hipLaunchKernelGGL(layernorm_fwd_kernel, dim3(ceil_div(M, 4)), dim3(256), 0, S_(stream), x, gamma, beta, static_cast<bf16*>(y),
                        y32, mean, rstd, M, C, eps);
     ASSL_LAUNCH_CHECK();
