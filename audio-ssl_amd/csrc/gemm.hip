@@ -1852,7 +1852,10 @@ static int run_bf16(const GemmArgs& g, int trans_a, int trans_b, hipStream_t s) 
             ga.ksplit = ks;
         }
         const bool layout_ok = p8 != 2 || (!trans_a && !trans_b);            // AUDIOSSL_GEMM_P8=2: K-contiguous operands only
-        if (p8 == 1 || (layout_ok && t256 * ga.ksplit >= 128 && K / ga.ksplit >= 1024))
+        // ... and with 12 K-tiles once the grid is several rounds deep (the transformer blocks' K = 768 layers at 27,648 rows:
+        // 27648 x 2304 x 768 NT 188.6 -> 140.5 us, x 3072 235.3 -> 181.2, x 768 63.9 -> 53.2 against the K-step-32 kernel)
+        const bool deep = t256 * ga.ksplit >= 512 && K / ga.ksplit >= 768;
+        if (p8 == 1 || (layout_ok && t256 * ga.ksplit >= 128 && (K / ga.ksplit >= 1024 || deep)))
             return sp_mask() & 8 ? dispatch_sp<8>(ga, trans_a, trans_b, s) : dispatch_p8(ga, trans_a, trans_b, s);
     }
     // the hand-scheduled 256 x 128 kernel (written for the multi-problem launches of the projector heads, see dispatch_multi):
