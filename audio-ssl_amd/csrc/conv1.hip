@@ -93,44 +93,56 @@ __global__ __launch_bounds__(256) void conv1_moments_kernel(const float* __restr
     }
 }
 
-// 64 threads, one per output channel.
-__global__ void conv1_finalize_kernel(double* __restrict__ momr, const float* __restrict__ w,
+// 576 threads = (channel, tap a): the 81 covariances once per workgroup, per thread the row sum_b w_b cov(a, b), then the 9 rows of
+// a channel folded in tap order by its first thread.  (One thread per channel walking all 81 products after a serial fold of the
+// replicas: 9 us at the head of both encoder chains.)
+__global__ __launch_bounds__(576) void conv1_finalize_kernel(double* __restrict__ momr, const float* __restrict__ w,
                                       const float* __restrict__ bias, const float* __restrict__ gamma,
                                       const float* __restrict__ beta, float* running_mean, float* running_var,
                                       float momentum, float eps, double count, float* scale, float* shift,
                                       float* save_mean, float* save_rstd, int repl) {
-    const int c = threadIdx.x;
-    if (c >= 64) return;
-    // fold the replicas into mom[0..53] (kept for the backward), then every channel reads the totals
     __shared__ double tot[NMOM];
-    if (c < NMOM) {
+    __shared__ double cov[81];
+    __shared__ double rowv[64][9], rowm[64][9];
+    const int i = threadIdx.x;
+    // fold the replicas into mom[0..53] (kept for the backward), then every channel reads the totals
+    if (i < NMOM) {
         double t = 0.0;
-        for (int r = 0; r < repl; ++r) t += momr[r * NMOM + c];
-        tot[c] = t;
+        for (int r = 0; r < repl; ++r) t += momr[r * NMOM + i];
+        tot[i] = t;
     }
     __syncthreads();
-    if (c < NMOM) momr[c] = tot[c];
-    const double* mom = tot;
-    double mean = 0.0, var = 0.0;
-    for (int a = 0; a < 9; ++a) mean += (double)w[c * 9 + a] * mom[a];
-    mean = mean / count;
-    for (int a = 0; a < 9; ++a)
-        for (int b = 0; b < 9; ++b) {
-            const double s2 = mom[9 + (a <= b ? tri(a, b) : tri(b, a))] / count;
-            const double cov = s2 - (mom[a] / count) * (mom[b] / count);
-            var += (double)w[c * 9 + a] * (double)w[c * 9 + b] * cov;
+    if (i < NMOM) momr[i] = tot[i];
+    if (i < 81) {
+        const int a = i / 9, bb = i - a * 9;
+        const double s2 = tot[9 + (a <= bb ? tri(a, bb) : tri(bb, a))] / count;
+        cov[i] = s2 - (tot[a] / count) * (tot[bb] / count);
+    }
+    __syncthreads();
+    const int c = i / 9, a = i - (i / 9) * 9;
+    if (i < 576) {
+        double r = 0.0;
+        for (int bb = 0; bb < 9; ++bb) r += (double)w[c * 9 + bb] * cov[a * 9 + bb];
+        rowv[c][a] = (double)w[c * 9 + a] * r;
+        rowm[c][a] = (double)w[c * 9 + a] * tot[a];
+    }
+    __syncthreads();
+    if (i < 576 && a == 0) {
+        double mean = 0.0, var = 0.0;
+        for (int k = 0; k < 9; ++k) { mean += rowm[c][k]; var += rowv[c][k]; }
+        mean = mean / count;
+        var = var < 0.0 ? 0.0 : var;
+        mean += (double)bias[c];
+        const double rstd = 1.0 / sqrt(var + (double)eps);
+        const float sc = (float)((double)gamma[c] * rstd);
+        scale[c] = sc;
+        shift[c] = (float)((double)beta[c] - mean * (double)gamma[c] * rstd);
+        save_mean[c] = (float)mean;
+        save_rstd[c] = (float)rstd;
+        if (running_mean) {
+            running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mean;
+            running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)(var * count / (count - 1.0));
         }
-    var = var < 0.0 ? 0.0 : var;
-    mean += (double)bias[c];
-    const double rstd = 1.0 / sqrt(var + (double)eps);
-    const float sc = (float)((double)gamma[c] * rstd);
-    scale[c] = sc;
-    shift[c] = (float)((double)beta[c] - mean * (double)gamma[c] * rstd);
-    save_mean[c] = (float)mean;
-    save_rstd[c] = (float)rstd;
-    if (running_mean) {
-        running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mean;
-        running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)(var * count / (count - 1.0));
     }
 }
 
@@ -651,7 +663,7 @@ extern "C" int audiossl_conv1_stats(const float* img, int N, int F, int T, const
     // every workgroup ends with 54 fp64 atomics; on ONE set of 54 addresses they serialise at the memory side -
     // MOM_REPL replicas of the accumulator, folded by the finalize kernel
     launch_moments(img, mom, N, F, T, s);
-    hipLaunchKernelGGL(conv1_finalize_kernel, dim3(1), dim3(64), 0, s, mom, w, bias, gamma, beta, running_mean,
+    hipLaunchKernelGGL(conv1_finalize_kernel, dim3(1), dim3(576), 0, s, mom, w, bias, gamma, beta, running_mean,
                        running_var, momentum, eps, (double)total, scale, shift, save_mean, save_rstd, MOM_REPL);
     ASSL_LAUNCH_CHECK();
 }
@@ -682,7 +694,7 @@ extern "C" int audiossl_conv1_finalize(double* mom_totals, const float* w, const
                                        float* running_mean, float* running_var, float momentum, float eps, double count,
                                        float* scale, float* shift, float* save_mean, float* save_rstd, void* stream) {
     ASSL_REQUIRE(mom_totals && w && bias && gamma && beta && scale && shift && save_mean && save_rstd && count > 1.0);
-    hipLaunchKernelGGL(conv1_finalize_kernel, dim3(1), dim3(64), 0, static_cast<hipStream_t>(stream), mom_totals, w, bias, gamma, beta,
+    hipLaunchKernelGGL(conv1_finalize_kernel, dim3(1), dim3(576), 0, static_cast<hipStream_t>(stream), mom_totals, w, bias, gamma, beta,
                        running_mean, running_var, momentum, eps, count, scale, shift, save_mean, save_rstd, 1);
     ASSL_LAUNCH_CHECK();
 }
